@@ -1,0 +1,257 @@
+/*
+ * claxon_hip.h -- C ABI of the MI355X (gfx950) batched FLAC frame decoder.
+ *
+ * This is the drop-in boundary for ONE path of ruuda/claxon: per-subframe
+ * decode (src/subframe.rs) plus stereo decorrelation (src/frame.rs), executed
+ * for a whole batch of independent frames by hand-written HIP kernels.
+ * Every entry point below names the reference interface it replaces
+ * (file:line into the claxon v0.4.3 tree).  Plain pointers and sizes only;
+ * no exceptions, panics or C++/torch types cross this boundary.
+ *
+ * Threading: a clx_ctx / clx_batch is NOT thread safe (the reference takes
+ * `&mut self` everywhere, frame.rs:667); distinct contexts (one per GPU / per
+ * HIP stream) may be used concurrently.
+ *
+ * Memory: "device" pointers are HIP device pointers on the context's GPU.
+ * A device arena must be 16-byte aligned and its ALLOCATION must cover
+ * arena_len rounded up to a multiple of 16 bytes (the kernels stage the
+ * bitstream with 16-byte granules; bytes past arena_len are never interpreted).
+ */
+#ifndef CLAXON_HIP_H
+#define CLAXON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLX_VERSION_MAJOR 0
+#define CLX_VERSION_MINOR 1
+#define CLX_VERSION_PATCH 0
+
+/* ------------------------------------------------------------------------
+ * Error convention.  Replaces `claxon::Error` (error.rs:18-32):
+ *   IoError(io::Error) | FormatError(&'static str) | Unsupported(&'static str)
+ * Equality in the reference is variant + string (error.rs:34-45) and its tests
+ * compare strings (tests/testsamples.rs:412), so the strings are API: each
+ * clx_msg maps 1:1 to the reference's message (clx_message()).
+ * ---------------------------------------------------------------------- */
+typedef enum clx_status {
+    CLX_OK          = 0,
+    CLX_IO_ERROR    = 1,  /* Error::IoError(UnexpectedEof): bits ran out mid-frame (input.rs:139-142, 242) */
+    CLX_FORMAT_ERROR= 2,  /* Error::FormatError(msg) */
+    CLX_UNSUPPORTED = 3,  /* Error::Unsupported(msg) */
+    CLX_END_OF_STREAM = 4,/* Ok(None): EOF before the two sync bytes (frame.rs:140-143) */
+    CLX_API_ERROR   = 5   /* bad argument / HIP failure; no reference analogue */
+} clx_status;
+
+typedef enum clx_msg {
+    CLX_MSG_NONE = 0,
+    CLX_MSG_UNEXPECTED_EOF,              /* io::ErrorKind::UnexpectedEof */
+    /* subframe.rs */
+    CLX_MSG_SUBFRAME_HEADER_INVALID,     /* subframe.rs:32  */
+    CLX_MSG_SUBFRAME_HEADER_RESERVED,    /* subframe.rs:47,55 */
+    CLX_MSG_WASTED_BITS_EXCEED_31,       /* subframe.rs:83  */
+    CLX_MSG_NO_NON_WASTED_BITS,          /* subframe.rs:199 */
+    CLX_MSG_RESIDUAL_RESERVED,           /* subframe.rs:245 */
+    CLX_MSG_INVALID_PARTITION_ORDER,     /* subframe.rs:263 */
+    CLX_MSG_INVALID_RESIDUAL,            /* subframe.rs:276 */
+    CLX_MSG_FIXED_ORDER_GT_BLOCK,        /* subframe.rs:500 */
+    CLX_MSG_LPC_ORDER_GT_BLOCK,          /* subframe.rs:663 */
+    CLX_MSG_QLP_PRECISION_INVALID,       /* subframe.rs:674 */
+    CLX_MSG_UNENCODED_BINARY,            /* subframe.rs:318,366 (Unsupported) */
+    CLX_MSG_NEGATIVE_QLP_SHIFT,          /* subframe.rs:688-690 (Unsupported) */
+    /* frame.rs */
+    CLX_MSG_FRAME_CRC_MISMATCH,          /* frame.rs:761 */
+    CLX_MSG_FRAME_HEADER_CRC_MISMATCH,   /* frame.rs:300 */
+    CLX_MSG_FRAME_SYNC_MISSING,          /* frame.rs:148 */
+    CLX_MSG_FRAME_HEADER_RESERVED,       /* frame.rs:157,177,224,236,241 */
+    CLX_MSG_FRAME_HEADER_INVALID,        /* frame.rs:210 */
+    CLX_MSG_FRAME_NUMBER_TOO_LARGE,      /* frame.rs:255 */
+    CLX_MSG_BLOCK_SIZE_EXCEEDS_65535,    /* frame.rs:273 */
+    CLX_MSG_INVALID_VARINT,              /* frame.rs:82,98 */
+    CLX_MSG_NO_BPS_IN_HEADER,            /* frame.rs:691 (Unsupported) */
+    /* lib.rs / metadata.rs (stream open; host only) */
+    CLX_MSG_INVALID_STREAM_HEADER,       /* lib.rs:200 */
+    CLX_MSG_ID3_HEADER,                  /* lib.rs:198 */
+    CLX_MSG_STREAMINFO_MISSING,          /* lib.rs:247 */
+    CLX_MSG_SECOND_STREAMINFO,           /* lib.rs:268 */
+    CLX_MSG_STREAMINFO_LENGTH,           /* metadata.rs:272 */
+    CLX_MSG_INVALID_METADATA_BLOCK_TYPE, /* metadata.rs:305 */
+    CLX_MSG_MIN_BLOCK_GT_MAX_BLOCK,      /* metadata.rs:361 */
+    CLX_MSG_BLOCK_SIZE_LT_16,            /* metadata.rs:364 */
+    CLX_MSG_MIN_FRAME_GT_MAX_FRAME,      /* metadata.rs:367 */
+    CLX_MSG_INVALID_SAMPLE_RATE,         /* metadata.rs:373 */
+    CLX_MSG_APPLICATION_BLOCK_TOO_SHORT, /* metadata.rs:527 */
+    CLX_MSG_APPLICATION_BLOCK_TOO_LARGE, /* metadata.rs:534 (Unsupported) */
+    CLX_MSG_COUNT
+} clx_msg;
+
+/* The reference's exact message string for `msg` ("" for CLX_MSG_NONE). */
+const char* clx_message(uint32_t msg);
+/* The status (error variant) the reference attaches to `msg`. */
+int clx_message_status(uint32_t msg);
+/* (major<<16)|(minor<<8)|patch */
+uint32_t clx_version(void);
+
+/* ------------------------------------------------------------------------
+ * Frame headers (host).  Replaces `read_frame_header_or_eof` (frame.rs:131-316)
+ * and `read_var_length_int` (frame.rs:64-105), incl. the CRC-8 check
+ * (crc.rs:62-93) -- byte-aligned, ~6-16 bytes per frame, not accelerated.
+ * ---------------------------------------------------------------------- */
+enum { CLX_CH_INDEPENDENT = 0, CLX_CH_LEFT_SIDE = 1, CLX_CH_RIGHT_SIDE = 2, CLX_CH_MID_SIDE = 3 };
+
+typedef struct clx_frame_header {
+    uint64_t time;               /* first sample number: block_size*frame_number or sample number (frame.rs:771-774) */
+    uint32_t sample_rate;        /* 0 = "get from streaminfo" (frame.rs:193) */
+    uint32_t frame_or_sample_lo; /* low 32 bits of the coded number */
+    uint16_t block_size;
+    uint16_t header_bytes;       /* bytes consumed incl. the CRC-8 */
+    uint8_t  n_channels;
+    uint8_t  channel_assignment; /* CLX_CH_* */
+    uint8_t  bps;                /* 0 = "get from streaminfo" -> Unsupported at decode (frame.rs:687-692) */
+    uint8_t  variable_blocking;
+} clx_frame_header;
+
+/* Parse one frame header from `p[0..avail)`.  Returns a clx_status; on error
+ * *msg holds the clx_msg.  CLX_END_OF_STREAM iff fewer than 2 bytes are
+ * available (frame.rs:140-143).  `check_crc`=0 mirrors cfg(fuzzing). */
+int clx_parse_frame_header(const uint8_t* p, size_t avail, int check_crc,
+                           clx_frame_header* out, uint32_t* msg);
+
+/* CRC helpers (crc.rs:89-113): CRC-8 poly 0x07, CRC-16 poly 0x8005, init 0, MSB first. */
+uint8_t  clx_crc8(const uint8_t* p, size_t n);
+uint16_t clx_crc16(const uint8_t* p, size_t n);
+
+/* ------------------------------------------------------------------------
+ * Batch decode (device).  Replaces, for n frames at once, the body of
+ * `FrameReader::read_next_or_eof` between header parse and footer
+ * (frame.rs:699-750): `subframe::decode` per channel on one bit cursor
+ * (subframe.rs:184-228, called from frame.rs:708,715,716,725,726,734,735)
+ * and `decode_left_side/right_side/mid_side` (frame.rs:319-389).
+ * ---------------------------------------------------------------------- */
+typedef struct clx_frame_desc {
+    uint64_t byte_off;      /* frame start (sync code) in the arena */
+    uint32_t max_bytes;     /* bytes readable from byte_off (rest of stream, or packet length) */
+    uint16_t header_bytes;  /* first subframe starts at byte_off+header_bytes, bit 0 */
+    uint16_t block_size;    /* 1..65535 */
+    uint8_t  n_channels;    /* 1..8 */
+    uint8_t  channel_assignment; /* CLX_CH_* */
+    uint8_t  bps;           /* header bps (side channels decode at bps+1 on device) */
+    uint8_t  reserved[5];
+} clx_frame_desc;           /* 24 bytes */
+
+typedef struct clx_frame_result {
+    int32_t  status;        /* clx_status */
+    uint32_t msg;           /* clx_msg */
+    uint64_t end_bit;       /* bit offset (from byte_off) just past the last subframe;
+                               the CRC-16 sits at byte ceil(end_bit/8) (frame.rs:744-754) */
+} clx_frame_result;         /* 16 bytes */
+
+typedef struct clx_ctx   clx_ctx;
+typedef struct clx_batch clx_batch;
+
+/* Create a context bound to HIP device `device`.  Fails (CLX_API_ERROR) when no
+ * gfx950 device / HIP runtime is usable: there is NO CPU fallback. */
+int  clx_create(int device, clx_ctx** out);
+void clx_destroy(clx_ctx* ctx);
+/* Human-readable text of the last CLX_API_ERROR on this context. */
+const char* clx_last_error(const clx_ctx* ctx);
+
+/* Flags for clx_decode_frames */
+enum {
+    CLX_ARENA_ON_DEVICE = 1u << 0,   /* arena is a device pointer (else host; copied H2D) */
+    CLX_OUT_ON_DEVICE   = 1u << 1,   /* out is a device pointer (else host; copied D2H)   */
+    CLX_VERIFY_CRC16    = 1u << 2    /* also verify each frame's CRC-16 footer on device
+                                        (frame.rs:752-763); mismatch -> CLX_MSG_FRAME_CRC_MISMATCH */
+};
+
+/* One-shot convenience: plan + run + fetch results.  `out` is planar i32
+ * (channel c of frame i at out[out_sample_offsets[i] + c*block_size ...),
+ * frame.rs:409-410,477-481).  `results[i]` receives frame i's status. */
+int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,
+                      const clx_frame_desc* frames, size_t n,
+                      int32_t* out, const uint64_t* out_sample_offsets,
+                      clx_frame_result* results, uint32_t flags);
+
+/* Config-2 entry: n independent byte-aligned SUBFRAMES (no frame header):
+ * subframe i starts at arena[byte_offs[i]], decoded at bps[i] into
+ * out[out_sample_offsets[i] .. +block_size[i]).  = `subframe::decode` (subframe.rs:184). */
+int clx_decode_subframes(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,
+                         const uint64_t* byte_offs, const uint16_t* block_sizes,
+                         const uint8_t* bps, size_t n,
+                         int32_t* out, const uint64_t* out_sample_offsets,
+                         clx_frame_result* results, uint32_t flags);
+
+/* Planned batch: descriptors uploaded once, then run any number of times on
+ * device-resident data (what bench.py times).  `stream` is a hipStream_t
+ * (NULL = the context's own stream). */
+int  clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
+                      const uint64_t* out_sample_offsets, uint32_t flags, clx_batch** out);
+int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
+                   int32_t* d_out, void* stream);
+/* Blocks until the last run finished, then copies the per-frame results to host. */
+int  clx_batch_results(clx_batch* b, clx_frame_result* results);
+/* Number of predictor slots (subframes incl. alignment padding) in the plan. */
+uint64_t clx_batch_slots(const clx_batch* b);
+/* Per-kernel HIP-event timing of the LAST run made with profiling enabled.
+ * kernel: 0 = rice_residual_decode, 1 = predict_decorrelate, 2 = crc16_verify. */
+int  clx_batch_set_profiling(clx_batch* b, int enable);
+int  clx_batch_kernel_ms(clx_batch* b, int kernel, float* ms);
+void clx_batch_destroy(clx_batch* b);
+
+/* ------------------------------------------------------------------------
+ * Stream API (host C++ classes claxon::FlacReader / FrameReader / Block live
+ * in claxon_amd/csrc/host/claxon.hpp; these are their C handles so that any
+ * FFI can reach them).  Replaces FlacReader::{new,open,streaminfo,blocks}
+ * (lib.rs:217-458) and FrameReader::read_next_or_eof (frame.rs:667) for a
+ * stream held in memory; frames are indexed on the host and decoded on the
+ * device in batches.
+ * ---------------------------------------------------------------------- */
+typedef struct clx_streaminfo {          /* metadata.rs:24-54 */
+    uint16_t min_block_size, max_block_size;
+    uint32_t min_frame_size, max_frame_size;   /* 0 = unknown (None) */
+    uint32_t sample_rate, channels, bits_per_sample;
+    uint64_t samples;                          /* 0 = unknown (None) */
+    uint8_t  md5sum[16];
+} clx_streaminfo;
+
+typedef struct clx_block_info {          /* frame.rs:402-411 (Block) */
+    uint64_t time;
+    uint32_t block_size;
+    uint32_t channels;
+} clx_block_info;
+
+typedef struct clx_reader clx_reader;
+
+/* Parse the `fLaC` marker + metadata blocks of an in-memory stream
+ * (lib.rs:186-205, 230-307; metadata.rs:214-400).  *audio_offset = first frame byte. */
+int clx_read_stream_header(const uint8_t* data, size_t len, clx_streaminfo* info,
+                           size_t* audio_offset, uint32_t* msg);
+
+int  clx_reader_open(clx_ctx* ctx, const char* path, clx_reader** out, uint32_t* msg);       /* lib.rs:455 */
+int  clx_reader_new(clx_ctx* ctx, const uint8_t* data, size_t len, clx_reader** out, uint32_t* msg); /* lib.rs:217 */
+int  clx_reader_streaminfo(const clx_reader* r, clx_streaminfo* out);                        /* lib.rs:312 */
+/* read_next_or_eof: decodes (in device batches, lazily) and hands out the next
+ * block.  `buffer` (capacity `cap` i32) receives channels*block_size planar
+ * samples.  CLX_END_OF_STREAM at the end; errors as the reference. */
+int  clx_reader_next_block(clx_reader* r, int32_t* buffer, size_t cap,
+                           clx_block_info* info, uint32_t* msg);                             /* frame.rs:667 */
+void clx_reader_close(clx_reader* r);
+
+/* Host-side frame indexer for a contiguous stream: locates frame starts by
+ * sync code + CRC-8-valid header, confirmed by the previous frame's CRC-16
+ * (frame.rs:131-316 grammar; the reference has no resync, frame.rs:601-602).
+ * Writes up to `cap` descriptors/headers; returns the number found in *n_found.
+ * Stops at the first position where the chain cannot be continued and reports
+ * that byte offset in *stop_off. */
+int clx_index_frames(const uint8_t* data, size_t len, size_t start_off,
+                     clx_frame_desc* descs, clx_frame_header* headers, size_t cap,
+                     size_t* n_found, size_t* stop_off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAXON_HIP_H */

@@ -1,0 +1,190 @@
+"""Pins the CPU oracle (oracle/claxon_oracle.c) against every known-answer vector
+the reference's own unit tests hold for the hot path.  The
+numbers below are the reference's test data (file:line cited per test)."""
+import numpy as np
+import pytest
+
+from conftest import fixture_bytes  # noqa: F401
+
+
+# ---------------------------------------------------------------- crc.rs:197-209
+def test_crc8_vectors(oracle):
+    assert oracle.crc8(bytes([0x1f])) == 0x5d
+    assert oracle.crc8(bytes([0x04, 0x01])) == 0x53
+    assert oracle.crc8(b"abc") == 0x5f
+
+
+def test_crc16_vectors(oracle):
+    assert oracle.crc16(bytes([0x1f])) == 0x8041
+    assert oracle.crc16(bytes([0x04, 0x01])) == 0x1806
+    assert oracle.crc16(b"abc") == 0xcadb
+
+
+# ---------------------------------------------------------------- subframe.rs:103-140, 172-179
+def test_extend_sign_u16(oracle):
+    f = oracle.lib().clxo_extend_sign_u16
+    assert f(5, 4) == 5
+    assert f(0x3ffe, 15) == 0x3ffe
+    assert f(16 - 5, 4) == -5
+    assert f(512 - 3, 9) == -3
+    assert f(0xffff, 16) == -1
+    assert f(0xfffe, 16) == -2
+    assert f(0x7fff, 15) == -1
+
+
+def test_extend_sign_u32(oracle):
+    f = oracle.lib().clxo_extend_sign_u32
+    assert f(5, 4) == 5
+    assert f(0x3ffffffe, 31) == 0x3ffffffe
+    assert f(16 - 5, 4) == -5
+    assert f(512 - 3, 9) == -3
+    assert f(0xfffe, 16) == -2
+    assert f(0xffffffff, 32) == -1
+    assert f(0xfffffffe, 32) == -2
+    assert f(0x7fffffff, 31) == -1
+    # samples from a real FLAC stream (subframe.rs:135-139)
+    assert f(124680, 17) == -6392
+    assert f(124467, 17) == -6605
+    assert f(124222, 17) == -6850
+    assert f(124011, 17) == -7061
+
+
+def test_rice_to_signed(oracle):
+    f = oracle.lib().clxo_rice_to_signed
+    assert [f(i) for i in range(5)] == [0, -1, 1, -2, 2]
+
+
+# ---------------------------------------------------------------- subframe.rs:476-490
+def test_predict_fixed(oracle):
+    buf = [-729, -722, -667, -19, -16, 17, -23, -7, 16, -16, -5, 3, -8, -13, -15, -1]
+    want = [-729, -722, -667, -583, -486, -359, -225, -91, 59, 209, 354, 497, 630, 740, 812, 845]
+    assert oracle.predict_fixed(3, buf).tolist() == want
+    # i32 overflow trap
+    assert oracle.predict_fixed(2, [21877, 27482, -6513]).tolist() == [21877, 27482, 26574]
+
+
+# ---------------------------------------------------------------- subframe.rs:616-649
+def test_predict_lpc(oracle):
+    coefs = [-75, 166, 121, -269, -75, -399, 1042]
+    buf = [-796, -547, -285, -32, 199, 443, 670, -2, -23, 14, 6, 3, -4, 12, -2, 10]
+    want = [-796, -547, -285, -32, 199, 443, 670, 875, 1046, 1208, 1343, 1454, 1541, 1616, 1663, 1701]
+    assert oracle.predict_lpc(coefs, 9, buf).tolist() == want
+
+    coefs = [119, -255, 555, -836, 879, -1199, 1757]
+    buf = [-21363, -21951, -22649, -24364, -27297, -26870, -30017, 3157]
+    assert oracle.predict_lpc(coefs, 10, buf).tolist() == buf[:7] + [-29718]
+
+    coefs = [709, -2589, 4600, -4612, 1350, 4220, -9743, 12671, -12129, 8586,
+             -3775, -645, 3904, -5543, 4373, 182, -6873, 13265, -15417, 11550]
+    buf = [213238, 210830, 234493, 209515, 235139, 201836, 208151, 186277, 157720, 148176,
+           115037, 104836, 60794, 54523, 412, 17943, -6025, -3713, 8373, 11764, 30094]
+    assert oracle.predict_lpc(coefs, 12, buf).tolist() == buf[:20] + [33931]
+
+
+# ---------------------------------------------------------------- frame.rs:336-342, 362-368, 391-399
+RESULT_LR = [2, 5, 83, 113, 127, -63, -45, -15, -5, -33, -59, -125, 127, 89, 7, 3]
+
+
+def test_decode_left_side(oracle):
+    buf = [2, 5, 83, 113, 127, -63, -45, -15, 7, 38, 142, 238, 0, -152, -52, -18]
+    assert oracle.decorrelate("left_side", buf).tolist() == RESULT_LR
+
+
+def test_decode_right_side(oracle):
+    buf = [7, 38, 142, 238, 0, -152, -52, -18, -5, -33, -59, -125, 127, 89, 7, 3]
+    assert oracle.decorrelate("right_side", buf).tolist() == RESULT_LR
+
+
+def test_decode_mid_side(oracle):
+    buf = [-2, -14, 12, -6, 127, 13, -19, -6, 7, 38, 142, 238, 0, -152, -52, -18]
+    assert oracle.decorrelate("mid_side", buf).tolist() == RESULT_LR
+
+
+# ---------------------------------------------------------------- frame.rs:107-129
+def test_read_var_length_int(oracle):
+    data = bytes([0x24, 0xc2, 0xa2, 0xe2, 0x82, 0xac, 0xf0, 0x90, 0x8d, 0x88, 0xc2, 0x00, 0x80])
+    r = oracle.read_var_length_ints(data, 6)
+    assert [x[1] for x in r[:4]] == [0x24, 0xa2, 0x20ac, 0x010348]
+    assert all(x[0] == oracle.STATUS_OK for x in r[:4])
+    # two-byte integer with invalid continuation byte; continuation byte first
+    from claxon_msgs import MSG
+    assert r[4][0] == oracle.STATUS_FORMAT and r[4][2] == MSG["CLX_MSG_INVALID_VARINT"]
+    assert r[5][0] == oracle.STATUS_FORMAT and r[5][2] == MSG["CLX_MSG_INVALID_VARINT"]
+
+
+# ---------------------------------------------------------------- input.rs:645-777 (Bitstream)
+def _run(oracle, data, script):
+    return oracle.bitstream_script(bytes(data), script)
+
+
+def test_read_bit(oracle):
+    script = [("bit", 0)] * 3 + [("leq_u8", 1)] + [("bit", 0)] * 4 + [("bit", 0)] * 3 + [("leq_u8", 2)] + \
+             [("bit", 0)] * 3 + [("bit", 0)]
+    r = _run(oracle, [0b10100100, 0b11100001], script)
+    vals = [v for v, _ in r]
+    assert vals[:16] == [1, 0, 1, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 1][:15] + [vals[15]]
+    assert all(okk for _, okk in r[:15])
+    assert not r[15][1]   # read_bit past the end is an error
+
+
+def test_read_unary(oracle):
+    data = [0b10100100, 0b10000000, 0b00100000, 0b00000000, 0b00001010]
+    script = [("unary", 0)] * 6 + [("leq_u8", 3), ("bit", 0)]
+    r = _run(oracle, data, script)
+    assert [v for v, _ in r[:7]] == [0, 1, 2, 2, 9, 17, 0b010]
+    assert all(okk for _, okk in r[:7])
+    assert not r[7][1]
+
+
+def test_read_leq_u8(oracle):
+    data = [0b10100101, 0b11100001, 0b11010010, 0b01010101, 0b01110011, 0b00111111, 0b10101010, 0b00001100]
+    widths = [0, 1, 1, 2, 2, 3, 3, 4, 5, 6, 7, 8, 6, 8, 4, 1, 1, 2]
+    want = [0, 1, 0, 0b10, 0b01, 0b011, 0b110, 0b0001, 0b11010, 0b010010, 0b1010101, 0b11001100,
+            0b111111, 0b10101010, 0b0000, 1, 1, 0b00]
+    r = _run(oracle, data, [("leq_u8", w) for w in widths])
+    assert [v for v, _ in r] == want
+    assert all(okk for _, okk in r)
+
+
+def test_read_gt_u8_leq_u16(oracle):
+    data = [0b10100101, 0b11100001, 0b11010010, 0b01010101, 0b11110000]
+    script = [("gt_u8_leq_u16", 10), ("gt_u8_leq_u16", 10), ("leq_u8", 3), ("gt_u8_leq_u16", 10),
+              ("leq_u8", 7), ("gt_u8_leq_u16", 10)]
+    r = _run(oracle, data, script)
+    assert [v for v, _ in r[:5]] == [0b1010010111, 0b1000011101, 0b001, 0b0010101011, 0b1110000]
+    assert not r[5][1]
+
+
+def test_read_leq_u16(oracle):
+    data = [0b10100101, 0b11100001, 0b11010010, 0b01010101]
+    r = _run(oracle, data, [("leq_u16", 0), ("leq_u16", 1), ("leq_u16", 13), ("leq_u16", 9)])
+    assert [v for v, _ in r] == [0, 1, 0b0100101111000, 0b011101001]
+
+
+def test_read_leq_u32(oracle):
+    data = [0b10100101, 0b11100001, 0b11010010, 0b01010101]
+    r = _run(oracle, data, [("leq_u32", 1), ("leq_u32", 17), ("leq_u32", 14)])
+    assert [v for v, _ in r] == [1, 0b01001011110000111, 0b01001001010101]
+
+
+def test_read_mixed(oracle):
+    # warm-up samples from an actual stream (input.rs:760-777)
+    data = [0x03, 0xc7, 0xbf, 0xe5, 0x9b, 0x74, 0x1e, 0x3a, 0xdd, 0x7d, 0xc5, 0x5e, 0xf6, 0xbf, 0x78, 0x1b, 0xbd]
+    r = _run(oracle, data, [("leq_u8", 6), ("leq_u8", 1)] + [("leq_u32", 17)] * 7)
+    assert r[0][0] == 0 and r[1][0] == 1
+    minus = 1 << 16
+    want = [-14401, -13514, -12168, -10517, -9131, -8489, -8698]
+    assert [v for v, _ in r[2:]] == [minus | (w & 0xffff) for w in want]
+    # and through the sign extension used by decode_verbatim
+    f = oracle.lib().clxo_extend_sign_u32
+    assert [f(v, 17) for v, _ in r[2:]] == want
+
+
+# ---------------------------------------------------------------- frame.rs:531-543, 582-597 (Block indexing)
+def test_block_planar_indexing():
+    # Block::sample(ch, i) == buffer[ch*bs + i]; this is the layout contract of the C ABI.
+    buf = np.array([2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47])
+    bs = 5
+    assert buf[0 * bs + 2] == 5 and buf[1 * bs + 3] == 23 and buf[2 * bs + 4] == 47
+    bs = 3  # stereo_samples iterator yields (buffer[i], buffer[i+bs])
+    assert [(buf[i], buf[i + bs]) for i in range(bs)] == [(2, 7), (3, 11), (5, 13)]
