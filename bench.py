@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- decoded Msamples/s of the batched FLAC frame decode hot path on MI355X.
+
+A "step" = one pass of the hot path (K1 Rice/residual decode, K2 predictor + decorrelation) over one
+batch of synthetic frames whose compressed bytes, descriptors and output buffer are already resident
+in HBM.  Workload at every N: BASELINE.json configs[2] -- 10 000 stereo 16-bit frames, block size
+4096, mid/side, both subframes LPC order 8 (SURVEY.md §8d "config 3") -- per GPU (weak scaling:
+frames are independent, ranks share nothing, no collective on the data path).
+
+One JSON line on rank 0; see DESIGN.md §6 for how roofline / cpu_baseline are derived.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config: 10000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-crc", action="store_true", help="also run the CRC-16 kernel inside the step")
+    args = ap.parse_args()
+
+    import torch
+    import claxon_amd as cx
+    import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- synthetic workload for this rank (distinct seeds per rank: frame indices are offset)
+    t_gen = time.time()
+    w = synth.config3(args.frames) if rank == 0 else _config3_shard(synth, args.frames, rank)
+    gen_s = time.time() - t_gen
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
+
+    ctx = cx.Context(local_rank)
+    d_arena = torch.from_numpy(w.arena).to(dev)
+    d_out = torch.zeros(w.pcm.size, dtype=torch.int32, device=dev)
+    batch = ctx.plan(descs, w.out_offs, verify_crc=args.verify_crc)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- parity gate before anything is timed: statuses OK and bit-exact vs the source PCM
+    res = batch.results()
+    ok = bool(np.all(res["status"] == 0)) and bool(torch.equal(d_out, torch.from_numpy(w.pcm).to(dev)))
+    if not ok:
+        raise SystemExit("bench: decode is not bit-exact; refusing to report a number")
+
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    samples_per_step_all = w.total_samples * world
+    value = samples_per_step_all / (ms_per_step * 1e-3) / 1e6
+
+    # ---- per-kernel durations (HIP events recorded by the library on the launch stream)
+    batch.set_profiling(True)
+    k_ms = [[], [], []]
+    for _ in range(max(5, min(args.steps, 20))):
+        step()
+        torch.cuda.synchronize()
+        for k in range(3 if args.verify_crc else 2):
+            k_ms[k].append(batch.kernel_ms(k))
+    batch.set_profiling(False)
+    k1 = float(np.mean(k_ms[0])); k2 = float(np.mean(k_ms[1]))
+    names = ["clx_k_residual", "clx_k_predict"]
+    dom = 0 if k1 >= k2 else 1
+    dom_ms = max(k1, k2)
+    alg_bytes = w.algorithmic_bytes          # compressed bytes read once + 4 B per decoded sample written once
+    peak = 8000.0                            # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = _pmc_traffic(names[dom])
+    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "kernel_ms": {names[0]: round(k1, 4), names[1]: round(k2, 4)},
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "step_achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / peak, 4)}
+
+    out = {
+        "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32 (i64 LPC accumulate)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 "
+                               "(precision 12), Rice partition order 4, optimal k" % args.frames,
+                   "frames_per_gpu": args.frames, "samples_per_step": samples_per_step_all,
+                   "compressed_bytes_per_gpu": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
+                   "parallelism": "frames sharded across %d GPU(s), no collective" % world,
+                   "bit_exact": True, "crc16_in_step": bool(args.verify_crc), "gen_seconds": round(gen_s, 1)},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = _cpu_baseline(w)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _config3_shard(synth, n, rank):
+    """Rank r decodes frames with PCM seeds offset by r*n (distinct data, same distribution)."""
+    base = synth.BASE_SEED
+    synth.BASE_SEED = base + rank * 1_000_003
+    try:
+        return synth.config3(n)
+    finally:
+        synth.BASE_SEED = base
+
+
+def _cpu_baseline(w):
+    """The oracle (a C restatement of Claxon's decode path, `kind: port`; real Claxon is Rust and cannot be
+    built here) on this box's host cores, decoding the same arena from memory with per-thread recycled output
+    buffers (examples/bench_decode.rs:55-78 methodology)."""
+    import oracle
+    ncpu = os.cpu_count() or 1
+    arena = w.arena[:w.arena_len]
+
+    def run(nthreads, reps):
+        best = 0.0
+        for _ in range(reps):
+            t = time.perf_counter()
+            r = oracle.decode_batch(arena, w.offs, w.lens, check_crc=True, nthreads=nthreads, want_results=False)
+            dt = time.perf_counter() - t
+            assert r["samples"] == w.total_samples
+            best = max(best, r["samples"] / dt / 1e6)
+        return best
+
+    run(1, 1)                                   # warm
+    single = run(1, 3)
+    multi = run(ncpu, 5) if ncpu > 1 else single
+    return {"value": round(multi, 1), "unit": "Msamples/s", "cores": ncpu, "kind": "port",
+            "single_thread": round(single, 1),
+            "sample": "the full step workload (%d frames = %.1f Msamples), best of 5 passes on %d threads; "
+                      "single_thread = best of 3 passes on 1 thread; includes Claxon's per-byte CRC-16" %
+                      (w.n, w.total_samples / 1e6, ncpu)}
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary of this same command, if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

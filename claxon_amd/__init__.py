@@ -1,0 +1,454 @@
+"""claxon_amd -- MI355X (gfx950) batched FLAC frame decoder behind Claxon's FrameReader/Block API.
+
+This package is a thin ctypes binding of the C ABI in ``include/claxon_hip.h``
+(implemented by ``claxon_amd/csrc`` as ``libclaxon_hip.so``: hand-written HIP
+kernels + a C++ host layer).  It exists so that tests and ``bench.py`` can drive
+the library; the product is the shared library.
+
+There is no CPU decode path: creating a :class:`Context` raises when the
+library or a gfx950 device is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libclaxon_hip.so")
+
+OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
+CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)
+ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16 = 1, 2, 4
+
+
+class ClaxonError(RuntimeError):
+    """Mirrors claxon::Error (error.rs:18-32): .status is the variant, .message the reference's string."""
+
+    def __init__(self, status, msg=0, text=None):
+        self.status, self.msg = status, msg
+        self.message = text if text is not None else (message(msg) if _lib is not None else "")
+        super().__init__("status %d: %s" % (status, self.message))
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("byte_off", C.c_uint64), ("max_bytes", C.c_uint32), ("header_bytes", C.c_uint16),
+                ("block_size", C.c_uint16), ("n_channels", C.c_uint8), ("channel_assignment", C.c_uint8),
+                ("bps", C.c_uint8), ("reserved", C.c_uint8 * 5)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("msg", C.c_uint32), ("end_bit", C.c_uint64)]
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [("time", C.c_uint64), ("sample_rate", C.c_uint32), ("frame_or_sample_lo", C.c_uint32),
+                ("block_size", C.c_uint16), ("header_bytes", C.c_uint16), ("n_channels", C.c_uint8),
+                ("channel_assignment", C.c_uint8), ("bps", C.c_uint8), ("variable_blocking", C.c_uint8)]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("min_block_size", C.c_uint16), ("max_block_size", C.c_uint16),
+                ("min_frame_size", C.c_uint32), ("max_frame_size", C.c_uint32),
+                ("sample_rate", C.c_uint32), ("channels", C.c_uint32), ("bits_per_sample", C.c_uint32),
+                ("samples", C.c_uint64), ("md5sum", C.c_uint8 * 16)]
+
+
+class BlockInfo(C.Structure):
+    _fields_ = [("time", C.c_uint64), ("block_size", C.c_uint32), ("channels", C.c_uint32)]
+
+
+FRAME_DESC_DTYPE = np.dtype([("byte_off", "<u8"), ("max_bytes", "<u4"), ("header_bytes", "<u2"),
+                             ("block_size", "<u2"), ("n_channels", "u1"), ("channel_assignment", "u1"),
+                             ("bps", "u1"), ("reserved", "u1", (5,))])
+FRAME_RESULT_DTYPE = np.dtype([("status", "<i4"), ("msg", "<u4"), ("end_bit", "<u8")])
+FRAME_HEADER_DTYPE = np.dtype([("time", "<u8"), ("sample_rate", "<u4"), ("frame_or_sample_lo", "<u4"),
+                               ("block_size", "<u2"), ("header_bytes", "<u2"), ("n_channels", "u1"),
+                               ("channel_assignment", "u1"), ("bps", "u1"), ("variable_blocking", "u1")])
+assert FRAME_DESC_DTYPE.itemsize == C.sizeof(FrameDesc) == 24
+assert FRAME_RESULT_DTYPE.itemsize == C.sizeof(FrameResult) == 16
+assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
+
+EXPORTS = [
+    "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
+    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes",
+    "clx_batch_create", "clx_batch_run", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
+    "clx_batch_kernel_ms", "clx_batch_destroy", "clx_read_stream_header", "clx_reader_open", "clx_reader_new",
+    "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames",
+]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_device.h", "clx_plan.h",
+                                            os.path.join("host", "claxon.hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "claxon_hip.h"))
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           os.path.join(_CSRC, "clx_api.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libclaxon_hip.so (raises if it has not been built -- there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ClaxonError(API_ERROR, 0, "libclaxon_hip.so is not built (run `python -c 'import __graft_entry__ as g; "
+                                        "g.build()'`); claxon_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
+    L.clx_message.restype = C.c_char_p
+    L.clx_message.argtypes = [C.c_uint32]
+    L.clx_message_status.argtypes = [C.c_uint32]
+    L.clx_version.restype = C.c_uint32
+    L.clx_parse_frame_header.argtypes = [vp, sz, C.c_int, C.POINTER(FrameHeader), u32p]
+    L.clx_crc8.restype = C.c_uint8
+    L.clx_crc8.argtypes = [vp, sz]
+    L.clx_crc16.restype = C.c_uint16
+    L.clx_crc16.argtypes = [vp, sz]
+    L.clx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.clx_destroy.argtypes = [vp]
+    L.clx_destroy.restype = None
+    L.clx_last_error.restype = C.c_char_p
+    L.clx_last_error.argtypes = [vp]
+    L.clx_decode_frames.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, C.c_uint32]
+    L.clx_decode_subframes.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, C.c_uint32]
+    L.clx_batch_create.argtypes = [vp, vp, sz, vp, C.c_uint32, C.POINTER(vp)]
+    L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
+    L.clx_batch_results.argtypes = [vp, vp]
+    L.clx_batch_slots.restype = C.c_uint64
+    L.clx_batch_slots.argtypes = [vp]
+    L.clx_batch_set_profiling.argtypes = [vp, C.c_int]
+    L.clx_batch_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.clx_batch_destroy.argtypes = [vp]
+    L.clx_batch_destroy.restype = None
+    L.clx_read_stream_header.argtypes = [vp, sz, C.POINTER(StreamInfo), C.POINTER(sz), u32p]
+    L.clx_reader_open.argtypes = [vp, C.c_char_p, C.POINTER(vp), u32p]
+    L.clx_reader_new.argtypes = [vp, vp, sz, C.POINTER(vp), u32p]
+    L.clx_reader_streaminfo.argtypes = [vp, C.POINTER(StreamInfo)]
+    L.clx_reader_next_block.argtypes = [vp, vp, sz, C.POINTER(BlockInfo), u32p]
+    L.clx_reader_close.argtypes = [vp]
+    L.clx_reader_close.restype = None
+    L.clx_index_frames.argtypes = [vp, sz, sz, vp, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    _lib = L
+    return L
+
+
+def message(msg):
+    return lib().clx_message(int(msg)).decode()
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+# ----------------------------------------------------------------------------- host-side helpers
+
+def crc8(data):
+    a = _u8(data)
+    return int(lib().clx_crc8(_np_ptr(a), a.size))
+
+
+def crc16(data):
+    a = _u8(data)
+    return int(lib().clx_crc16(_np_ptr(a), a.size))
+
+
+def parse_frame_header(data, check_crc=True):
+    """read_frame_header_or_eof (frame.rs:131-316).  Returns (status, msg, FrameHeader)."""
+    a = _u8(data)
+    h = FrameHeader()
+    m = C.c_uint32(0)
+    st = lib().clx_parse_frame_header(_np_ptr(a), a.size, 1 if check_crc else 0, C.byref(h), C.byref(m))
+    return st, int(m.value), h
+
+
+def read_stream_header(data):
+    a = _u8(data)
+    si = StreamInfo()
+    off = C.c_size_t(0)
+    m = C.c_uint32(0)
+    st = lib().clx_read_stream_header(_np_ptr(a), a.size, C.byref(si), C.byref(off), C.byref(m))
+    return st, int(m.value), si, int(off.value)
+
+
+def index_frames(data, start=0, cap=1 << 20):
+    """Host frame indexer.  Returns (descs[np FRAME_DESC_DTYPE], headers[np FRAME_HEADER_DTYPE], stop_offset)."""
+    a = _u8(data)
+    cap = max(1, min(cap, a.size // 8 + 2))
+    descs = np.zeros(cap, dtype=FRAME_DESC_DTYPE)
+    hdrs = np.zeros(cap, dtype=FRAME_HEADER_DTYPE)
+    n = C.c_size_t(0)
+    stop = C.c_size_t(0)
+    st = lib().clx_index_frames(_np_ptr(a), a.size, start, _np_ptr(descs), _np_ptr(hdrs), cap, C.byref(n), C.byref(stop))
+    if st != OK:
+        raise ClaxonError(st)
+    return descs[:n.value].copy(), hdrs[:n.value].copy(), int(stop.value)
+
+
+def descs_from_offsets(arena, offs, max_bytes=None, check_crc=True):
+    """Build frame descriptors for frames whose start offsets are known (containers, the synthetic
+    generator): parses each frame header on the host.  Raises on a malformed header."""
+    a = _u8(arena)
+    offs = np.asarray(offs, dtype=np.uint64)
+    descs = np.zeros(offs.size, dtype=FRAME_DESC_DTYPE)
+    hdrs = np.zeros(offs.size, dtype=FRAME_HEADER_DTYPE)
+    L = lib()
+    h = FrameHeader()
+    m = C.c_uint32(0)
+    base = a.ctypes.data
+    for i, off in enumerate(offs.tolist()):
+        avail = a.size - off if max_bytes is None else min(int(max_bytes[i]), a.size - off)
+        st = L.clx_parse_frame_header(C.c_void_p(base + off), avail, 1 if check_crc else 0, C.byref(h), C.byref(m))
+        if st != OK:
+            raise ClaxonError(st, int(m.value))
+        descs[i] = (off, avail, h.header_bytes, h.block_size, h.n_channels, h.channel_assignment, h.bps, (0,) * 5)
+        hdrs[i] = (h.time, h.sample_rate, h.frame_or_sample_lo, h.block_size, h.header_bytes, h.n_channels,
+                   h.channel_assignment, h.bps, h.variable_blocking)
+    return descs, hdrs
+
+
+def descs_for_subframes(offs, block_sizes, bps):
+    n = len(offs)
+    d = np.zeros(n, dtype=FRAME_DESC_DTYPE)
+    d["byte_off"] = offs
+    d["max_bytes"] = 0xffffffff
+    d["block_size"] = block_sizes
+    d["n_channels"] = 1
+    d["bps"] = bps
+    d["reserved"][:, 0] = 1
+    return d
+
+
+# ----------------------------------------------------------------------------- device objects
+
+class Context:
+    """clx_ctx: one per GPU / stream; not thread safe."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p(None)
+        st = lib().clx_create(int(device), C.byref(self._h))
+        if st != OK or not self._h:
+            self._h = None
+            raise ClaxonError(API_ERROR, 0, "clx_create(%d) failed: no usable gfx950 HIP device; claxon_amd has no "
+                                            "CPU fallback" % device)
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().clx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return lib().clx_last_error(self._h).decode()
+
+    def _check(self, st):
+        if st != OK:
+            raise ClaxonError(st, 0, self.last_error())
+
+    def decode_frames(self, arena, descs, out_offs, out=None, verify_crc=False):
+        """One-shot host->device->host decode.  Returns (out int32, results np FRAME_RESULT_DTYPE)."""
+        a = _u8(arena)
+        descs = np.ascontiguousarray(descs, dtype=FRAME_DESC_DTYPE)
+        out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+        n = descs.size
+        total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+        if out is None:
+            out = np.zeros(total, dtype=np.int32)
+        assert out.dtype == np.int32 and out.size >= total
+        res = np.zeros(n, dtype=FRAME_RESULT_DTYPE)
+        st = lib().clx_decode_frames(self._h, _np_ptr(a), a.size, _np_ptr(descs), n, _np_ptr(out), _np_ptr(out_offs),
+                                     _np_ptr(res), VERIFY_CRC16 if verify_crc else 0)
+        self._check(st)
+        return out, res
+
+    def decode_subframes(self, arena, offs, block_sizes, bps, out_offs, out=None):
+        a = _u8(arena)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        bsz = np.ascontiguousarray(block_sizes, dtype=np.uint16)
+        bp = np.ascontiguousarray(bps, dtype=np.uint8)
+        out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+        n = offs.size
+        total = int((out_offs + bsz.astype(np.uint64)).max()) if n else 0
+        if out is None:
+            out = np.zeros(total, dtype=np.int32)
+        res = np.zeros(n, dtype=FRAME_RESULT_DTYPE)
+        st = lib().clx_decode_subframes(self._h, _np_ptr(a), a.size, _np_ptr(offs), _np_ptr(bsz), _np_ptr(bp), n,
+                                        _np_ptr(out), _np_ptr(out_offs), _np_ptr(res), 0)
+        self._check(st)
+        return out, res
+
+    def plan(self, descs, out_offs, verify_crc=False):
+        return Batch(self, descs, out_offs, verify_crc)
+
+
+class Batch:
+    """clx_batch: a planned batch, run on device-resident buffers (what bench.py times)."""
+
+    def __init__(self, ctx, descs, out_offs, verify_crc=False):
+        self.ctx = ctx
+        descs = np.ascontiguousarray(descs, dtype=FRAME_DESC_DTYPE)
+        out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+        self.n = descs.size
+        self._h = C.c_void_p(None)
+        st = lib().clx_batch_create(ctx._h, _np_ptr(descs), self.n, _np_ptr(out_offs),
+                                    VERIFY_CRC16 if verify_crc else 0, C.byref(self._h))
+        ctx._check(st)
+
+    @property
+    def slots(self):
+        return int(lib().clx_batch_slots(self._h))
+
+    def run(self, d_arena_ptr, arena_len, d_out_ptr, stream=0):
+        """d_arena_ptr / d_out_ptr: integer device addresses (e.g. torch tensor .data_ptr())."""
+        st = lib().clx_batch_run(self._h, C.c_void_p(d_arena_ptr), arena_len, C.c_void_p(d_out_ptr),
+                                 C.c_void_p(stream) if stream else None)
+        self.ctx._check(st)
+
+    def results(self):
+        res = np.zeros(self.n, dtype=FRAME_RESULT_DTYPE)
+        self.ctx._check(lib().clx_batch_results(self._h, _np_ptr(res)))
+        return res
+
+    def set_profiling(self, on=True):
+        lib().clx_batch_set_profiling(self._h, 1 if on else 0)
+
+    def kernel_ms(self, kernel):
+        ms = C.c_float(0)
+        self.ctx._check(lib().clx_batch_kernel_ms(self._h, kernel, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self._h:
+            lib().clx_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Block:
+    """frame.rs:402-529"""
+
+    def __init__(self, time, block_size, channels, buffer):
+        self._time, self._bs, self._ch, self._buf = time, block_size, channels, buffer
+
+    def time(self):
+        return self._time
+
+    def len(self):
+        return self._bs * self._ch
+
+    def duration(self):
+        return self._bs
+
+    def channels(self):
+        return self._ch
+
+    def channel(self, ch):
+        if ch >= self._ch:
+            raise IndexError(ch)
+        return self._buf[ch * self._bs:(ch + 1) * self._bs]
+
+    def sample(self, ch, i):
+        return int(self._buf[ch * self._bs + i])
+
+    def into_buffer(self):
+        return self._buf
+
+    def stereo_samples(self):
+        if self._ch != 2:
+            raise ValueError("stereo_samples() must only be called for blocks with two channels.")
+        return zip(self._buf[:self._bs].tolist(), self._buf[self._bs:2 * self._bs].tolist())
+
+
+class FlacReader:
+    """lib.rs:93-97, 207-471 over an in-memory stream; frames are decoded on the GPU in batches."""
+
+    def __init__(self, ctx, data=None, path=None):
+        self.ctx = ctx
+        self._h = C.c_void_p(None)
+        m = C.c_uint32(0)
+        if path is not None:
+            st = lib().clx_reader_open(ctx._h, os.fsencode(path), C.byref(self._h), C.byref(m))
+        else:
+            a = _u8(data)
+            st = lib().clx_reader_new(ctx._h, _np_ptr(a), a.size, C.byref(self._h), C.byref(m))
+        if st != OK:
+            self._h = None
+            raise ClaxonError(st, int(m.value))
+        self._si = StreamInfo()
+        lib().clx_reader_streaminfo(self._h, C.byref(self._si))
+
+    @classmethod
+    def open(cls, ctx, path):
+        return cls(ctx, path=path)
+
+    def streaminfo(self):
+        return self._si
+
+    def read_next_or_eof(self):
+        """Returns a Block, or None at the end of the stream; raises ClaxonError like the reference returns Err."""
+        cap = 8 * 65535
+        buf = np.empty(cap, dtype=np.int32)
+        info = BlockInfo()
+        m = C.c_uint32(0)
+        st = lib().clx_reader_next_block(self._h, _np_ptr(buf), cap, C.byref(info), C.byref(m))
+        if st == END_OF_STREAM:
+            return None
+        if st != OK:
+            raise ClaxonError(st, int(m.value), self.ctx.last_error() if st == API_ERROR else None)
+        n = info.block_size * info.channels
+        return Block(info.time, info.block_size, info.channels, buf[:n].copy())
+
+    def blocks(self):
+        while True:
+            b = self.read_next_or_eof()
+            if b is None:
+                return
+            yield b
+
+    def samples(self):
+        """Interleaved samples (lib.rs:473-520)."""
+        for b in self.blocks():
+            inter = b.into_buffer().reshape(b.channels(), b.duration()).T.reshape(-1)
+            for s in inter.tolist():
+                yield s
+
+    def close(self):
+        if self._h:
+            lib().clx_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

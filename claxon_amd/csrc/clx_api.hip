@@ -1,0 +1,756 @@
+// clx_api.hip -- host side of the C ABI declared in include/claxon_hip.h.
+//
+// Owns what the reference's host code owns around the hot path: the byte-aligned frame header
+// (frame.rs:131-316), the stream header / STREAMINFO (lib.rs:186-307, metadata.rs:214-400), the
+// error convention (error.rs) and the Block / FrameReader / FlacReader surface -- and plans and
+// launches the HIP kernels for everything between header and footer.  There is no CPU decode path
+// in this library: without a usable HIP device every decode entry point fails with CLX_API_ERROR.
+#include "clx_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "clx_plan.h"
+#include "host/claxon.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// messages (strings are the reference's, error.rs / call sites cited in claxon_hip.h)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct MsgInfo { int status; const char* text; };
+const MsgInfo kMsgs[CLX_MSG_COUNT] = {
+    /* NONE */ { CLX_OK, "" },
+    /* UNEXPECTED_EOF */ { CLX_IO_ERROR, "unexpected eof" },
+    { CLX_FORMAT_ERROR, "invalid subframe header" },
+    { CLX_FORMAT_ERROR, "invalid subframe header, encountered reserved value" },
+    { CLX_FORMAT_ERROR, "wasted bits per sample must not exceed 31" },
+    { CLX_FORMAT_ERROR, "subframe has no non-wasted bits" },
+    { CLX_FORMAT_ERROR, "invalid residual, encountered reserved value" },
+    { CLX_FORMAT_ERROR, "invalid partition order" },
+    { CLX_FORMAT_ERROR, "invalid residual" },
+    { CLX_FORMAT_ERROR, "invalid fixed subframe, order is larger than block size" },
+    { CLX_FORMAT_ERROR, "invalid LPC subframe, lpc order is larger than block size" },
+    { CLX_FORMAT_ERROR, "invalid subframe, qlp precision value invalid" },
+    { CLX_UNSUPPORTED, "unencoded binary is not yet implemented" },
+    { CLX_UNSUPPORTED, "a negative quantized linear predictor coefficient shift is not supported, please file a bug." },
+    { CLX_FORMAT_ERROR, "frame CRC mismatch" },
+    { CLX_FORMAT_ERROR, "frame header CRC mismatch" },
+    { CLX_FORMAT_ERROR, "frame sync code missing" },
+    { CLX_FORMAT_ERROR, "invalid frame header, encountered reserved value" },
+    { CLX_FORMAT_ERROR, "invalid frame header" },
+    { CLX_FORMAT_ERROR, "invalid frame header, frame number too large" },
+    { CLX_FORMAT_ERROR, "invalid block size, exceeds 65535" },
+    { CLX_FORMAT_ERROR, "invalid variable-length integer" },
+    { CLX_UNSUPPORTED, "header without bits per sample info" },
+    { CLX_FORMAT_ERROR, "invalid stream header" },
+    { CLX_FORMAT_ERROR, "stream starts with ID3 header rather than FLAC header" },
+    { CLX_FORMAT_ERROR, "streaminfo block missing" },
+    { CLX_FORMAT_ERROR, "encountered second streaminfo block" },
+    { CLX_FORMAT_ERROR, "invalid streaminfo metadata block length" },
+    { CLX_FORMAT_ERROR, "invalid metadata block type" },
+    { CLX_FORMAT_ERROR, "inconsistent bounds, min block size > max block size" },
+    { CLX_FORMAT_ERROR, "invalid block size, must be at least 16" },
+    { CLX_FORMAT_ERROR, "inconsistent bounds, min frame size > max frame size" },
+    { CLX_FORMAT_ERROR, "invalid sample rate" },
+    { CLX_FORMAT_ERROR, "application block length must be at least 4 bytes" },
+    { CLX_UNSUPPORTED, "application blocks larger than 10 MiB are not supported" },
+};
+
+// CRC tables generated from the polynomials (crc.rs:61,69): x^8+x^2+x+1 and x^16+x^15+x^2+1.
+struct CrcTables {
+    uint8_t t8[256];
+    uint16_t t16[256];
+    CrcTables() {
+        for (int i = 0; i < 256; ++i) {
+            uint8_t a = (uint8_t)i;
+            uint16_t b = (uint16_t)(i << 8);
+            for (int k = 0; k < 8; ++k) {
+                a = (uint8_t)((a & 0x80) ? (a << 1) ^ 0x07 : a << 1);
+                b = (uint16_t)((b & 0x8000) ? (b << 1) ^ 0x8005 : b << 1);
+            }
+            t8[i] = a; t16[i] = b;
+        }
+    }
+};
+const CrcTables& crc_tables() { static const CrcTables t; return t; }
+}  // namespace
+
+extern "C" const char* clx_message(uint32_t msg) { return msg < CLX_MSG_COUNT ? kMsgs[msg].text : "unknown"; }
+extern "C" int clx_message_status(uint32_t msg) { return msg < CLX_MSG_COUNT ? kMsgs[msg].status : CLX_API_ERROR; }
+extern "C" uint32_t clx_version(void) { return (CLX_VERSION_MAJOR << 16) | (CLX_VERSION_MINOR << 8) | CLX_VERSION_PATCH; }
+
+extern "C" uint8_t clx_crc8(const uint8_t* p, size_t n) {
+    const CrcTables& t = crc_tables();
+    uint8_t s = 0;
+    for (size_t i = 0; i < n; ++i) s = t.t8[s ^ p[i]];
+    return s;
+}
+extern "C" uint16_t clx_crc16(const uint8_t* p, size_t n) {
+    const CrcTables& t = crc_tables();
+    uint16_t s = 0;
+    for (size_t i = 0; i < n; ++i) s = (uint16_t)((s << 8) ^ t.t16[(uint8_t)(s >> 8) ^ p[i]]);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame header (frame.rs:64-105, 131-316).  Byte-aligned, so a plain cursor does.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ByteCursor {
+    const uint8_t* p; size_t n; size_t pos;
+    bool u8(uint32_t* v) { if (pos >= n) return false; *v = p[pos++]; return true; }
+    bool be16(uint32_t* v) { uint32_t a, b; if (!u8(&a) || !u8(&b)) return false; *v = (a << 8) | b; return true; }
+};
+inline int fail(uint32_t* msg, int status, uint32_t m) { if (msg) *msg = m; return status; }
+}  // namespace
+
+extern "C" int clx_parse_frame_header(const uint8_t* p, size_t avail, int check_crc,
+                                      clx_frame_header* out, uint32_t* msg) {
+    if (msg) *msg = CLX_MSG_NONE;
+    if (!out || (!p && avail)) return fail(msg, CLX_API_ERROR, CLX_MSG_NONE);
+    std::memset(out, 0, sizeof *out);
+    ByteCursor c{ p, avail, 0 };
+    uint32_t srb;
+    if (!c.be16(&srb)) return CLX_END_OF_STREAM;                      // Ok(None), frame.rs:140-143
+    if ((srb & 0xfffcu) != 0xfff8u) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_SYNC_MISSING);
+    if (srb & 2u) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_HEADER_RESERVED);
+    out->variable_blocking = (uint8_t)(srb & 1u);
+
+    uint32_t bs_sr;
+    if (!c.u8(&bs_sr)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    uint32_t block_size = 0; bool bs8 = false, bs16 = false;
+    const uint32_t bn = bs_sr >> 4;
+    if (bn == 0) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_HEADER_RESERVED);
+    else if (bn == 1) block_size = 192;
+    else if (bn <= 5) block_size = 576u << (bn - 2);
+    else if (bn == 6) bs8 = true;
+    else if (bn == 7) bs16 = true;
+    else block_size = 256u << (bn - 8);
+
+    uint32_t sample_rate = 0; bool sr8 = false, sr16 = false, sr16x10 = false;
+    static const uint32_t kRates[12] = { 0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000 };
+    const uint32_t sn = bs_sr & 15u;
+    if (sn < 12) sample_rate = kRates[sn];
+    else if (sn == 12) sr8 = true;
+    else if (sn == 13) sr16 = true;
+    else if (sn == 14) sr16x10 = true;
+    else return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_HEADER_INVALID);
+
+    uint32_t cbr;
+    if (!c.u8(&cbr)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    const uint32_t ca = cbr >> 4;
+    if (ca < 8) { out->channel_assignment = CLX_CH_INDEPENDENT; out->n_channels = (uint8_t)(ca + 1); }
+    else if (ca == 8) { out->channel_assignment = CLX_CH_LEFT_SIDE; out->n_channels = 2; }
+    else if (ca == 9) { out->channel_assignment = CLX_CH_RIGHT_SIDE; out->n_channels = 2; }
+    else if (ca == 10) { out->channel_assignment = CLX_CH_MID_SIDE; out->n_channels = 2; }
+    else return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_HEADER_RESERVED);
+    static const int kBps[8] = { 0, 8, 12, -1, 16, 20, 24, -1 };
+    const int bps = kBps[(cbr & 0x0eu) >> 1];
+    if (bps < 0) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_HEADER_RESERVED);
+    out->bps = (uint8_t)bps;
+    if (cbr & 1u) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_HEADER_RESERVED);
+
+    // read_var_length_int, frame.rs:64-105
+    uint32_t first;
+    if (!c.u8(&first)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    uint32_t extra = 0, mask_data = 0x7f, mask_mark = 0x80;
+    while (first & mask_mark) { ++extra; mask_data >>= 1; mask_mark >>= 1; }
+    if (extra > 0) {
+        if (extra == 1) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_VARINT);
+        --extra;
+    }
+    uint64_t number = (uint64_t)(first & mask_data) << (6 * extra);
+    for (int i = (int)extra - 1; i >= 0; --i) {
+        uint32_t b;
+        if (!c.u8(&b)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        if ((b & 0xc0u) != 0x80u) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_VARINT);
+        number |= (uint64_t)(b & 0x3fu) << (6 * i);
+    }
+    if (!out->variable_blocking && number > 0x7fffffffull)
+        return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_NUMBER_TOO_LARGE);
+
+    if (bs8) { uint32_t b; if (!c.u8(&b)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); block_size = b + 1; }
+    if (bs16) {
+        uint32_t b; if (!c.be16(&b)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        if (b == 0xffffu) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_BLOCK_SIZE_EXCEEDS_65535);
+        block_size = b + 1;
+    }
+    if (sr8) { uint32_t b; if (!c.u8(&b)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); sample_rate = b; }
+    if (sr16) { uint32_t b; if (!c.be16(&b)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); sample_rate = b; }
+    if (sr16x10) { uint32_t b; if (!c.be16(&b)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); sample_rate = b * 10; }
+
+    const uint8_t computed = clx_crc8(p, c.pos);
+    uint32_t presumed;
+    if (!c.u8(&presumed)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    if (check_crc && computed != presumed) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_FRAME_HEADER_CRC_MISMATCH);
+
+    out->block_size = (uint16_t)block_size;
+    out->sample_rate = sample_rate;
+    out->header_bytes = (uint16_t)c.pos;
+    out->frame_or_sample_lo = (uint32_t)number;
+    out->time = out->variable_blocking ? number : (uint64_t)block_size * (uint64_t)(uint32_t)number;   // frame.rs:771-774
+    return CLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context / batch
+// ------------------------------------------------------------------------------------------------
+struct clx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+};
+
+struct clx_batch {
+    clx_ctx* ctx = nullptr;
+    size_t n = 0;
+    uint64_t n_slots = 0;
+    uint32_t flags = 0;
+    std::vector<clx_frame_desc> h_descs;
+    std::vector<clx_dev_frame> h_frames;
+    clx_dev_frame* d_frames = nullptr;
+    clx_sf_desc* d_sfd = nullptr;
+    clx_frame_result* d_results = nullptr;
+    bool profiling = false;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool ev_valid = false;
+    hipStream_t last_stream = nullptr;
+    size_t planned_arena_len = 0;
+};
+
+namespace {
+bool hip_ok(clx_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    if (ctx) { ctx->last_error = std::string(what) + ": " + hipGetErrorString(e); }
+    return false;
+}
+#define HIP_TRY(ctx, call) do { if (!hip_ok((ctx), (call), #call)) return CLX_API_ERROR; } while (0)
+}  // namespace
+
+extern "C" int clx_create(int device, clx_ctx** out) {
+    if (!out) return CLX_API_ERROR;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CLX_API_ERROR;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CLX_API_ERROR;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CLX_API_ERROR;   // the code object is gfx950-only
+    clx_ctx* c = new (std::nothrow) clx_ctx();
+    if (!c) return CLX_API_ERROR;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c; return CLX_API_ERROR;
+    }
+    *out = c;
+    return CLX_OK;
+}
+
+extern "C" void clx_destroy(clx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* clx_last_error(const clx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+extern "C" void clx_batch_destroy(clx_batch* b) {
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->d_frames) (void)hipFree(b->d_frames);
+    if (b->d_sfd) (void)hipFree(b->d_sfd);
+    if (b->d_results) (void)hipFree(b->d_results);
+    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
+                                const uint64_t* out_sample_offsets, uint32_t flags, clx_batch** out) {
+    if (!ctx || !out || (n && (!frames || !out_sample_offsets))) return CLX_API_ERROR;
+    *out = nullptr;
+    if (n > 0xfffffff0ull) { ctx->last_error = "too many frames in one batch"; return CLX_API_ERROR; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    clx_batch* b = new (std::nothrow) clx_batch();
+    if (!b) return CLX_API_ERROR;
+    b->ctx = ctx; b->n = n; b->flags = flags;
+    b->h_descs.assign(frames, frames + n);
+    b->h_frames.resize(n ? n : 1);
+    uint64_t slot = 0;
+    const long bad = clx_plan_frames(frames, n, out_sample_offsets, b->h_frames.data(), &slot);
+    if (bad >= 0) {
+        ctx->last_error = "invalid clx_frame_desc at index " + std::to_string(bad);
+        clx_batch_destroy(b); return CLX_API_ERROR;
+    }
+    if (slot > 0xfffffff0ull) { ctx->last_error = "too many subframes in one batch"; clx_batch_destroy(b); return CLX_API_ERROR; }
+    b->n_slots = slot;
+    const size_t nf = n ? n : 1, ns = slot ? (size_t)slot : 1;
+    if (!hip_ok(ctx, hipMalloc((void**)&b->d_frames, nf * sizeof(clx_dev_frame)), "hipMalloc frames") ||
+        !hip_ok(ctx, hipMalloc((void**)&b->d_sfd, ns * sizeof(clx_sf_desc)), "hipMalloc sfdesc") ||
+        !hip_ok(ctx, hipMalloc((void**)&b->d_results, nf * sizeof(clx_frame_result)), "hipMalloc results")) {
+        clx_batch_destroy(b); return CLX_API_ERROR;
+    }
+    for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
+    b->planned_arena_len = (size_t)-1;
+    *out = b;
+    return CLX_OK;
+}
+
+extern "C" uint64_t clx_batch_slots(const clx_batch* b) { return b ? b->n_slots : 0; }
+
+extern "C" int clx_batch_set_profiling(clx_batch* b, int enable) {
+    if (!b) return CLX_API_ERROR;
+    b->profiling = enable != 0;
+    b->ev_valid = false;
+    return CLX_OK;
+}
+
+extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, void* stream_) {
+    if (!b || !b->ctx) return CLX_API_ERROR;
+    clx_ctx* ctx = b->ctx;
+    if (b->n == 0) return CLX_OK;
+    if (!d_arena || !d_out) { ctx->last_error = "null device pointer"; return CLX_API_ERROR; }
+    if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    b->last_stream = stream;
+
+    if (b->planned_arena_len != arena_len) {
+        // clamp every frame's readable span against the arena and upload the plan (once per arena size)
+        std::vector<clx_dev_frame> up(b->h_frames);
+        clx_plan_limits(b->h_descs.data(), b->n, arena_len, up.data());
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_frames, up.data(), b->n * sizeof(clx_dev_frame), hipMemcpyHostToDevice, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));                    // `up` goes out of scope
+        b->planned_arena_len = arena_len;
+    }
+    const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
+
+    HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
+    if (b->profiling) HIP_TRY(ctx, hipEventRecord(b->ev[0], stream));
+    hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), 0, stream,
+                       d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
+    if (b->profiling) HIP_TRY(ctx, hipEventRecord(b->ev[1], stream));
+    const unsigned k2_blocks = (unsigned)((b->n_slots + 63) / 64);
+    if (k2_blocks)
+        hipLaunchKernelGGL(clx_k_predict, dim3(k2_blocks), dim3(64), 0, stream, d_out, (const clx_sf_desc*)b->d_sfd,
+                           (uint32_t)b->n_slots);
+    if (b->profiling) HIP_TRY(ctx, hipEventRecord(b->ev[2], stream));
+    if (b->flags & CLX_VERIFY_CRC16)
+        hipLaunchKernelGGL(clx_k_crc16, dim3((unsigned)b->n), dim3(64), 0, stream, d_arena,
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, b->d_results);
+    if (b->profiling) { HIP_TRY(ctx, hipEventRecord(b->ev[3], stream)); b->ev_valid = true; }
+    HIP_TRY(ctx, hipGetLastError());
+    return CLX_OK;
+}
+
+extern "C" int clx_batch_results(clx_batch* b, clx_frame_result* results) {
+    if (!b || !b->ctx || (b->n && !results)) return CLX_API_ERROR;
+    clx_ctx* ctx = b->ctx;
+    if (b->n == 0) return CLX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = b->last_stream ? b->last_stream : ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(results, b->d_results, b->n * sizeof(clx_frame_result), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return CLX_OK;
+}
+
+extern "C" int clx_batch_kernel_ms(clx_batch* b, int kernel, float* ms) {
+    if (!b || !ms || kernel < 0 || kernel > 2 || !b->ev_valid) return CLX_API_ERROR;
+    clx_ctx* ctx = b->ctx;
+    HIP_TRY(ctx, hipEventSynchronize(b->ev[3]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, b->ev[kernel], b->ev[kernel + 1]));
+    return CLX_OK;
+}
+
+extern "C" int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,
+                                 const clx_frame_desc* frames, size_t n,
+                                 int32_t* out, const uint64_t* out_sample_offsets,
+                                 clx_frame_result* results, uint32_t flags) {
+    if (!ctx) return CLX_API_ERROR;
+    if (n == 0) return CLX_OK;
+    if (!arena || !frames || !out || !out_sample_offsets || !results) { ctx->last_error = "null argument"; return CLX_API_ERROR; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    clx_batch* b = nullptr;
+    int st = clx_batch_create(ctx, frames, n, out_sample_offsets, flags, &b);
+    if (st != CLX_OK) return st;
+    uint8_t* d_arena = nullptr; int32_t* d_out = nullptr;
+    uint64_t out_len = 0;
+    for (size_t i = 0; i < n; ++i)
+        out_len = std::max<uint64_t>(out_len, out_sample_offsets[i] + (uint64_t)frames[i].n_channels * frames[i].block_size);
+    auto cleanup = [&]() {
+        if (!(flags & CLX_ARENA_ON_DEVICE) && d_arena) (void)hipFree(d_arena);
+        if (!(flags & CLX_OUT_ON_DEVICE) && d_out) (void)hipFree(d_out);
+        clx_batch_destroy(b);
+    };
+    if (flags & CLX_ARENA_ON_DEVICE) d_arena = const_cast<uint8_t*>(arena);
+    else {
+        const size_t alloc = ((arena_len + 15) & ~(size_t)15) + 16;
+        if (!hip_ok(ctx, hipMalloc((void**)&d_arena, alloc), "hipMalloc arena")) { cleanup(); return CLX_API_ERROR; }
+        if (!hip_ok(ctx, hipMemsetAsync(d_arena + (alloc - 32), 0, 32, ctx->stream), "memset") ||
+            !hip_ok(ctx, hipMemcpyAsync(d_arena, arena, arena_len, hipMemcpyHostToDevice, ctx->stream), "H2D arena")) { cleanup(); return CLX_API_ERROR; }
+    }
+    if (flags & CLX_OUT_ON_DEVICE) d_out = out;
+    else if (!hip_ok(ctx, hipMalloc((void**)&d_out, std::max<uint64_t>(out_len, 1) * sizeof(int32_t)), "hipMalloc out")) { cleanup(); return CLX_API_ERROR; }
+    st = clx_batch_run(b, d_arena, arena_len, d_out, ctx->stream);
+    if (st == CLX_OK) st = clx_batch_results(b, results);
+    if (st == CLX_OK && !(flags & CLX_OUT_ON_DEVICE)) {
+        // only blocks of successfully decoded frames are observable (frame.rs:667: Err drops the buffer)
+        if (!hip_ok(ctx, hipMemcpyAsync(out, d_out, out_len * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), "D2H out") ||
+            !hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) st = CLX_API_ERROR;
+    }
+    cleanup();
+    return st;
+}
+
+extern "C" int clx_decode_subframes(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,
+                                    const uint64_t* byte_offs, const uint16_t* block_sizes,
+                                    const uint8_t* bps, size_t n,
+                                    int32_t* out, const uint64_t* out_sample_offsets,
+                                    clx_frame_result* results, uint32_t flags) {
+    if (!ctx) return CLX_API_ERROR;
+    if (n == 0) return CLX_OK;
+    if (!byte_offs || !block_sizes || !bps) { ctx->last_error = "null argument"; return CLX_API_ERROR; }
+    std::vector<clx_frame_desc> descs(n);
+    for (size_t i = 0; i < n; ++i) {
+        clx_frame_desc& d = descs[i];
+        std::memset(&d, 0, sizeof d);
+        d.byte_off = byte_offs[i];
+        d.max_bytes = 0xffffffffu;
+        d.header_bytes = 0;
+        d.block_size = block_sizes[i];
+        d.n_channels = 1;
+        d.channel_assignment = CLX_CH_INDEPENDENT;
+        d.bps = bps[i];
+        d.reserved[0] = 1;                // bare subframe: no CRC-16 footer
+    }
+    return clx_decode_frames(ctx, arena, arena_len, descs.data(), n, out, out_sample_offsets, results,
+                             flags & ~(uint32_t)CLX_VERIFY_CRC16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream header + STREAMINFO (lib.rs:186-205, 230-307; metadata.rs:214-400).  Other metadata blocks
+// are skipped by length (VORBIS_COMMENT parsing is outside the hot-path scope).
+// ------------------------------------------------------------------------------------------------
+extern "C" int clx_read_stream_header(const uint8_t* d, size_t len, clx_streaminfo* info, size_t* audio_offset, uint32_t* msg) {
+    if (msg) *msg = CLX_MSG_NONE;
+    if (!info || !audio_offset || (!d && len)) return CLX_API_ERROR;
+    ByteCursor c{ d, len, 0 };
+    auto be = [&](int nbytes, uint64_t* v) { uint64_t r = 0; for (int i = 0; i < nbytes; ++i) { uint32_t b; if (!c.u8(&b)) return false; r = (r << 8) | b; } *v = r; return true; };
+    uint64_t magic;
+    if (!be(4, &magic)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    if (magic != 0x664c6143ull)
+        return fail(msg, CLX_FORMAT_ERROR, (magic & 0xffffff00ull) == 0x49443300ull ? CLX_MSG_ID3_HEADER : CLX_MSG_INVALID_STREAM_HEADER);
+    bool first = true;
+    for (;;) {
+        uint32_t hb; uint64_t length;
+        if (!c.u8(&hb) || !be(3, &length)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        const bool is_last = (hb >> 7) == 1;
+        const uint32_t type = hb & 0x7fu;
+        if (type == 0) {
+            if (length != 34) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_STREAMINFO_LENGTH);
+            clx_streaminfo s; std::memset(&s, 0, sizeof s);
+            uint64_t v, sr_msb, sr_lsb, bps_ns, ns_lsb;
+            if (!be(2, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+            s.min_block_size = (uint16_t)v;
+            if (!be(2, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+            s.max_block_size = (uint16_t)v;
+            if (!be(3, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+            s.min_frame_size = (uint32_t)v;
+            if (!be(3, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+            s.max_frame_size = (uint32_t)v;
+            if (!be(2, &sr_msb) || !be(1, &sr_lsb) || !be(1, &bps_ns) || !be(4, &ns_lsb)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+            s.sample_rate = (uint32_t)((sr_msb << 4) | (sr_lsb >> 4));
+            s.channels = (uint32_t)(((sr_lsb >> 1) & 7) + 1);
+            s.bits_per_sample = (uint32_t)((((sr_lsb & 1) << 4) | (bps_ns >> 4)) + 1);
+            s.samples = ((bps_ns & 15) << 32) | ns_lsb;
+            if (c.pos + 16 > len) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+            std::memcpy(s.md5sum, d + c.pos, 16); c.pos += 16;
+            if (s.min_block_size > s.max_block_size) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_MIN_BLOCK_GT_MAX_BLOCK);
+            if (s.min_block_size < 16) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_BLOCK_SIZE_LT_16);
+            if (s.min_frame_size > s.max_frame_size && s.max_frame_size != 0) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_MIN_FRAME_GT_MAX_FRAME);
+            if (s.sample_rate == 0 || s.sample_rate > 655350) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_SAMPLE_RATE);
+            if (!first) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_SECOND_STREAMINFO);
+            *info = s;
+        } else {
+            if (type == 127) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_METADATA_BLOCK_TYPE);
+            if (type == 2) {
+                if (length < 4) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_APPLICATION_BLOCK_TOO_SHORT);
+                if (length > 10u * 1024 * 1024) return fail(msg, CLX_UNSUPPORTED, CLX_MSG_APPLICATION_BLOCK_TOO_LARGE);
+            }
+            if (c.pos + length > len) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+            c.pos += (size_t)length;
+            if (first) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_STREAMINFO_MISSING);
+        }
+        first = false;
+        if (is_last) break;
+    }
+    *audio_offset = c.pos;
+    return CLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame indexer (host): sync code + CRC-8-valid header, chain confirmed by the previous frame's CRC-16
+// ------------------------------------------------------------------------------------------------
+extern "C" int clx_index_frames(const uint8_t* data, size_t len, size_t start_off,
+                                clx_frame_desc* descs, clx_frame_header* headers, size_t cap,
+                                size_t* n_found, size_t* stop_off) {
+    if (!n_found || !stop_off || (!data && len) || (cap && !descs)) return CLX_API_ERROR;
+    *n_found = 0; *stop_off = start_off;
+    const CrcTables& t = crc_tables();
+    size_t pos = start_off;
+    while (*n_found < cap && pos + 2 <= len) {
+        clx_frame_header h; uint32_t m;
+        if (clx_parse_frame_header(data + pos, len - pos, 1, &h, &m) != CLX_OK) break;
+        // find the end: the next CRC-8-valid header whose preceding two bytes are this frame's CRC-16,
+        // or the end of the stream
+        uint16_t crc = 0;
+        size_t q = pos;
+        size_t found_end = 0;
+        const size_t min_end = pos + h.header_bytes + 2;
+        for (;;) {
+            // crc covers [pos, q)
+            if (q + 2 >= min_end && q + 2 <= len) {
+                const uint16_t footer = (uint16_t)((data[q] << 8) | data[q + 1]);
+                if (footer == crc) {
+                    const size_t e = q + 2;
+                    if (e == len) { found_end = e; break; }
+                    if (e + 2 <= len && data[e] == 0xff && (data[e + 1] & 0xfe) == 0xf8) {
+                        clx_frame_header nh; uint32_t nm;
+                        if (clx_parse_frame_header(data + e, len - e, 1, &nh, &nm) == CLX_OK) { found_end = e; break; }
+                    }
+                }
+            }
+            if (q >= len) break;
+            crc = (uint16_t)((crc << 8) ^ t.t16[(uint8_t)(crc >> 8) ^ data[q]]);
+            ++q;
+        }
+        if (!found_end) break;
+        clx_frame_desc& d = descs[*n_found];
+        std::memset(&d, 0, sizeof d);
+        d.byte_off = pos;
+        d.max_bytes = (uint32_t)std::min<size_t>(len - pos, 0xffffffffu);    // rest of the stream, as the reference's reader sees it
+        d.header_bytes = h.header_bytes;
+        d.block_size = h.block_size;
+        d.n_channels = h.n_channels;
+        d.channel_assignment = h.channel_assignment;
+        d.bps = h.bps;
+        if (headers) headers[*n_found] = h;
+        ++*n_found;
+        pos = found_end;
+    }
+    *stop_off = pos;
+    return CLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// claxon::FrameReader / FlacReader / Block (host/claxon.hpp) -- the reference's API surface
+// ------------------------------------------------------------------------------------------------
+namespace claxon {
+
+Error Error::from(int status, uint32_t msg) {
+    Error e;
+    e.kind = status == CLX_IO_ERROR ? ErrorKind::IoError : status == CLX_FORMAT_ERROR ? ErrorKind::FormatError
+           : status == CLX_UNSUPPORTED ? ErrorKind::Unsupported : ErrorKind::Api;
+    e.status = status; e.msg = msg; e.text = clx_message(msg);
+    return e;
+}
+
+struct FrameReader::Impl {
+    clx_ctx* ctx = nullptr;
+    std::vector<uint8_t> data;        // the stream (host)
+    uint8_t* d_arena = nullptr;       // same bytes on the device, uploaded once
+    size_t pos = 0;                   // next undecoded byte
+    size_t batch_frames = 4096;
+    struct Pending { clx_frame_header hdr; int status; uint32_t msg; std::vector<int32_t> samples; };
+    std::vector<Pending> queue;
+    size_t qhead = 0;
+    bool failed = false; int fail_status = 0; uint32_t fail_msg = 0;
+    ~Impl() { if (d_arena) { (void)hipSetDevice(ctx->device); (void)hipFree(d_arena); } }
+};
+
+FrameReader::FrameReader(clx_ctx* ctx, const uint8_t* data, size_t len) : impl_(new Impl()) {
+    impl_->ctx = ctx;
+    impl_->data.assign(data, data + len);
+}
+FrameReader::FrameReader(FrameReader&& o) noexcept : impl_(o.impl_) { o.impl_ = nullptr; }
+FrameReader::~FrameReader() { delete impl_; }
+size_t FrameReader::position() const { return impl_->pos; }
+void FrameReader::set_batch_frames(size_t n) { impl_->batch_frames = n ? n : 1; }
+
+// Decode the next batch of frames starting at impl_->pos into the queue.
+static int fill_queue(FrameReader::Impl& I) {
+    I.queue.clear(); I.qhead = 0;
+    const uint8_t* data = I.data.data();
+    const size_t len = I.data.size();
+    // header of the frame at pos decides what the reference would do first (frame.rs:674-692)
+    clx_frame_header h0; uint32_t m0 = 0;
+    int st0 = clx_parse_frame_header(data + I.pos, len - I.pos, 1, &h0, &m0);
+    if (st0 != CLX_OK) {
+        FrameReader::Impl::Pending p{}; p.status = st0; p.msg = m0;
+        I.queue.push_back(std::move(p));
+        return CLX_OK;
+    }
+    std::vector<clx_frame_desc> descs(I.batch_frames);
+    std::vector<clx_frame_header> hdrs(I.batch_frames);
+    size_t n = 0, stop = 0;
+    clx_index_frames(data, len, I.pos, descs.data(), hdrs.data(), I.batch_frames, &n, &stop);
+    if (n == 0) {
+        // the chain could not be confirmed from here: decode this one frame against the rest of the stream
+        n = 1; hdrs[0] = h0;
+        clx_frame_desc& d = descs[0];
+        std::memset(&d, 0, sizeof d);
+        d.byte_off = I.pos; d.max_bytes = (uint32_t)std::min<size_t>(len - I.pos, 0xffffffffu);
+        d.header_bytes = h0.header_bytes; d.block_size = h0.block_size; d.n_channels = h0.n_channels;
+        d.channel_assignment = h0.channel_assignment; d.bps = h0.bps;
+    }
+    // frames whose header carries no bps are Unsupported before any subframe is read (frame.rs:687-692)
+    size_t usable = n;
+    for (size_t i = 0; i < n; ++i) if (descs[i].bps == 0) { usable = i; break; }
+    std::vector<clx_frame_result> results(usable);
+    std::vector<uint64_t> offs(usable);
+    uint64_t total = 0;
+    for (size_t i = 0; i < usable; ++i) { offs[i] = total; total += (uint64_t)descs[i].n_channels * descs[i].block_size; }
+    int32_t* d_out = nullptr;
+    std::vector<int32_t> host_out(total);
+    if (usable) {
+        if (hipSetDevice(I.ctx->device) != hipSuccess) return CLX_API_ERROR;
+        if (!I.d_arena) {
+            const size_t alloc = ((len + 15) & ~(size_t)15) + 16;
+            if (hipMalloc((void**)&I.d_arena, alloc) != hipSuccess) return CLX_API_ERROR;
+            if (hipMemset(I.d_arena, 0, alloc) != hipSuccess || hipMemcpy(I.d_arena, data, len, hipMemcpyHostToDevice) != hipSuccess) return CLX_API_ERROR;
+        }
+        if (hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * sizeof(int32_t)) != hipSuccess) return CLX_API_ERROR;
+        int st = clx_decode_frames(I.ctx, I.d_arena, len, descs.data(), usable, d_out, offs.data(), results.data(),
+                                   CLX_ARENA_ON_DEVICE | CLX_OUT_ON_DEVICE | CLX_VERIFY_CRC16);
+        if (st == CLX_OK && hipMemcpy(host_out.data(), d_out, total * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) st = CLX_API_ERROR;
+        (void)hipFree(d_out);
+        if (st != CLX_OK) return st;
+    }
+    size_t expect = I.pos;
+    for (size_t i = 0; i < n; ++i) {
+        FrameReader::Impl::Pending p{};
+        p.hdr = hdrs[i];
+        if (descs[i].byte_off != expect) break;             // the speculative index diverged from the true chain
+        if (i >= usable) { p.status = CLX_UNSUPPORTED; p.msg = CLX_MSG_NO_BPS_IN_HEADER; I.queue.push_back(std::move(p)); break; }
+        p.status = results[i].status; p.msg = results[i].msg;
+        if (p.status == CLX_OK) {
+            const size_t cnt = (size_t)descs[i].n_channels * descs[i].block_size;
+            p.samples.assign(host_out.begin() + (ptrdiff_t)offs[i], host_out.begin() + (ptrdiff_t)(offs[i] + cnt));
+            expect = (size_t)descs[i].byte_off + (size_t)((results[i].end_bit + 7) / 8) + 2;
+            I.queue.push_back(std::move(p));
+        } else { I.queue.push_back(std::move(p)); break; }
+    }
+    I.pos = expect;
+    return CLX_OK;
+}
+
+FrameResult FrameReader::read_next_or_eof(std::vector<int32_t> buffer) {
+    Impl& I = *impl_;
+    FrameResult r;
+    if (I.failed) { r.error = Error::from(I.fail_status, I.fail_msg); r.is_err = true; return r; }
+    if (I.qhead >= I.queue.size()) {
+        int st = fill_queue(I);
+        if (st != CLX_OK) { r.is_err = true; r.error = Error::from(CLX_API_ERROR, 0); r.error.text = clx_last_error(I.ctx); return r; }
+    }
+    Impl::Pending& p = I.queue[I.qhead++];
+    if (p.status == CLX_END_OF_STREAM) { --I.qhead; r.has_block = false; return r; }      // Ok(None), stays at EOF
+    if (p.status != CLX_OK) {
+        I.failed = true; I.fail_status = p.status; I.fail_msg = p.msg;
+        r.is_err = true; r.error = Error::from(p.status, p.msg); return r;
+    }
+    // ensure_buffer_len (frame.rs:616-637) then overwrite every sample
+    buffer.resize(p.samples.size());
+    std::copy(p.samples.begin(), p.samples.end(), buffer.begin());
+    r.has_block = true;
+    r.block = Block(p.hdr.time, p.hdr.block_size, std::move(buffer));
+    return r;
+}
+
+struct FlacReader::Impl {
+    clx_streaminfo info{};
+    FrameReader* frames = nullptr;
+    ~Impl() { delete frames; }
+};
+
+FlacReader::FlacReader() : impl_(new Impl()) {}
+FlacReader::FlacReader(FlacReader&& o) noexcept : impl_(o.impl_) { o.impl_ = nullptr; }
+FlacReader::~FlacReader() { delete impl_; }
+
+Result<FlacReader> FlacReader::create(clx_ctx* ctx, const uint8_t* data, size_t len) {
+    Result<FlacReader> r;
+    clx_streaminfo si; size_t off = 0; uint32_t msg = 0;
+    int st = clx_read_stream_header(data, len, &si, &off, &msg);
+    if (st != CLX_OK) { r.is_err = true; r.error = Error::from(st, msg); return r; }
+    r.value.impl_->info = si;
+    r.value.impl_->frames = new FrameReader(ctx, data + off, len - off);
+    return r;
+}
+
+Result<FlacReader> FlacReader::open(clx_ctx* ctx, const char* path) {
+    Result<FlacReader> r;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { r.is_err = true; r.error = Error::from(CLX_IO_ERROR, CLX_MSG_NONE); r.error.text = "cannot open file"; return r; }
+    std::vector<uint8_t> data;
+    uint8_t buf[65536];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + got);
+    std::fclose(f);
+    return create(ctx, data.data(), data.size());
+}
+
+const clx_streaminfo& FlacReader::streaminfo() const { return impl_->info; }
+FrameReader& FlacReader::blocks() { return *impl_->frames; }
+
+}  // namespace claxon
+
+// ------------------------------------------------------------------------------------------------
+// C handles over the C++ reader
+// ------------------------------------------------------------------------------------------------
+struct clx_reader { claxon::FlacReader reader; std::vector<int32_t> recycle; };
+
+extern "C" int clx_reader_new(clx_ctx* ctx, const uint8_t* data, size_t len, clx_reader** out, uint32_t* msg) {
+    if (msg) *msg = CLX_MSG_NONE;
+    if (!ctx || !out || (!data && len)) return CLX_API_ERROR;
+    *out = nullptr;
+    auto r = claxon::FlacReader::create(ctx, data, len);
+    if (r.is_err) { if (msg) *msg = r.error.msg; return r.error.status; }
+    *out = new clx_reader{ std::move(r.value), {} };
+    return CLX_OK;
+}
+
+extern "C" int clx_reader_open(clx_ctx* ctx, const char* path, clx_reader** out, uint32_t* msg) {
+    if (msg) *msg = CLX_MSG_NONE;
+    if (!ctx || !out || !path) return CLX_API_ERROR;
+    *out = nullptr;
+    auto r = claxon::FlacReader::open(ctx, path);
+    if (r.is_err) { if (msg) *msg = r.error.msg; return r.error.status; }
+    *out = new clx_reader{ std::move(r.value), {} };
+    return CLX_OK;
+}
+
+extern "C" int clx_reader_streaminfo(const clx_reader* r, clx_streaminfo* out) {
+    if (!r || !out) return CLX_API_ERROR;
+    *out = r->reader.streaminfo();
+    return CLX_OK;
+}
+
+extern "C" int clx_reader_next_block(clx_reader* r, int32_t* buffer, size_t cap, clx_block_info* info, uint32_t* msg) {
+    if (msg) *msg = CLX_MSG_NONE;
+    if (!r || !info) return CLX_API_ERROR;
+    claxon::FrameResult fr = r->reader.blocks().read_next_or_eof(std::move(r->recycle));
+    r->recycle.clear();
+    if (fr.is_err) { if (msg) *msg = fr.error.msg; return fr.error.status; }
+    if (!fr.has_block) return CLX_END_OF_STREAM;
+    info->time = fr.block.time(); info->block_size = fr.block.duration(); info->channels = fr.block.channels();
+    if ((size_t)fr.block.len() > cap || (!buffer && fr.block.len())) return CLX_API_ERROR;
+    std::vector<int32_t> buf = fr.block.into_buffer();
+    std::memcpy(buffer, buf.data(), buf.size() * sizeof(int32_t));
+    r->recycle = std::move(buf);
+    return CLX_OK;
+}
+
+extern "C" void clx_reader_close(clx_reader* r) { delete r; }

@@ -1,0 +1,43 @@
+// clx_device.h -- device-side records shared by the host library and the HIP kernels.
+//
+// Data layout in HBM:
+//   arena   : the compressed frames, byte for byte as in the FLAC stream (16-byte aligned base)
+//   frames  : one clx_dev_frame per frame (32 B) -- what read_frame_header_or_eof (frame.rs:131-316)
+//             yields, plus where the decode goes
+//   sfdesc  : one clx_sf_desc per predictor slot (80 B): the parsed subframe header K1 hands to K2
+//   out     : planar i32 PCM; frame i's channel c at out[out_off + c*block_size ...) (frame.rs:409-410)
+//   results : one clx_frame_result per frame
+#ifndef CLX_DEVICE_H
+#define CLX_DEVICE_H
+
+#include <stdint.h>
+
+struct clx_dev_frame {
+    uint64_t byte_off;       // frame start (sync code) in the arena
+    uint64_t out_off;        // sample index of channel 0 in `out`
+    uint32_t limit_bits;     // readable bits from byte_off: 8*min(max_bytes, arena_len-byte_off), capped at 2^31
+    uint32_t first_slot;     // predictor slot of subframe 0 (even for stereo-decorrelated frames)
+    uint16_t header_bytes;   // first subframe starts at byte_off+header_bytes
+    uint16_t block_size;
+    uint8_t  n_channels;
+    uint8_t  channel_assignment;   // CLX_CH_*
+    uint8_t  bps;
+    uint8_t  flags;          // bit0: bare subframe (no CRC-16 footer)
+};
+
+struct clx_sf_desc {
+    uint64_t out_base;       // sample index of this subframe's first sample in `out`
+    uint32_t n;              // block size; 0 = empty slot / frame failed before this subframe was parsed
+    uint8_t  order;          // IIR taps (0: constant/verbatim/fixed-0; fixed 1..4; lpc 1..32)
+    uint8_t  shift;          // qlp shift (0 for fixed predictors)
+    uint8_t  wasted;         // wasted bits per sample: final left shift (subframe.rs:216-225)
+    uint8_t  decor;          // CLX_CH_* of the frame (0 = independent): stereo decorrelation role
+    int16_t  coef[32];       // coef[j] multiplies s[i-1-j] (first coded coefficient <-> newest sample)
+};
+
+#ifdef __cplusplus
+static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
+static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
+#endif
+
+#endif

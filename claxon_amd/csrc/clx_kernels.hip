@@ -1,0 +1,633 @@
+// clx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the batched FLAC frame decoder.
+//
+//   K1  clx_k_residual   one wavefront per frame: subframe headers, warm-up samples, LPC coefficients,
+//                        Rice/Rice2 partitioned residual decode (wave-parallel), CONSTANT / VERBATIM fill.
+//                        Replaces subframe.rs:29-91, 236-415, 492-511, 651-708 and the channel dispatch
+//                        of frame.rs:705-742 (one bit cursor, subframes in sequence).
+//   K2  clx_k_predict    one lane per channel: fixed / LPC synthesis as an integer IIR (i64 accumulate,
+//                        arithmetic >> shift, wrapping i32), wasted-bits shift, and the left/side,
+//                        right/side, mid/side decorrelation fused into the coalesced write-back.
+//                        Replaces subframe.rs:216-225, 417-474, 524-614 and frame.rs:319-389.
+//   K3  clx_k_crc16      one wavefront per frame: CRC-16 of the frame's bytes against its footer
+//                        (frame.rs:752-763, crc.rs:109-112) as a GF(2) fold of per-lane partial CRCs.
+//
+// No MFMA anywhere: this is bit-serial / integer-recurrence work bounded by HBM traffic and issue
+// latency, not a dense contraction.  All data-dependent control flow around cross-lane operations
+// (ballot / shuffle / barrier) is kept wave-uniform.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/claxon_hip.h"
+#include "clx_device.h"
+
+#define CLX_NW 512u            // LDS bitstream window: 512 big-endian-normalised dwords = 2 KiB per wave
+#define CLX_STAGE 1024u        // LDS residual staging (values per span)
+
+// ------------------------------------------------------------------------------------------------
+// Bit window: a 2 KiB slice of the frame's bytes staged in LDS with coalesced 16-byte loads.  Dwords
+// are byte-swapped on the way in so that FLAC's MSB-first bit order (input.rs:447-468) becomes plain
+// shifts.  Bit positions (`pos`) are relative to `origin` = the arena's 16-byte granule holding the
+// frame's first byte, so every global access is a naturally aligned dword / dwordx4.
+// ------------------------------------------------------------------------------------------------
+struct K1Lds {
+    uint32_t W[CLX_NW + 4];
+    uint32_t tab[8][64];       // tab[g][lane]: exit states of that lane's chunk for entry states 4g..4g+3
+    uint8_t  gtab[8][32];      // gtab[g][s]: exit state of lane group g (8 lanes) for entry state s
+    int32_t  stage[CLX_STAGE];
+};
+
+struct BitSrc {
+    const uint32_t* origin;    // arena + (byte_off & ~15)
+    uint32_t avail_dw;         // dwords readable from origin (arena allocation is padded to 16 B)
+    uint32_t win_dw;           // first dword (relative to origin) held in L.W
+};
+
+__device__ __forceinline__ uint32_t clx_gload_dw(const BitSrc& b, uint32_t dw) {
+    return dw < b.avail_dw ? __builtin_bswap32(b.origin[dw]) : 0u;
+}
+
+// (Re)stage the window so that it starts at the 16-byte granule containing bit `pos`.  Wave-uniform.
+__device__ __forceinline__ void clx_window_load(K1Lds& L, BitSrc& b, uint32_t pos, int lane) {
+    __syncthreads();
+    b.win_dw = (pos >> 5) & ~3u;
+#pragma unroll
+    for (int r = 0; r < (int)(CLX_NW / 256); ++r) {
+        uint32_t dw = b.win_dw + 4u * (uint32_t)(lane + 64 * r);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (dw + 4u <= b.avail_dw) v = *reinterpret_cast<const uint4*>(b.origin + dw);
+        else if (dw < b.avail_dw) {           // ragged tail (never happens with a 16-byte padded arena)
+            v.x = b.origin[dw];
+            if (dw + 1 < b.avail_dw) v.y = b.origin[dw + 1];
+            if (dw + 2 < b.avail_dw) v.z = b.origin[dw + 2];
+        }
+        uint32_t* dst = &L.W[4 * (lane + 64 * r)];
+        dst[0] = __builtin_bswap32(v.x); dst[1] = __builtin_bswap32(v.y);
+        dst[2] = __builtin_bswap32(v.z); dst[3] = __builtin_bswap32(v.w);
+    }
+    if (lane < 4) L.W[CLX_NW + lane] = clx_gload_dw(b, b.win_dw + CLX_NW + (uint32_t)lane);
+    __syncthreads();
+}
+
+// Make sure bits [pos, pos+nbits) (+ one dword of slack) are inside the LDS window.  Wave-uniform.
+__device__ __forceinline__ void clx_window_ensure(K1Lds& L, BitSrc& b, uint32_t pos, uint32_t nbits, int lane) {
+    uint32_t first = pos >> 5, last = (pos + nbits + 63u) >> 5;
+    if (first < b.win_dw || last >= b.win_dw + CLX_NW) clx_window_load(L, b, pos, lane);
+}
+
+// 32 bits starting at bit `pos`, left aligned.  LDS when inside the window, else (rare) global memory.
+__device__ __forceinline__ uint32_t clx_peek32(const K1Lds& L, const BitSrc& b, uint32_t pos) {
+    uint32_t dw = pos >> 5, off = pos & 31u;
+    uint32_t i = dw - b.win_dw;
+    uint32_t hi, lo;
+    if (i < CLX_NW + 3u) { hi = L.W[i]; lo = L.W[i + 1]; }
+    else { hi = clx_gload_dw(b, dw); lo = clx_gload_dw(b, dw + 1); }
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)((v << off) >> 32);
+}
+
+// `bits` (1..32) bits at `pos`, right aligned; 0 bits -> 0 (read_leq_u8(0) == 0, input.rs:706).
+__device__ __forceinline__ uint32_t clx_peek_bits(const K1Lds& L, const BitSrc& b, uint32_t pos, uint32_t bits) {
+    return bits ? (clx_peek32(L, b, pos) >> (32u - bits)) : 0u;
+}
+// sign-extended `bits`-wide field (extend_sign_u32, subframe.rs:117-122)
+__device__ __forceinline__ int32_t clx_peek_signed(const K1Lds& L, const BitSrc& b, uint32_t pos, uint32_t bits) {
+    return (int32_t)clx_peek32(L, b, pos) >> (32u - bits);
+}
+
+__device__ __forceinline__ uint32_t clx_wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    *total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+// value of `v` in the (unique) lane where `pred` holds; `dflt` when there is none.  Wave-uniform result.
+__device__ __forceinline__ uint32_t clx_pick(uint32_t v, bool pred, uint32_t dflt) {
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return dflt;
+    return __shfl(v, __ffsll((long long)m) - 1, 64);
+}
+
+// Exit state of one chunk for one entry state.  A chunk is `B` stream bits held left-aligned in `c`
+// (low 32-B bits zero).  States: m in [0,k] = "m remainder bits still to skip, then a code starts";
+// SC = k+1 = "inside a unary run that started earlier".  subframe.rs:337-341 per code:
+// q zeros, a one, k remainder bits.
+__device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint32_t k, uint32_t m) {
+    const uint32_t SC = k + 1u;
+    uint32_t p = (m == SC) ? 0u : m;
+    for (;;) {
+        if (p >= B) return p - B;
+        uint32_t rest = c << p;
+        if (rest == 0u) return SC;
+        p += (uint32_t)__clz((int)rest) + 1u + k;
+    }
+}
+
+#define CLX_ERR_NONE 0u
+#define CLX_MKERR(status, msg) (((uint32_t)(status) << 16) | (uint32_t)(msg))
+
+// Decode `count` Rice codes with parameter k starting at bit `pos` into dst[0..count).
+// Returns the bit position after the last code; *err != 0 on EOF.  Wave-uniform control flow.
+//
+// Per span of 64 lanes x B bits: (1) every lane walks its chunk once per possible entry state and
+// publishes the exit states; (2) a three-level walk over the 64 chunks (8 groups of 8) resolves every
+// lane's true entry state; (3) lanes mark the codes that *start* in their chunk, a wave prefix sum gives
+// output indices; (4) each lane extracts its codes (clz for the unary part, shift for the remainder)
+// into LDS, from where they are written to HBM coalesced.
+__device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32_t k, uint32_t count,
+                                       int32_t* dst, uint32_t limit, uint32_t* err, int lane) {
+    const uint32_t SC = k + 1u, ns = k + 2u;
+    uint32_t done = 0;
+    while (done < count) {
+        const uint32_t remaining = count - done;
+        const uint32_t expect = remaining * (k + 2u);
+        uint32_t B = expect <= 256u ? 4u : expect <= 512u ? 8u : expect <= 1024u ? 16u : 32u;
+        if (k == 0u && B == 32u) B = 16u;                   // at most CLX_STAGE codes per span
+        clx_window_ensure(L, b, pos, 64u * B + 64u, lane);
+
+        const uint32_t cpos = pos + B * (uint32_t)lane;
+        uint32_t c = clx_peek32(L, b, cpos);
+        if (B < 32u) c &= ~(0xffffffffu >> B);
+
+        // (1) exit-state tables
+        for (uint32_t g = 0; 4u * g < ns; ++g) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                uint32_t m = 4u * g + j;
+                uint32_t ex = (m < ns) ? clx_chunk_exit(c, B, k, m) : 0u;
+                packed |= ex << (8u * j);
+            }
+            L.tab[g][lane] = packed;
+        }
+        __syncthreads();
+        // (2a) group tables: lane (g8, e) walks group g8's 8 chunks for entry states e, e+8, ...
+        {
+            const uint32_t g8 = (uint32_t)lane >> 3;
+            for (uint32_t st = (uint32_t)lane & 7u; st < ns; st += 8u) {
+                uint32_t m = st;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i)
+                    m = (L.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
+                L.gtab[g8][st] = (uint8_t)m;
+            }
+        }
+        __syncthreads();
+        // (2b) across groups (uniform), (2c) inside each group
+        uint32_t my_entry = 0;
+        {
+            uint32_t m = 0, mine = 0;                       // a span always begins at a code start
+#pragma unroll
+            for (uint32_t g = 0; g < 8; ++g) {
+                if (((uint32_t)lane >> 3) == g) mine = m;
+                m = L.gtab[g][m];
+            }
+            m = mine;
+            const uint32_t g8 = (uint32_t)lane >> 3;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) {
+                if (((uint32_t)lane & 7u) == i) my_entry = m;
+                m = (L.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
+            }
+        }
+        // (3) starts in my chunk
+        uint32_t S = 0;
+        {
+            uint32_t p = (my_entry == SC) ? 0u : my_entry;
+            bool fresh = (my_entry != SC);
+            while (p < B) {
+                if (fresh) S |= 1u << p;
+                fresh = true;
+                uint32_t rest = c << p;
+                if (rest == 0u) break;
+                p += (uint32_t)__clz((int)rest) + 1u + k;
+            }
+        }
+        const uint32_t cnt = (uint32_t)__popc(S);
+        uint32_t total;
+        const uint32_t prefix = clx_wave_excl_scan(cnt, lane, &total);
+        const uint32_t ntake = total < remaining ? total : remaining;
+
+        // (4) extraction
+        uint32_t maxcnt = cnt;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            uint32_t o = __shfl_xor(maxcnt, d, 64);
+            maxcnt = o > maxcnt ? o : maxcnt;
+        }
+        bool eof = false;
+        uint32_t edge_pos = 0; bool have_edge = false;      // start #remaining, or end of code #total-1
+        uint32_t Sit = S;
+        for (uint32_t j = 0; j < maxcnt; ++j) {
+            if (Sit != 0u) {
+                const uint32_t p = (uint32_t)__ffs((int)Sit) - 1u;
+                Sit &= Sit - 1u;
+                const uint32_t s = cpos + p;
+                const uint32_t idx = prefix + j;
+                if (idx < ntake) {
+                    uint32_t v = clx_peek32(L, b, s);
+                    uint32_t t = s;                          // terminator position
+                    if (v == 0u) {                           // long unary run (subframe.rs:326-328: rare)
+                        t = s + 32u;
+                        while (t < limit) { v = clx_peek32(L, b, t); if (v != 0u) break; t += 32u; }
+                    }
+                    uint32_t end;
+                    int32_t val = 0;
+                    if (v == 0u) { eof = true; end = limit + 1u; }
+                    else {
+                        const uint32_t z = (uint32_t)__clz((int)v);
+                        t += z;
+                        const uint32_t q = t - s;
+                        end = t + 1u + k;
+                        uint32_t r;
+                        if (k == 0u) r = 0u;
+                        else if (z + 1u + k <= 32u) r = (v << (z + 1u)) >> (32u - k);         // whole code inside the 32-bit peek
+                        else r = clx_peek_bits(L, b, t + 1u, k);
+                        const uint32_t u = (q << k) | r;     // u32 wrapping shift, subframe.rs:340
+                        val = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                         // rice_to_signed, subframe.rs:157-170
+                        if (end > limit) eof = true;
+                    }
+                    L.stage[idx] = val;
+                    if (idx + 1u == total && total <= remaining) { edge_pos = end; have_edge = true; }
+                } else if (idx == remaining) { edge_pos = s; have_edge = true; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = (uint32_t)lane; i < ntake; i += 64u) dst[done + i] = L.stage[i];
+        const uint32_t newpos = clx_pick(edge_pos, have_edge, limit + 1u);
+        if (__any(eof)) { *err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); return newpos; }
+        done += ntake;
+        pos = newpos;
+        __syncthreads();
+    }
+    return pos;
+}
+
+// Sequential header reader: mirrors the reference's sequence of Bitstream calls one for one, so that
+// the FIRST error in stream order wins (EOF vs format error), exactly as `try!` does.
+struct HdrReader {
+    uint32_t pos, limit, err;
+};
+__device__ __forceinline__ bool clx_hdr_bits(const K1Lds& L, const BitSrc& b, HdrReader& h, uint32_t n, uint32_t* v) {
+    if (h.pos + n > h.limit) { h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); return false; }
+    *v = clx_peek_bits(L, b, h.pos, n);
+    h.pos += n;
+    return true;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
+                    const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
+                    int32_t* __restrict__ out, clx_sf_desc* __restrict__ sfd,
+                    clx_frame_result* __restrict__ results) {
+    __shared__ K1Lds L;
+    const int lane = (int)threadIdx.x;
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames) return;
+    const clx_dev_frame fr = frames[f];
+
+    BitSrc b;
+    const uint64_t origin_byte = fr.byte_off & ~15ull;
+    b.origin = reinterpret_cast<const uint32_t*>(arena + origin_byte);
+    {
+        uint64_t a = (arena_alloc_len > origin_byte) ? ((arena_alloc_len - origin_byte) >> 2) : 0ull;
+        b.avail_dw = a > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)a;
+    }
+    b.win_dw = 0;
+    const uint32_t o = 8u * (uint32_t)(fr.byte_off & 15ull);          // bit offset of the frame inside its granule
+    HdrReader h;
+    h.limit = o + fr.limit_bits;
+    h.pos = o + 8u * (uint32_t)fr.header_bytes;
+    h.err = CLX_ERR_NONE;
+    if (h.pos > h.limit) h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    clx_window_load(L, b, h.pos < h.limit ? h.pos : o, lane);
+
+    const uint32_t bs = fr.block_size;
+    const uint32_t ca = fr.channel_assignment;
+
+    for (uint32_t ch = 0; ch < fr.n_channels && h.err == CLX_ERR_NONE; ++ch) {
+        // side channels carry one extra bit (frame.rs:713-741)
+        uint32_t bps = fr.bps;
+        if ((ca == CLX_CH_LEFT_SIDE && ch == 1) || (ca == CLX_CH_RIGHT_SIDE && ch == 0) ||
+            (ca == CLX_CH_MID_SIDE && ch == 1)) bps += 1u;
+        int32_t* const chan = out + fr.out_off + (uint64_t)ch * bs;
+        clx_window_ensure(L, b, h.pos, 128u, lane);
+
+        // ---- read_subframe_header, subframe.rs:29-91
+        uint32_t v;
+        if (!clx_hdr_bits(L, b, h, 1, &v)) break;
+        if (v) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_SUBFRAME_HEADER_INVALID); break; }
+        if (!clx_hdr_bits(L, b, h, 6, &v)) break;
+        uint32_t kind, order = 0;               // kind: 0 constant, 1 verbatim, 2 fixed, 3 lpc
+        if (v == 0u) kind = 0;
+        else if (v == 1u) kind = 1;
+        else if ((v & 0x3eu) == 0x02u || (v & 0x3cu) == 0x04u || (v & 0x30u) == 0x10u) {
+            h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_SUBFRAME_HEADER_RESERVED); break;
+        } else if ((v & 0x38u) == 0x08u) {
+            order = v & 7u;
+            if (order > 4u) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_SUBFRAME_HEADER_RESERVED); break; }
+            kind = 2;
+        } else { kind = 3; order = (v & 0x1fu) + 1u; }
+        if (!clx_hdr_bits(L, b, h, 1, &v)) break;
+        uint32_t wasted = 0;
+        if (v) {                                 // 1 + read_unary (subframe.rs:73-77)
+            uint32_t t = h.pos; uint32_t w = 0; bool found = false;
+            while (t < h.limit) {
+                w = clx_peek32(L, b, t);
+                if (w != 0u) { found = true; break; }
+                t += 32u;
+            }
+            if (found) { t += (uint32_t)__clz((int)w); if (t >= h.limit) found = false; }
+            if (!found) { h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); break; }
+            wasted = 1u + (t - h.pos);
+            h.pos = t + 1u;
+            if (wasted > 31u) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_WASTED_BITS_EXCEED_31); break; }
+        }
+        // ---- subframe::decode, subframe.rs:198-211
+        if (wasted >= bps) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_NO_NON_WASTED_BITS); break; }
+        const uint32_t sf_bps = bps - wasted;
+
+        uint32_t qshift = 0;
+        int32_t my_coef = 0;                     // lane j holds coef[j] (j < order)
+
+        if (kind == 0u) {                        // decode_constant, subframe.rs:382-394
+            if (h.pos + sf_bps > h.limit) { h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); break; }
+            const int32_t s = clx_peek_signed(L, b, h.pos, sf_bps);
+            h.pos += sf_bps;
+            for (uint32_t i = (uint32_t)lane; i < bs; i += 64u) chan[i] = s;
+        } else if (kind == 1u) {                 // decode_verbatim, subframe.rs:397-415
+            if ((uint64_t)h.pos + (uint64_t)bs * sf_bps > (uint64_t)h.limit) {
+                h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); break;
+            }
+            for (uint32_t i0 = 0; i0 < bs; i0 += 64u) {
+                clx_window_ensure(L, b, h.pos + i0 * sf_bps, 64u * sf_bps + 32u, lane);
+                const uint32_t i = i0 + (uint32_t)lane;
+                if (i < bs) chan[i] = clx_peek_signed(L, b, h.pos + i * sf_bps, sf_bps);
+            }
+            h.pos += bs * sf_bps;
+        } else {
+            // decode_fixed (subframe.rs:492-516) / decode_lpc (subframe.rs:651-721)
+            if (bs < order) {
+                h.err = CLX_MKERR(CLX_FORMAT_ERROR, kind == 2u ? CLX_MSG_FIXED_ORDER_GT_BLOCK : CLX_MSG_LPC_ORDER_GT_BLOCK);
+                break;
+            }
+            // warm-up samples: `order` verbatim fields, one per lane
+            if (h.pos + order * sf_bps > h.limit) { h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); break; }
+            clx_window_ensure(L, b, h.pos, order * sf_bps + 32u * 15u + 64u, lane);
+            if ((uint32_t)lane < order) chan[lane] = clx_peek_signed(L, b, h.pos + (uint32_t)lane * sf_bps, sf_bps);
+            h.pos += order * sf_bps;
+            if (kind == 3u) {
+                if (!clx_hdr_bits(L, b, h, 4, &v)) break;
+                const uint32_t precision = v + 1u;
+                if (v == 15u) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_QLP_PRECISION_INVALID); break; }
+                if (!clx_hdr_bits(L, b, h, 5, &v)) break;
+                if (v & 0x10u) { h.err = CLX_MKERR(CLX_UNSUPPORTED, CLX_MSG_NEGATIVE_QLP_SHIFT); break; }
+                qshift = v;
+                if (h.pos + order * precision > h.limit) { h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); break; }
+                // j-th coded coefficient applies to s[i-1-j] (stored reversed in the reference, subframe.rs:696-701)
+                if ((uint32_t)lane < order) my_coef = clx_peek_signed(L, b, h.pos + (uint32_t)lane * precision, precision);
+                h.pos += order * precision;
+            } else {
+                // fixed predictors as IIR taps on s[i-1-j] (subframe.rs:427-431, oldest-to-newest there)
+                my_coef = (order == 1u) ? (lane == 0 ? 1 : 0)
+                        : (order == 2u) ? (lane == 0 ? 2 : lane == 1 ? -1 : 0)
+                        : (order == 3u) ? (lane == 0 ? 3 : lane == 1 ? -3 : lane == 2 ? 1 : 0)
+                        : (order == 4u) ? (lane == 0 ? 4 : lane == 1 ? -6 : lane == 2 ? 4 : lane == 3 ? -1 : 0) : 0;
+            }
+            // ---- decode_residual, subframe.rs:236-304
+            if (!clx_hdr_bits(L, b, h, 2, &v)) break;
+            if (v > 1u) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_RESIDUAL_RESERVED); break; }
+            const uint32_t rice2 = v;
+            if (!clx_hdr_bits(L, b, h, 4, &v)) break;
+            const uint32_t porder = v;
+            const uint32_t n_part = 1u << porder;
+            const uint32_t per = bs >> porder;
+            if ((bs & (n_part - 1u)) != 0u) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_INVALID_PARTITION_ORDER); break; }
+            if (order > per) { h.err = CLX_MKERR(CLX_FORMAT_ERROR, CLX_MSG_INVALID_RESIDUAL); break; }
+            uint32_t start = order;
+            uint32_t len = per - order;
+            for (uint32_t part = 0; part < n_part; ++part) {
+                clx_window_ensure(L, b, h.pos, 64u, lane);
+                if (!clx_hdr_bits(L, b, h, rice2 ? 5u : 4u, &v)) break;
+                if (v == (rice2 ? 31u : 15u)) { h.err = CLX_MKERR(CLX_UNSUPPORTED, CLX_MSG_UNENCODED_BINARY); break; }
+                uint32_t perr = CLX_ERR_NONE;
+                h.pos = clx_rice_partition(L, b, h.pos, v, len, chan + start, h.limit, &perr, lane);
+                if (perr != CLX_ERR_NONE) { h.err = perr; break; }
+                start += len;
+                len = per;
+            }
+            if (h.err != CLX_ERR_NONE) break;
+        }
+        // ---- hand the predictor to K2
+        {
+            const uint32_t slot = fr.first_slot + ch;
+            clx_sf_desc* d = &sfd[slot];
+            if ((uint32_t)lane < 32u) d->coef[lane] = (int16_t)((uint32_t)lane < order ? my_coef : 0);
+            if (lane == 0) {
+                d->out_base = fr.out_off + (uint64_t)ch * bs;
+                d->order = (uint8_t)((kind >= 2u) ? order : 0u);
+                d->shift = (uint8_t)qshift;
+                d->wasted = (uint8_t)wasted;
+                d->decor = (uint8_t)ca;
+                d->n = bs;
+            }
+        }
+    }
+    if (lane == 0) {
+        clx_frame_result r;
+        r.status = (int32_t)(h.err >> 16);
+        r.msg = h.err & 0xffffu;
+        r.end_bit = (uint64_t)(h.pos - o);
+        results[f] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: predictor synthesis + wasted-bits shift + stereo decorrelation.  One lane per subframe
+// ("predictor slot"); 64 slots per wave; T = 32 samples per tile.  A tile is read from HBM
+// coalesced (two 128-byte row segments per load instruction), transposed through LDS so that each
+// lane walks its own channel, and written back through the same transposition with the
+// left/side, right/side or mid/side reconstruction applied on the way out.
+// ------------------------------------------------------------------------------------------------
+#define CLX_T 32
+
+struct K2Lds {
+    int32_t  tile[64][CLX_T + 1];
+    uint64_t rowbase[64];
+    uint32_t rown[64];
+    uint32_t rowdecor[64];
+};
+
+template <int OMAX>
+__device__ __forceinline__ void clx_predict_loop(K2Lds& L, int32_t* __restrict__ out, const clx_sf_desc* __restrict__ mydesc,
+                                                 uint32_t n, uint32_t order, uint32_t shift, uint32_t wasted,
+                                                 uint32_t nmax, int lane) {
+    int32_t c[OMAX];
+    int32_t hist[OMAX];
+#pragma unroll
+    for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)mydesc->coef[j] : 0; hist[j] = 0; }
+
+    const int half = lane >> 5, col = lane & 31;
+    int32_t pre[CLX_T];
+    // prefetch tile 0
+#pragma unroll
+    for (int it = 0; it < CLX_T; ++it) {
+        const int row = it * 2 + half;
+        const uint32_t idx = (uint32_t)col;
+        pre[it] = (idx < L.rown[row]) ? out[L.rowbase[row] + idx] : 0;
+    }
+    for (uint32_t t0 = 0; t0 < nmax; t0 += CLX_T) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < CLX_T; ++it) L.tile[it * 2 + half][col] = pre[it];
+        __syncthreads();
+        // prefetch the next tile while this one is being computed
+        if (t0 + CLX_T < nmax) {
+#pragma unroll
+            for (int it = 0; it < CLX_T; ++it) {
+                const int row = it * 2 + half;
+                const uint32_t idx = t0 + CLX_T + (uint32_t)col;
+                pre[it] = (idx < L.rown[row]) ? out[L.rowbase[row] + idx] : 0;
+            }
+        }
+        // the recurrence: s[i] = x[i] + ((sum_j c[j]*s[i-1-j]) >> shift), subframe.rs:559-566, 575-582, 606-613
+#pragma unroll
+        for (int i = 0; i < CLX_T; ++i) {
+            const int32_t x = L.tile[lane][i];
+            int64_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) acc += (int64_t)c[j] * (int64_t)hist[j];
+            const int32_t pred = (int32_t)(acc >> shift);
+            const int32_t s = (t0 + (uint32_t)i >= order) ? (int32_t)((uint32_t)x + (uint32_t)pred) : x;
+#pragma unroll
+            for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
+            hist[0] = s;
+            L.tile[lane][i] = (int32_t)((uint32_t)s << wasted);                 // wrapping_shl, subframe.rs:223
+        }
+        __syncthreads();
+        // write back, decorrelating stereo pairs (rows 2r, 2r+1) on the way out
+#pragma unroll
+        for (int it = 0; it < CLX_T; ++it) {
+            const int row = it * 2 + half;
+            const uint32_t idx = t0 + (uint32_t)col;
+            const uint32_t rn = L.rown[row];
+            if (idx < rn) {
+                int32_t v = L.tile[row][col];
+                const uint32_t d = L.rowdecor[row];
+                if (d != CLX_CH_INDEPENDENT && L.rown[row ^ 1] == rn) {
+                    const int32_t a = L.tile[row & ~1][col];                   // channel 0 as coded
+                    const int32_t bb = L.tile[row | 1][col];                   // channel 1 as coded
+                    if (d == CLX_CH_LEFT_SIDE) {                               // frame.rs:319-334
+                        if (row & 1) v = (int32_t)((uint32_t)a - (uint32_t)bb);
+                    } else if (d == CLX_CH_RIGHT_SIDE) {                       // frame.rs:345-360
+                        if (!(row & 1)) v = (int32_t)((uint32_t)a + (uint32_t)bb);
+                    } else {                                                   // frame.rs:371-389
+                        const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
+                        // m +- side is even, so Rust's truncating `/ 2` equals an arithmetic shift
+                        v = (row & 1) ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1)
+                                      : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
+                    }
+                }
+                out[L.rowbase[row] + idx] = v;
+            }
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots) {
+    __shared__ K2Lds L;
+    const int lane = (int)threadIdx.x;
+    const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+    uint32_t n = 0, order = 0, shift = 0, wasted = 0, decor = 0;
+    uint64_t base = 0;
+    const clx_sf_desc* d = &sfd[slot < n_slots ? slot : 0];
+    if (slot < n_slots) {
+        n = d->n; order = d->order; shift = d->shift; wasted = d->wasted; decor = d->decor; base = d->out_base;
+    }
+    if (n == 0u) { order = 0; shift = 0; wasted = 0; decor = 0; }
+    L.rowbase[lane] = base; L.rown[lane] = n; L.rowdecor[lane] = decor;
+    uint32_t nmax = n, omax = order;
+    bool work = (order != 0u) || (wasted != 0u) || (decor != 0u);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
+        uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
+    }
+    __syncthreads();
+    // a wave of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits is already final
+    if (nmax == 0u || !__any(work)) return;
+    if (omax <= 4u)       clx_predict_loop<4>(L, out, d, n, order, shift, wasted, nmax, lane);
+    else if (omax <= 8u)  clx_predict_loop<8>(L, out, d, n, order, shift, wasted, nmax, lane);
+    else if (omax <= 12u) clx_predict_loop<12>(L, out, d, n, order, shift, wasted, nmax, lane);
+    else                  clx_predict_loop<32>(L, out, d, n, order, shift, wasted, nmax, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: CRC-16 (poly 0x8005, init 0, MSB first; crc.rs:69, 109-112) of each successfully decoded
+// frame's bytes [byte_off, byte_off + ceil(end_bit/8)) against the big-endian footer that follows
+// (frame.rs:752-763).  CRC with init 0 is linear: crc(A||B) = crc(A)*x^(8|B|) mod P  xor  crc(B).
+// Each lane folds a contiguous slice, then the slices are combined right to left.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t clx_crc16_byte(uint32_t crc, uint32_t byte) {
+    crc ^= byte << 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x8005u) & 0xffffu : (crc << 1) & 0xffffu;
+    return crc;
+}
+// (a * b) mod P over GF(2), 16-bit polynomials
+__device__ __forceinline__ uint32_t clx_gf_mulmod(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+        r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu;
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+// x^(8*nbytes) mod P
+__device__ __forceinline__ uint32_t clx_xpow8(uint32_t nbytes) {
+    uint32_t result = 1u;            // x^0
+    uint32_t base = 0x0100u;         // x^8
+    while (nbytes) {
+        if (nbytes & 1u) result = clx_gf_mulmod(result, base);
+        base = clx_gf_mulmod(base, base);
+        nbytes >>= 1;
+    }
+    return result;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_crc16(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
+                 clx_frame_result* __restrict__ results) {
+    const int lane = (int)threadIdx.x;
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames) return;
+    const clx_dev_frame fr = frames[f];
+    clx_frame_result r = results[f];
+    if (r.status != CLX_OK || (fr.flags & 1u)) return;
+    const uint32_t nbytes = (uint32_t)((r.end_bit + 7u) >> 3);
+    if ((uint64_t)nbytes * 8u + 16u > (uint64_t)fr.limit_bits) {           // read_be_u16 fails: frame.rs:754
+        if (lane == 0) { results[f].status = CLX_IO_ERROR; results[f].msg = CLX_MSG_UNEXPECTED_EOF; }
+        return;
+    }
+    const uint8_t* p = arena + fr.byte_off;
+    const uint32_t per = (nbytes + 63u) / 64u;
+    const uint32_t lo = (uint32_t)lane * per < nbytes ? (uint32_t)lane * per : nbytes;
+    const uint32_t hi = lo + per < nbytes ? lo + per : nbytes;
+    uint32_t crc = 0;
+    for (uint32_t i = lo; i < hi; ++i) crc = clx_crc16_byte(crc, p[i]);
+    // combine: lane L's CRC must be advanced over all bytes to its right
+    const uint32_t tail = nbytes - hi;
+    uint32_t contrib = (hi > lo) ? clx_gf_mulmod(crc, clx_xpow8(tail)) : 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) contrib ^= __shfl_xor(contrib, s, 64);
+    if (lane == 0) {
+        const uint32_t presumed = ((uint32_t)p[nbytes] << 8) | (uint32_t)p[nbytes + 1];
+        if (contrib != presumed) { results[f].status = CLX_FORMAT_ERROR; results[f].msg = CLX_MSG_FRAME_CRC_MISMATCH; }
+    }
+}

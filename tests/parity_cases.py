@@ -1,0 +1,124 @@
+"""Parity cases shared by the wave-simulator tests (CPU, `-m "not gpu"`) and the GPU tests (`-m gpu`):
+each runs the product path (host header parser + HIP kernels through a backend) and compares it with
+the oracle on the same seeded inputs -- bit-exact samples, identical status / message / end_bit."""
+import glob
+import os
+
+import numpy as np
+
+import claxon_amd as cx
+import synth
+from claxon_msgs import MSG, MSG_NAME
+from conftest import FIXTURES
+from parity_util import assert_same_as_oracle, product_frame_decode
+
+
+def workload_descs(w):
+    if w.bare_subframes:
+        return cx.descs_for_subframes(w.offs, w.block_sizes, w.bps)
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
+    return descs
+
+
+def check_workload(oracle, backend, w, verify_crc=True):
+    """decode(w) == source PCM == oracle decode; statuses OK; end_bit matches the oracle."""
+    descs = workload_descs(w)
+    out, res = backend.decode(w.arena, w.arena_len, descs, w.out_offs, verify_crc and not w.bare_subframes,
+                              fill=0x5a5a5a5a)
+    assert np.all(res["status"] == cx.OK), (np.unique(res["status"]), [MSG_NAME[m] for m in np.unique(res["msg"])])
+    assert np.array_equal(out[:w.pcm.size], w.pcm)
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    if w.bare_subframes:
+        r = oracle.decode_subframes(w.arena[:w.arena_len], w.offs, w.block_sizes, w.bps, out=ref, out_offs=w.out_offs)
+    else:
+        r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs)
+    assert np.array_equal(out[:w.pcm.size], ref)
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+
+
+def check_truncations(oracle, backend, n_frames=8, cuts_per_frame=24, seed=1000):
+    """EOF parity: every prefix of a frame must fail (or succeed) exactly as the reference does."""
+    w = synth.small_mixed(n_frames, bs=64, seed_off=seed)
+    seen = set()
+    for i in range(w.n):
+        fr = w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])]
+        L = len(fr)
+        rng = np.random.default_rng(seed + i)
+        cuts = sorted(set(list(range(0, min(L, 12))) + rng.integers(0, L, cuts_per_frame).tolist() + [L - 3, L - 2, L - 1, L]))
+        for c in cuts:
+            if c < 0:
+                continue
+            seen.add(assert_same_as_oracle(oracle, backend, fr[:c].copy(), True, "frame %d cut %d/%d" % (i, c, L)))
+    assert (cx.OK, 0) in seen and (cx.IO_ERROR, MSG["CLX_MSG_UNEXPECTED_EOF"]) in seen and (cx.END_OF_STREAM, 0) in seen
+
+
+def check_bitflips(oracle, backend, n_frames=12, trials=16, seed=2000):
+    """Garbage in, the SAME garbage (or the same error) out: wrapping arithmetic, reserved values, first error in
+    stream order.  CRC checks off on both sides, as under cfg(fuzzing)."""
+    w = synth.small_mixed(n_frames, bs=64, seed_off=seed)
+    rng = np.random.default_rng(seed)
+    seen = set()
+    for i in range(w.n):
+        fr = w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])].copy()
+        _, _, h = cx.parse_frame_header(fr)
+        for trial in range(trials):
+            g = fr.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                lo = h.header_bytes * 8
+                hi = min(len(g) * 8, lo + 200) if rng.uniform() < 0.6 else len(g) * 8
+                pos = int(rng.integers(lo, hi))
+                g[pos >> 3] ^= (0x80 >> (pos & 7))
+            seen.add(assert_same_as_oracle(oracle, backend, g, False, "frame %d trial %d" % (i, trial)))
+    return seen
+
+
+def stream_decode_both(oracle, backend, data, check_crc):
+    """FlacReader::new + blocks() loop on both sides; asserts equality frame by frame."""
+    data = np.frombuffer(bytes(data), dtype=np.uint8)
+    st, msg, si, off = cx.read_stream_header(data)
+    st2, msg2, si2, off2 = oracle.stream_open(data)
+    assert (st, msg) == (st2, msg2)
+    if st != cx.OK:
+        return ("open", st, msg), [], None
+    assert off == off2 and bytes(si.md5sum) == bytes(si2.md5sum)
+    pos, blocks = off, []
+    while True:
+        info, ref = oracle.frame_decode(data[pos:], check_crc)
+        st, msg, eb, got, h = product_frame_decode(backend, data[pos:].copy(), check_crc, fill=13)
+        assert (st, msg) == (info.status, info.msg), (pos, st, msg, info.status, info.msg)
+        if st != cx.OK:
+            return ("end", st, msg), blocks, si
+        assert np.array_equal(got, ref) and eb == info.end_bit
+        blocks.append((h, got))
+        pos += int(info.bytes_consumed)
+
+
+def check_fixtures(oracle, backend):
+    import hashlib
+    md5s = {"pop.flac": "68464288fa5e19835516972dcf47223c", "short.flac": "927598b89c89c1129a152eecfc14075e",
+            "wasted_bits.flac": "4fbca4cf30f188453c0676e0cd700c71", "non_subset.flac": None,
+            "repeated_vorbis_comment.flac": "68464288fa5e19835516972dcf47223c",
+            "empty_vorbis_comment.flac": "68464288fa5e19835516972dcf47223c"}
+    for name, md5 in md5s.items():
+        data = open(os.path.join(FIXTURES, name), "rb").read()
+        end, blocks, si = stream_decode_both(oracle, backend, data, True)
+        assert end == ("end", cx.END_OF_STREAM, 0), (name, end)
+        if md5:
+            nbytes = (si.bits_per_sample + 7) // 8
+            h = hashlib.md5()
+            for hd, s in blocks:
+                inter = s.reshape(hd.n_channels, hd.block_size).T.astype("<i4")
+                h.update(np.ascontiguousarray(inter.view(np.uint8).reshape(hd.block_size, hd.n_channels, 4)[:, :, :nbytes]).tobytes())
+            assert h.hexdigest() == md5, name
+
+
+def check_fuzz_corpus(oracle, backend):
+    seen = set()
+    files = sorted(glob.glob(os.path.join(FIXTURES, "fuzz", "*.flac")))
+    assert len(files) == 23
+    for p in files:
+        data = open(p, "rb").read()
+        for crc in (True, False):
+            end, blocks, _ = stream_decode_both(oracle, backend, data, crc)
+            seen.add(end)
+    assert len(seen) >= 8

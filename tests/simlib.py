@@ -1,0 +1,63 @@
+"""Loader for the wave simulator build of the production kernels (tests/wavesim)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import claxon_amd as cx
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wavesim")
+_SO = os.path.join(_DIR, "libwavesim.so")
+_CSRC = os.path.join(os.path.dirname(_DIR), "..", "claxon_amd", "csrc")
+
+SF_DESC_DTYPE = np.dtype([("out_base", "<u8"), ("n", "<u4"), ("order", "u1"), ("shift", "u1"), ("wasted", "u1"),
+                          ("decor", "u1"), ("coef", "<i2", (32,))])
+assert SF_DESC_DTYPE.itemsize == 80
+
+
+def build(force=False):
+    deps = [os.path.join(_DIR, f) for f in ("sim_lib.cpp", "wavesim.h")] + \
+           [os.path.join(_CSRC, f) for f in ("clx_kernels.hip", "clx_device.h", "clx_plan.h")]
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps):
+        return _SO
+    subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++",
+                           "-I", os.path.join(_DIR, "fake"), "-I", _CSRC, "-o", _SO, os.path.join(_DIR, "sim_lib.cpp")])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.sim_decode_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_only=False, fill=0):
+    """Run K1 (+K2, +K3) under simulation.  `arena` must be 16-byte padded beyond arena_len."""
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    # the simulator reads the arena exactly like the GPU: 16-byte aligned base, padded allocation
+    buf = np.zeros(arena.size + 64, dtype=np.uint8)
+    base = (-buf.ctypes.data) % 16
+    al = buf[base:base + arena.size]
+    al[:] = arena
+    descs = np.ascontiguousarray(descs, dtype=cx.FRAME_DESC_DTYPE)
+    out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+    n = descs.size
+    total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+    if out is None:
+        out = np.full(total, fill, dtype=np.int32)
+    res = np.zeros(n, dtype=cx.FRAME_RESULT_DTYPE)
+    nslots = C.c_uint64(0)
+    sfd = np.zeros(int(descs["n_channels"].sum()) + n + 2, dtype=SF_DESC_DTYPE)
+    flags = (cx.VERIFY_CRC16 if verify_crc else 0) | (0x100 if k1_only else 0)
+    st = lib().sim_decode_frames(al.ctypes.data, arena_len, descs.ctypes.data, n, out.ctypes.data, out_offs.ctypes.data,
+                                 res.ctypes.data, flags, sfd.ctypes.data, C.byref(nslots))
+    assert st == 0
+    return out, res, sfd[:nslots.value]

@@ -1,0 +1,114 @@
+"""The parity tests proper: the HIP path on a real MI355X, through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+import claxon_amd as cx
+import parity_cases as pc
+import synth
+from parity_util import GpuBackend
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    return GpuBackend(cx.Context(0))
+
+
+@pytest.mark.parametrize("make", [
+    lambda: synth.config2(300), lambda: synth.config3(300), lambda: synth.config4(200),
+    lambda: synth.config5_unique(400), lambda: synth.small_mixed(300),
+], ids=["config2", "config3", "config4", "config5", "small_mixed"])
+def test_gpu_workloads(oracle, gpu, make):
+    pc.check_workload(oracle, gpu, make())
+
+
+def test_gpu_truncations(oracle, gpu):
+    pc.check_truncations(oracle, gpu, n_frames=10, cuts_per_frame=24)
+
+
+def test_gpu_bitflips(oracle, gpu):
+    seen = pc.check_bitflips(oracle, gpu, n_frames=24, trials=20)
+    assert len(seen) >= 6
+
+
+def test_gpu_fixtures(oracle, gpu):
+    pc.check_fixtures(oracle, gpu)
+
+
+def test_gpu_fuzz_corpus(oracle, gpu):
+    pc.check_fuzz_corpus(oracle, gpu)
+
+
+def test_gpu_prefill_independence(oracle, gpu):
+    """fuzz/fuzzers/diff.rs idea: decode into buffers pre-filled with 13 and with 17 -- outputs must match."""
+    w = synth.small_mixed(64, seed_off=77)
+    descs = pc.workload_descs(w)
+    a, ra = gpu.decode(w.arena, w.arena_len, descs, w.out_offs, True, fill=13)
+    b, rb = gpu.decode(w.arena, w.arena_len, descs, w.out_offs, True, fill=17)
+    assert np.array_equal(a, b) and np.array_equal(ra, rb)
+
+
+def test_gpu_one_shot_host_api(oracle, gpu):
+    """clx_decode_frames / clx_decode_subframes with HOST buffers (H2D + decode + D2H inside the call)."""
+    w = synth.config3(40)
+    descs = pc.workload_descs(w)
+    out, res = gpu.ctx.decode_frames(w.arena[:w.arena_len], descs, w.out_offs, verify_crc=True)
+    assert np.all(res["status"] == cx.OK) and np.array_equal(out, w.pcm)
+    w = synth.config2(40)
+    out, res = gpu.ctx.decode_subframes(w.arena[:w.arena_len], w.offs, w.block_sizes, w.bps, w.out_offs)
+    assert np.all(res["status"] == cx.OK) and np.array_equal(out, w.pcm)
+
+
+def test_gpu_crc_mismatch_detected(oracle, gpu):
+    """A flipped bit in the *padding* leaves the decode intact but must fail the CRC-16 (frame.rs:761)."""
+    from claxon_msgs import MSG
+    w = synth.config3(4)
+    arena = w.arena.copy()
+    # corrupt the CRC footer of frame 2
+    end = int(w.offs[2] + w.lens[2])
+    arena[end - 1] ^= 0x01
+    descs = pc.workload_descs(w)
+    out, res = gpu.decode(arena, w.arena_len, descs, w.out_offs, True)
+    assert res["status"].tolist() == [0, 0, cx.FORMAT_ERROR, 0]
+    assert int(res["msg"][2]) == MSG["CLX_MSG_FRAME_CRC_MISMATCH"]
+
+
+def test_gpu_flac_reader_streams(oracle, gpu):
+    """FlacReader::open / blocks() (lib.rs:455, 367) on whole streams: host indexer + device batches."""
+    import os
+    from conftest import FIXTURES
+    for name in ("pop.flac", "short.flac", "wasted_bits.flac", "non_subset.flac"):
+        path = os.path.join(FIXTURES, name)
+        si, blocks, st, msg = oracle.decode_stream(open(path, "rb").read())
+        rd = cx.FlacReader.open(gpu.ctx, path)
+        got = list(rd.blocks())
+        assert len(got) == len(blocks)
+        for b, (info, ref) in zip(got, blocks):
+            assert (b.time(), b.duration(), b.channels()) == (info.time, info.block_size, info.channels)
+            assert np.array_equal(b.into_buffer(), ref)
+        assert rd.read_next_or_eof() is None
+    # a longer synthetic stream: fLaC + STREAMINFO + 300 frames back to back
+    w = synth.config5_unique(300)
+    si = bytearray(34)
+    si[0:2] = (4096).to_bytes(2, "big"); si[2:4] = (4096).to_bytes(2, "big")
+    si[10:14] = ((44100 << 12) | (1 << 9) | (15 << 4)).to_bytes(4, "big")
+    stream = b"fLaC" + bytes([0x80, 0, 0, 34]) + bytes(si) + w.arena[:w.arena_len].tobytes()
+    rd = cx.FlacReader(gpu.ctx, data=stream)
+    n = 0
+    for i, b in enumerate(rd.blocks()):
+        ref = w.pcm[int(w.out_offs[i]):int(w.out_offs[i]) + 2 * 4096]
+        assert np.array_equal(b.into_buffer(), ref)
+        n += 1
+    assert n == 300
+    # errors surface exactly like the reference: truncate mid-frame
+    cut = stream[:len(stream) - 1000]
+    rd = cx.FlacReader(gpu.ctx, data=cut)
+    got, err = 0, None
+    try:
+        for b in rd.blocks():
+            got += 1
+    except cx.ClaxonError as e:
+        err = e
+    si2, blocks2, st2, msg2 = oracle.decode_stream(cut)
+    assert got == len(blocks2) and err is not None and (err.status, err.msg) == (st2, msg2)

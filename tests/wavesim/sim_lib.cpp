@@ -1,0 +1,24 @@
+// TEST INFRASTRUCTURE: runs the production kernel source under the wave simulator.
+#include <vector>
+#include "clx_kernels.hip"
+#include "clx_plan.h"
+
+extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
+                                 int32_t* out, const uint64_t* out_offs, clx_frame_result* results, uint32_t flags,
+                                 clx_sf_desc* sfd_out /* optional, n_slots entries */, uint64_t* n_slots_out) {
+    std::vector<clx_dev_frame> dev(n ? n : 1);
+    uint64_t n_slots = 0;
+    if (clx_plan_frames(frames, n, out_offs, dev.data(), &n_slots) >= 0) return CLX_API_ERROR;
+    clx_plan_limits(frames, n, arena_len, dev.data());
+    std::vector<clx_sf_desc> sfd(n_slots ? n_slots : 1);
+    memset(sfd.data(), 0, sfd.size() * sizeof(clx_sf_desc));
+    const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
+    SIM_LAUNCH(clx_k_residual, n, 64, arena, alloc_len, dev.data(), (uint32_t)n, out, sfd.data(), results);
+    if (n_slots_out) *n_slots_out = n_slots;
+    if (sfd_out) memcpy(sfd_out, sfd.data(), n_slots * sizeof(clx_sf_desc));
+    if (flags & 0x100u) return CLX_OK;     // stop after K1 (residual inspection)
+    SIM_LAUNCH(clx_k_predict, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots);
+    if (flags & CLX_VERIFY_CRC16)
+        SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
+    return CLX_OK;
+}

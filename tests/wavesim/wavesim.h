@@ -1,0 +1,205 @@
+// wavesim.h -- a tiny wave64 SIMT simulator on ucontext fibers (TEST INFRASTRUCTURE).
+//
+// One fiber per lane.  Cross-lane operations (__shfl*, __ballot, __any) and __syncthreads() are
+// rendezvous points: a lane parks until every live lane of its wave (block) has arrived, then all
+// exchange values.  Lanes that have returned from the kernel count as inactive, like exec-masked
+// lanes.  A rendezvous reached from two different call sites at once -- i.e. a cross-lane operation
+// under divergent control flow, which the kernels promise not to do -- or a lane that never arrives
+// aborts with a diagnostic instead of silently "working".
+#ifndef WAVESIM_H
+#define WAVESIM_H
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));
+static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { uint4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }
+
+namespace wavesim {
+
+enum { kMaxThreads = 1024, kStack = 1 << 18 };
+
+struct State {
+    ucontext_t sched;
+    ucontext_t fiber[kMaxThreads];
+    char* stacks = nullptr;
+    int nthreads = 0;
+    int cur = -1;
+    bool done[kMaxThreads];
+    // rendezvous bookkeeping (per wave for cross-lane ops, per block for barriers)
+    int wave_arrived[kMaxThreads / 64];
+    unsigned wave_gen[kMaxThreads / 64];
+    const void* wave_site[kMaxThreads / 64];
+    int wave_live[kMaxThreads / 64];
+    int blk_arrived = 0; unsigned blk_gen = 0; int blk_live = 0;
+    uint64_t slot[2][kMaxThreads];      // exchange buffers, double buffered by generation parity
+    unsigned long long progress = 0, spins = 0;
+    void (*entry)(void*) = nullptr;
+    void* entry_arg = nullptr;
+};
+
+inline State& S() { static State s; return s; }
+
+struct Idx { unsigned x, y, z; };
+
+}  // namespace wavesim
+
+static wavesim::Idx threadIdx, blockIdx, blockDim, gridDim;
+
+namespace wavesim {
+
+inline void yield_() {
+    State& s = S();
+    int me = s.cur;
+    swapcontext(&s.fiber[me], &s.sched);
+}
+
+inline void die(const char* what) { fprintf(stderr, "wavesim: %s (block %u, thread %d)\n", what, blockIdx.x, S().cur); abort(); }
+
+// park until all live lanes of my wave arrived at the same site
+inline unsigned wave_rendezvous(const void* site) {
+    State& s = S();
+    const int me = s.cur, w = me / 64;
+    if (s.wave_arrived[w] == 0) s.wave_site[w] = site;
+    else if (s.wave_site[w] != site) die("cross-lane operation reached from divergent control flow");
+    const unsigned gen = s.wave_gen[w];
+    if (++s.wave_arrived[w] >= s.wave_live[w]) { s.wave_arrived[w] = 0; ++s.wave_gen[w]; ++s.progress; }
+    else while (s.wave_gen[w] == gen) yield_();
+    return gen;
+}
+
+inline void lane_exit() {
+    State& s = S();
+    const int me = s.cur, w = me / 64;
+    s.done[me] = true;
+    --s.wave_live[w]; --s.blk_live;
+    ++s.progress;
+    if (s.wave_live[w] > 0 && s.wave_arrived[w] >= s.wave_live[w]) { s.wave_arrived[w] = 0; ++s.wave_gen[w]; }
+    if (s.blk_live > 0 && s.blk_arrived >= s.blk_live) { s.blk_arrived = 0; ++s.blk_gen; }
+}
+
+inline void trampoline() {
+    State& s = S();
+    s.entry(s.entry_arg);
+    lane_exit();
+    yield_();
+    die("resumed a finished lane");
+}
+
+// run one block of `nthreads` threads; entry(arg) is the kernel body bound to its arguments
+inline void run_block(unsigned bx, unsigned grid_x, int nthreads, void (*entry)(void*), void* arg) {
+    State& s = S();
+    if (nthreads > kMaxThreads) die("block too large");
+    if (!s.stacks) s.stacks = (char*)malloc((size_t)kMaxThreads * kStack);
+    s.nthreads = nthreads; s.entry = entry; s.entry_arg = arg;
+    blockIdx = { bx, 0, 0 }; blockDim = { (unsigned)nthreads, 1, 1 }; gridDim = { grid_x, 1, 1 };
+    const int nw = (nthreads + 63) / 64;
+    for (int w = 0; w < nw; ++w) { s.wave_arrived[w] = 0; s.wave_gen[w] = 0; s.wave_live[w] = (w == nw - 1 && nthreads % 64) ? nthreads % 64 : 64; }
+    s.blk_arrived = 0; s.blk_gen = 0; s.blk_live = nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        s.done[t] = false;
+        getcontext(&s.fiber[t]);
+        s.fiber[t].uc_stack.ss_sp = s.stacks + (size_t)t * kStack;
+        s.fiber[t].uc_stack.ss_size = kStack;
+        s.fiber[t].uc_link = nullptr;
+        makecontext(&s.fiber[t], (void (*)())trampoline, 0);
+    }
+    int live = nthreads;
+    unsigned long long last_progress = s.progress; unsigned long long idle_rounds = 0;
+    while (live > 0) {
+        live = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            if (s.done[t]) continue;
+            ++live;
+            s.cur = t; threadIdx = { (unsigned)t, 0, 0 };
+            swapcontext(&s.sched, &s.fiber[t]);
+        }
+        if (s.progress == last_progress) { if (++idle_rounds > 4) { s.cur = -1; die("deadlock: lanes wait at a rendezvous that not every live lane reaches"); } }
+        else { idle_rounds = 0; last_progress = s.progress; }
+    }
+    s.cur = -1;
+}
+
+template <typename T> inline uint64_t to_bits(T v) { uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template <typename T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+
+// all-to-all exchange inside a wave: returns a pointer to the 64 published values
+template <typename T> inline const uint64_t* exchange(T v, const void* site) {
+    State& s = S();
+    const int me = s.cur, w = me / 64;
+    const unsigned par = s.wave_gen[w] & 1u;
+    s.slot[par][me] = to_bits(v);
+    // lanes that already exited publish nothing: clear their slots once per generation (by the first arriver)
+    if (s.wave_arrived[w] == 0) for (int l = 0; l < 64; ++l) if (w * 64 + l >= s.nthreads || s.done[w * 64 + l]) s.slot[par][w * 64 + l] = 0;
+    wave_rendezvous(site);
+    return &s.slot[par][w * 64];
+}
+
+}  // namespace wavesim
+
+#define WAVESIM_SITE __builtin_return_address(0)
+
+__attribute__((noinline)) static void __syncthreads() {
+    using namespace wavesim;
+    State& s = S();
+    const unsigned gen = s.blk_gen;
+    if (++s.blk_arrived >= s.blk_live) { s.blk_arrived = 0; ++s.blk_gen; ++s.progress; }
+    else while (s.blk_gen == gen) yield_();
+}
+
+template <typename T> __attribute__((noinline)) static T __shfl(T v, int src, int width = 64) {
+    (void)width;
+    const uint64_t* all = wavesim::exchange(v, WAVESIM_SITE);
+    return wavesim::from_bits<T>(all[src & 63]);
+}
+template <typename T> __attribute__((noinline)) static T __shfl_up(T v, unsigned delta, int width = 64) {
+    (void)width;
+    const int lane = wavesim::S().cur & 63;
+    const uint64_t* all = wavesim::exchange(v, WAVESIM_SITE);
+    return lane >= (int)delta ? wavesim::from_bits<T>(all[lane - (int)delta]) : v;
+}
+template <typename T> __attribute__((noinline)) static T __shfl_xor(T v, int mask, int width = 64) {
+    (void)width;
+    const int lane = wavesim::S().cur & 63;
+    const uint64_t* all = wavesim::exchange(v, WAVESIM_SITE);
+    return wavesim::from_bits<T>(all[(lane ^ mask) & 63]);
+}
+__attribute__((noinline)) static unsigned long long __ballot(int pred) {
+    const uint64_t* all = wavesim::exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (all[l]) m |= 1ull << l;
+    return m;
+}
+__attribute__((noinline)) static int __any(int pred) {
+    const uint64_t* all = wavesim::exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE);
+    for (int l = 0; l < 64; ++l) if (all[l]) return 1;
+    return 0;
+}
+
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+
+// SIM_LAUNCH(kernel, grid, block, args...)
+#define SIM_LAUNCH(kernel, grid, block, ...)                                                     \
+    do {                                                                                          \
+        auto body_ = [&]() { kernel(__VA_ARGS__); };                                              \
+        using Body_ = decltype(body_);                                                            \
+        for (unsigned bx_ = 0; bx_ < (unsigned)(grid); ++bx_)                                     \
+            wavesim::run_block(bx_, (unsigned)(grid), (int)(block), [](void* p) { (*(Body_*)p)(); }, &body_); \
+    } while (0)
+
+#endif
