@@ -44,6 +44,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctx = cx.Context(local_rank, wait_s=120)   # waits for the device to appear; raises if there is none
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -53,7 +54,6 @@ def main():
     gen_s = time.time() - t_gen
     descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
 
-    ctx = cx.Context(local_rank)
     d_arena = torch.from_numpy(w.arena).to(dev)
     d_out = torch.zeros(w.pcm.size, dtype=torch.int32, device=dev)
     batch = ctx.plan(descs, w.out_offs, verify_crc=args.verify_crc)

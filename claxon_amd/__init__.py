@@ -240,12 +240,39 @@ def descs_for_subframes(offs, block_sizes, bps):
 
 # ----------------------------------------------------------------------------- device objects
 
+def _wait_for_gpu_node(deadline):
+    """Poll (in child processes) until the kernel driver exposes a gfx950 agent or the deadline passes."""
+    import time
+    probe = "/opt/rocm/bin/rocminfo"
+    while time.time() < deadline:
+        if os.path.exists("/dev/kfd"):
+            if not os.path.exists(probe):
+                return
+            try:
+                r = subprocess.run([probe], capture_output=True, timeout=30)
+                if r.returncode == 0 and b"gfx950" in r.stdout:
+                    return
+            except Exception:
+                pass
+        time.sleep(1.0)
+
+
 class Context:
     """clx_ctx: one per GPU / stream; not thread safe."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, wait_s=0.0):
+        """`wait_s`: keep retrying for this long while the device is not (yet) visible -- a freshly
+        booted GPU box can take a few seconds to expose /dev/kfd.  It never falls back to the CPU."""
+        import time
         self._h = C.c_void_p(None)
-        st = lib().clx_create(int(device), C.byref(self._h))
+        deadline = time.time() + wait_s
+        if wait_s > 0:
+            _wait_for_gpu_node(deadline)       # probe from a child process: never poison this one's HIP runtime
+        while True:
+            st = lib().clx_create(int(device), C.byref(self._h))
+            if (st == OK and self._h) or time.time() >= deadline:
+                break
+            time.sleep(1.0)
         if st != OK or not self._h:
             self._h = None
             raise ClaxonError(API_ERROR, 0, "clx_create(%d) failed: no usable gfx950 HIP device; claxon_amd has no "

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def gpu():
-    return GpuBackend(cx.Context(0))
+    return GpuBackend(cx.Context(0, wait_s=120))
 
 
 @pytest.mark.parametrize("make", [
