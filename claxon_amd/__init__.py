@@ -107,6 +107,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ClaxonError(API_ERROR, 0, "libclaxon_hip.so is not built (run `python -c 'import __graft_entry__ as g; "
                                         "g.build()'`); claxon_amd has no CPU fallback")
+    # When PyTorch shares the process (it is the allocator / stream owner for tests and bench.py) its wheel
+    # brings its own copy of the HIP runtime under the unversioned name libamdhip64.so.  Importing torch FIRST
+    # makes our NEEDED libamdhip64.so.7 resolve to that already-loaded copy (same SONAME); the other order
+    # would put two HIP/HSA runtimes in one process and the second one finds no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
     L.clx_message.restype = C.c_char_p
