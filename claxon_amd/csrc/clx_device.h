@@ -27,7 +27,9 @@ struct clx_dev_frame {
 
 struct clx_sf_desc {
     uint64_t out_base;       // sample index of this subframe's first sample in `out`
-    uint32_t n;              // block size; 0 = empty slot / frame failed before this subframe was parsed
+    uint16_t n;              // block size; 0 = empty slot / frame failed before this subframe was parsed
+    uint8_t  lim_log2;       // 0..23: K1 proved |s| <= 2^lim_log2 makes 32-bit/24-bit-factor evaluation exact; 0xff: use i64
+    uint8_t  reserved;
     uint8_t  order;          // IIR taps (0: constant/verbatim/fixed-0; fixed 1..4; lpc 1..32)
     uint8_t  shift;          // qlp shift (0 for fixed predictors)
     uint8_t  wasted;         // wasted bits per sample: final left shift (subframe.rs:216-225)

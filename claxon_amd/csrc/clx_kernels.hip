@@ -427,13 +427,21 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
             const uint32_t slot = fr.first_slot + ch;
             clx_sf_desc* d = &sfd[slot];
             if ((uint32_t)lane < 32u) d->coef[lane] = (int16_t)((uint32_t)lane < order ? my_coef : 0);
+            // sum|c| over the taps: K2 may evaluate the recurrence in 32 bits with 24-bit factors when
+            // sum|c| * 2^(sf_bps-1) < 2^31 and sf_bps <= 24 (exact for every in-range history; K2 re-checks the range)
+            uint32_t cabs = (uint32_t)(my_coef < 0 ? -my_coef : my_coef);
+            if ((uint32_t)lane >= order || kind < 2u) cabs = 0;
+#pragma unroll
+            for (int sx = 32; sx >= 1; sx >>= 1) cabs += __shfl_xor(cabs, sx, 64);
             if (lane == 0) {
                 d->out_base = fr.out_off + (uint64_t)ch * bs;
                 d->order = (uint8_t)((kind >= 2u) ? order : 0u);
                 d->shift = (uint8_t)qshift;
                 d->wasted = (uint8_t)wasted;
                 d->decor = (uint8_t)ca;
-                d->n = bs;
+                d->lim_log2 = (uint8_t)((sf_bps <= 24u && ((uint64_t)cabs << (sf_bps - 1u)) < (1ull << 31)) ? (sf_bps - 1u) : 0xffu);
+                d->reserved = 0;
+                d->n = (uint16_t)bs;
             }
         }
     }
@@ -448,123 +456,183 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 
 // ------------------------------------------------------------------------------------------------
 // K2: predictor synthesis + wasted-bits shift + stereo decorrelation.  One lane per subframe
-// ("predictor slot"); 64 slots per wave; T = 32 samples per tile.  A tile is read from HBM
-// coalesced (two 128-byte row segments per load instruction), transposed through LDS so that each
-// lane walks its own channel, and written back through the same transposition with the
-// left/side, right/side or mid/side reconstruction applied on the way out.
+// ("predictor slot"), 64 slots per wave, everything in registers: each lane streams its own channel
+// with 16-byte loads / stores, BLK = 16 samples at a time (one 64-byte segment per row per block, so
+// every HBM sector that is touched is fully used), the next block in flight while the current one is
+// computed.  The recurrence
+//     s[i] = x[i] + ((sum_j c[j]*s[i-1-j]) >> shift)          subframe.rs:559-566, 575-582, 606-613
+// needs an i64 accumulator in general.  When K1 proved  sum|c| * 2^(sf_bps-1) < 2^31  and
+// sf_bps <= 24  (clx_sf_desc::lim_log2), the sum of a VALID stream fits i32 and every factor fits
+// 24 bits, so the block is first run with v_mad_i32_i24 (full rate) and its outputs are range-checked;
+// a block in which any lane leaves the proven range (corrupt streams only) is re-run with
+// v_mad_i64_i32, which is exact for any input -- garbage in, the reference's garbage out.
+// The stereo partner sits in lane^1 (host aligns decorrelated pairs to even slots) and is fetched
+// with a DPP quad permute; decorrelation (frame.rs:319-389) happens on the finished block, off the
+// recurrence's critical path.
 // ------------------------------------------------------------------------------------------------
-#define CLX_T 32
+#define CLX_BLK 16
 
-struct K2Lds {
-    int32_t  tile[64][CLX_T + 1];
-    uint64_t rowbase[64];
-    uint32_t rown[64];
-    uint32_t rowdecor[64];
-};
-
-template <int OMAX>
-__device__ __forceinline__ void clx_predict_loop(K2Lds& L, int32_t* __restrict__ out, const clx_sf_desc* __restrict__ mydesc,
-                                                 uint32_t n, uint32_t order, uint32_t shift, uint32_t wasted,
-                                                 uint32_t nmax, int lane) {
-    int32_t c[OMAX];
-    int32_t hist[OMAX];
+template <int OMAX, bool WIDE>
+__device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32_t (&y)[CLX_BLK], int32_t (&hist)[OMAX],
+                                              const int32_t (&c)[OMAX], uint32_t t0, uint32_t order, uint32_t shift) {
 #pragma unroll
-    for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)mydesc->coef[j] : 0; hist[j] = 0; }
-
-    const int half = lane >> 5, col = lane & 31;
-    int32_t pre[CLX_T];
-    // prefetch tile 0
-#pragma unroll
-    for (int it = 0; it < CLX_T; ++it) {
-        const int row = it * 2 + half;
-        const uint32_t idx = (uint32_t)col;
-        pre[it] = (idx < L.rown[row]) ? out[L.rowbase[row] + idx] : 0;
-    }
-    for (uint32_t t0 = 0; t0 < nmax; t0 += CLX_T) {
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < CLX_T; ++it) L.tile[it * 2 + half][col] = pre[it];
-        __syncthreads();
-        // prefetch the next tile while this one is being computed
-        if (t0 + CLX_T < nmax) {
-#pragma unroll
-            for (int it = 0; it < CLX_T; ++it) {
-                const int row = it * 2 + half;
-                const uint32_t idx = t0 + CLX_T + (uint32_t)col;
-                pre[it] = (idx < L.rown[row]) ? out[L.rowbase[row] + idx] : 0;
-            }
-        }
-        // the recurrence: s[i] = x[i] + ((sum_j c[j]*s[i-1-j]) >> shift), subframe.rs:559-566, 575-582, 606-613
-#pragma unroll
-        for (int i = 0; i < CLX_T; ++i) {
-            const int32_t x = L.tile[lane][i];
+    for (int i = 0; i < CLX_BLK; ++i) {
+        int32_t pred;
+        if (WIDE) {
             int64_t acc = 0;
 #pragma unroll
-            for (int j = 0; j < OMAX; ++j) acc += (int64_t)c[j] * (int64_t)hist[j];
-            const int32_t pred = (int32_t)(acc >> shift);
-            const int32_t s = (t0 + (uint32_t)i >= order) ? (int32_t)((uint32_t)x + (uint32_t)pred) : x;
+            for (int j = OMAX - 1; j >= 0; --j) acc += (int64_t)c[j] * (int64_t)hist[j];   // newest tap last: shortest dependent chain
+            pred = (int32_t)(acc >> shift);
+        } else {
+            int32_t acc = 0;
 #pragma unroll
-            for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
-            hist[0] = s;
-            L.tile[lane][i] = (int32_t)((uint32_t)s << wasted);                 // wrapping_shl, subframe.rs:223
+            for (int j = OMAX - 1; j >= 0; --j) acc = __mul24(c[j], hist[j]) + acc;        // v_mad_i32_i24
+            pred = acc >> shift;
         }
-        __syncthreads();
-        // write back, decorrelating stereo pairs (rows 2r, 2r+1) on the way out
+        const int32_t s = (t0 + (uint32_t)i >= order) ? (int32_t)((uint32_t)x[i] + (uint32_t)pred) : x[i];
 #pragma unroll
-        for (int it = 0; it < CLX_T; ++it) {
-            const int row = it * 2 + half;
-            const uint32_t idx = t0 + (uint32_t)col;
-            const uint32_t rn = L.rown[row];
-            if (idx < rn) {
-                int32_t v = L.tile[row][col];
-                const uint32_t d = L.rowdecor[row];
-                if (d != CLX_CH_INDEPENDENT && L.rown[row ^ 1] == rn) {
-                    const int32_t a = L.tile[row & ~1][col];                   // channel 0 as coded
-                    const int32_t bb = L.tile[row | 1][col];                   // channel 1 as coded
-                    if (d == CLX_CH_LEFT_SIDE) {                               // frame.rs:319-334
-                        if (row & 1) v = (int32_t)((uint32_t)a - (uint32_t)bb);
-                    } else if (d == CLX_CH_RIGHT_SIDE) {                       // frame.rs:345-360
-                        if (!(row & 1)) v = (int32_t)((uint32_t)a + (uint32_t)bb);
-                    } else {                                                   // frame.rs:371-389
-                        const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
-                        // m +- side is even, so Rust's truncating `/ 2` equals an arithmetic shift
-                        v = (row & 1) ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1)
-                                      : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
-                    }
-                }
-                out[L.rowbase[row] + idx] = v;
+        for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
+        hist[0] = s;
+        y[i] = s;
+    }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void clx_row_load(const int32_t* __restrict__ row, uint32_t t, uint32_t n, int32_t (&v)[CLX_BLK]) {
+    if (ALIGNED) {
+#pragma unroll
+        for (int q = 0; q < CLX_BLK / 4; ++q) {
+            int4 w = make_int4(0, 0, 0, 0);
+            if (t + 4u * q < n) w = *reinterpret_cast<const int4*>(row + t + 4 * q);
+            v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CLX_BLK; ++i) v[i] = (t + (uint32_t)i < n) ? row[t + i] : 0;
+    }
+}
+template <bool ALIGNED>
+__device__ __forceinline__ void clx_row_store(int32_t* __restrict__ row, uint32_t t, uint32_t n, const int32_t (&v)[CLX_BLK]) {
+    if (ALIGNED) {
+#pragma unroll
+        for (int q = 0; q < CLX_BLK / 4; ++q)
+            if (t + 4u * q < n) *reinterpret_cast<int4*>(row + t + 4 * q) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < CLX_BLK; ++i) if (t + (uint32_t)i < n) row[t + i] = v[i];
+    }
+}
+
+template <int OMAX, bool ALIGNED>
+__device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ mydesc,
+                                                 uint32_t n, uint32_t order, uint32_t shift, uint32_t wasted,
+                                                 uint32_t decor, bool pair_ok, uint32_t lim_log2, uint32_t nmax, int lane) {
+    int32_t c[OMAX], hist[OMAX];
+#pragma unroll
+    for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)mydesc->coef[j] : 0; hist[j] = 0; }
+    int32_t* const row = out + mydesc->out_base;
+    const bool odd = (lane & 1) != 0;
+    const bool any_decor = __any(decor != CLX_CH_INDEPENDENT && pair_ok);
+    // |s| <= lim proves the i32/i24 evaluation exact; lanes K1 could not prove (lim_log2 = 0xff) force the wide path
+    // (range is [-lim, lim-1]: the 24-bit signed factor range when lim = 2^23)
+    const int32_t lim = (lim_log2 <= 23u) ? (int32_t)(1u << lim_log2) : -1;
+    const bool trivial = (n == 0u) || (order == 0u);          // nothing is predicted: any evaluation is exact
+    bool h_ok = (lim >= 0) || trivial;
+
+    int32_t cur[CLX_BLK], nxt[CLX_BLK], y[CLX_BLK];
+    clx_row_load<ALIGNED>(row, 0u, n, cur);
+    for (uint32_t t0 = 0; t0 < nmax; t0 += CLX_BLK) {
+        if (t0 + CLX_BLK < nmax) clx_row_load<ALIGNED>(row, t0 + CLX_BLK, n, nxt);
+        bool done = false;
+        if (__all(h_ok)) {
+            int32_t h0[OMAX];
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) h0[j] = hist[j];
+            clx_iir_block<OMAX, false>(cur, y, hist, c, t0, order, shift);
+            int32_t mx = y[0], mn = y[0];
+#pragma unroll
+            for (int i = 1; i < CLX_BLK; ++i) { mx = y[i] > mx ? y[i] : mx; mn = y[i] < mn ? y[i] : mn; }
+            const bool in_range = trivial || t0 >= n || (mx < lim && mn >= -lim);
+            if (__all(in_range)) done = true;
+            else {
+#pragma unroll
+                for (int j = 0; j < OMAX; ++j) hist[j] = h0[j];
             }
         }
+        if (!done) {
+            clx_iir_block<OMAX, true>(cur, y, hist, c, t0, order, shift);
+            bool ok = lim >= 0;
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) ok = ok && hist[j] < lim && hist[j] >= -lim;
+            h_ok = ok || trivial || t0 + CLX_BLK >= n;
+        }
+        // wasted-bits shift (subframe.rs:216-225) and stereo decorrelation (frame.rs:319-389) on the finished block
+#pragma unroll
+        for (int i = 0; i < CLX_BLK; ++i) y[i] = (int32_t)((uint32_t)y[i] << wasted);
+        if (any_decor) {
+#pragma unroll
+            for (int i = 0; i < CLX_BLK; ++i) {
+                const int32_t mine = y[i];
+                const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+                const int32_t a = odd ? other : mine;                       // channel 0 as coded
+                const int32_t bb = odd ? mine : other;                      // channel 1 as coded
+                int32_t v = mine;
+                if (pair_ok) {
+                    if (decor == CLX_CH_LEFT_SIDE) { if (odd) v = (int32_t)((uint32_t)a - (uint32_t)bb); }
+                    else if (decor == CLX_CH_RIGHT_SIDE) { if (!odd) v = (int32_t)((uint32_t)a + (uint32_t)bb); }
+                    else if (decor == CLX_CH_MID_SIDE) {
+                        const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
+                        // m +- side is even, so Rust's truncating `/ 2` equals an arithmetic shift
+                        v = odd ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1) : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
+                    }
+                }
+                y[i] = v;
+            }
+        }
+        clx_row_store<ALIGNED>(row, t0, n, y);
+#pragma unroll
+        for (int i = 0; i < CLX_BLK; ++i) cur[i] = nxt[i];
     }
 }
 
 extern "C" __global__ __launch_bounds__(64)
 void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots) {
-    __shared__ K2Lds L;
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
-    uint32_t n = 0, order = 0, shift = 0, wasted = 0, decor = 0;
+    uint32_t n = 0, order = 0, shift = 0, wasted = 0, decor = 0, lim_log2 = 0;
     uint64_t base = 0;
     const clx_sf_desc* d = &sfd[slot < n_slots ? slot : 0];
     if (slot < n_slots) {
         n = d->n; order = d->order; shift = d->shift; wasted = d->wasted; decor = d->decor; base = d->out_base;
+        lim_log2 = d->lim_log2;
     }
-    if (n == 0u) { order = 0; shift = 0; wasted = 0; decor = 0; }
-    L.rowbase[lane] = base; L.rown[lane] = n; L.rowdecor[lane] = decor;
+    if (n == 0u) { order = 0; shift = 0; wasted = 0; decor = 0; lim_log2 = 0; }
+    // a decorrelated pair is only formed when both of its subframes decoded (same block size, same mode)
+    const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0xB1, 0xF, 0xF, false);
+    const uint32_t pd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)decor, 0xB1, 0xF, 0xF, false);
+    const bool pair_ok = (decor != CLX_CH_INDEPENDENT) && pn == n && pd == decor && n != 0u;
     uint32_t nmax = n, omax = order;
-    bool work = (order != 0u) || (wasted != 0u) || (decor != 0u);
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
         uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
     }
-    __syncthreads();
+    const bool work = (order != 0u) || (wasted != 0u) || pair_ok;
     // a wave of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits is already final
     if (nmax == 0u || !__any(work)) return;
-    if (omax <= 4u)       clx_predict_loop<4>(L, out, d, n, order, shift, wasted, nmax, lane);
-    else if (omax <= 8u)  clx_predict_loop<8>(L, out, d, n, order, shift, wasted, nmax, lane);
-    else if (omax <= 12u) clx_predict_loop<12>(L, out, d, n, order, shift, wasted, nmax, lane);
-    else                  clx_predict_loop<32>(L, out, d, n, order, shift, wasted, nmax, lane);
+    // 16-byte row accesses need 16-byte aligned rows whose length is a multiple of 4 samples
+    const bool al = (n == 0u) || ((((uintptr_t)(out + base)) & 15u) == 0u && (n & 3u) == 0u);
+    if (__all(al)) {
+        if (omax <= 4u)       clx_predict_rows<4, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+    } else {
+        if (omax <= 4u)       clx_predict_rows<4, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

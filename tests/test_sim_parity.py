@@ -49,7 +49,11 @@ def test_sim_detects_divergent_collectives():
     src = textwrap.dedent("""
         #include <hip/hip_runtime.h>
         __global__ void bad(int* out) { int lane = threadIdx.x; int v = lane;
-          if (lane & 1) v = __shfl(v, 0, 64); else v = __shfl(v, 1, 64); out[lane] = v; }
+          if (lane & 1)
+            v = __shfl(v, 0, 64);
+          else
+            v = __shfl(v, 1, 64);
+          out[lane] = v; }
         int main() { static int out[64]; SIM_LAUNCH(bad, 1, 64, out); return 0; }
     """)
     with tempfile.TemporaryDirectory() as d:

@@ -148,7 +148,9 @@ template <typename T> inline const uint64_t* exchange(T v, const void* site) {
 
 }  // namespace wavesim
 
-#define WAVESIM_SITE __builtin_return_address(0)
+// A rendezvous "site" is the source line of the call (not a machine address: the host compiler is free to
+// duplicate code, which must not look like divergence).  Two lanes meeting from different lines = divergence.
+#define WAVESIM_SITE(line) ((const void*)(uintptr_t)(line))
 
 __attribute__((noinline)) static void __syncthreads() {
     using namespace wavesim;
@@ -158,34 +160,64 @@ __attribute__((noinline)) static void __syncthreads() {
     else while (s.blk_gen == gen) yield_();
 }
 
-template <typename T> __attribute__((noinline)) static T __shfl(T v, int src, int width = 64) {
+namespace wavesim {
+template <typename T> static T shfl_(int line, T v, int src, int width = 64) {
     (void)width;
-    const uint64_t* all = wavesim::exchange(v, WAVESIM_SITE);
-    return wavesim::from_bits<T>(all[src & 63]);
+    const uint64_t* all = exchange(v, WAVESIM_SITE(line));
+    return from_bits<T>(all[src & 63]);
 }
-template <typename T> __attribute__((noinline)) static T __shfl_up(T v, unsigned delta, int width = 64) {
+template <typename T> static T shfl_up_(int line, T v, unsigned delta, int width = 64) {
     (void)width;
-    const int lane = wavesim::S().cur & 63;
-    const uint64_t* all = wavesim::exchange(v, WAVESIM_SITE);
-    return lane >= (int)delta ? wavesim::from_bits<T>(all[lane - (int)delta]) : v;
+    const int lane = S().cur & 63;
+    const uint64_t* all = exchange(v, WAVESIM_SITE(line));
+    return lane >= (int)delta ? from_bits<T>(all[lane - (int)delta]) : v;
 }
-template <typename T> __attribute__((noinline)) static T __shfl_xor(T v, int mask, int width = 64) {
+template <typename T> static T shfl_xor_(int line, T v, int mask, int width = 64) {
     (void)width;
-    const int lane = wavesim::S().cur & 63;
-    const uint64_t* all = wavesim::exchange(v, WAVESIM_SITE);
-    return wavesim::from_bits<T>(all[(lane ^ mask) & 63]);
+    const int lane = S().cur & 63;
+    const uint64_t* all = exchange(v, WAVESIM_SITE(line));
+    return from_bits<T>(all[(lane ^ mask) & 63]);
 }
-__attribute__((noinline)) static unsigned long long __ballot(int pred) {
-    const uint64_t* all = wavesim::exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE);
+static unsigned long long ballot_(int line, int pred) {
+    const uint64_t* all = exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE(line));
     unsigned long long m = 0;
     for (int l = 0; l < 64; ++l) if (all[l]) m |= 1ull << l;
     return m;
 }
-__attribute__((noinline)) static int __any(int pred) {
-    const uint64_t* all = wavesim::exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE);
+static int any_(int line, int pred) {
+    const uint64_t* all = exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE(line));
     for (int l = 0; l < 64; ++l) if (all[l]) return 1;
     return 0;
 }
+static int all_(int line, int pred) {
+    // inactive (exited) lanes do not veto
+    const uint64_t* all = exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE(line));
+    State& s = S();
+    const int w = s.cur / 64;
+    for (int l = 0; l < 64; ++l) { const int t = w * 64 + l; if (t < s.nthreads && !s.done[t] && !all[l]) return 0; }
+    return 1;
+}
+// DPP quad_perm (dpp_ctrl 0x00-0xFF), full row/bank masks: lane l reads lane (l & ~3) | perm[l & 3]
+static int update_dpp_(int line, int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    if (dpp_ctrl < 0 || dpp_ctrl > 0xff) die("only quad_perm DPP controls are simulated");
+    const int lane = S().cur & 63;
+    const uint64_t* all = exchange(src, WAVESIM_SITE(line));
+    return from_bits<int>(all[(lane & ~3) | ((dpp_ctrl >> (2 * (lane & 3))) & 3)]);
+}
+}  // namespace wavesim
+
+#define __shfl(...) wavesim::shfl_(__LINE__, __VA_ARGS__)
+#define __shfl_up(...) wavesim::shfl_up_(__LINE__, __VA_ARGS__)
+#define __shfl_xor(...) wavesim::shfl_xor_(__LINE__, __VA_ARGS__)
+#define __ballot(...) wavesim::ballot_(__LINE__, __VA_ARGS__)
+#define __any(...) wavesim::any_(__LINE__, __VA_ARGS__)
+#define __all(...) wavesim::all_(__LINE__, __VA_ARGS__)
+#define __builtin_amdgcn_update_dpp(...) wavesim::update_dpp_(__LINE__, __VA_ARGS__)
+
+static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
+struct int4 { int x, y, z, w; } __attribute__((aligned(16)));
+static inline int4 make_int4(int a, int b, int c, int d) { int4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }
 
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
