@@ -489,7 +489,9 @@ __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32
             for (int j = OMAX - 1; j >= 0; --j) acc = __mul24(c[j], hist[j]) + acc;        // v_mad_i32_i24
             pred = acc >> shift;
         }
-        const int32_t s = (t0 + (uint32_t)i >= order) ? (int32_t)((uint32_t)x[i] + (uint32_t)pred) : x[i];
+        // warm-up samples (i < order) pass through; branch-free so the block stays one straight line of code
+        const uint32_t use = (t0 + (uint32_t)i >= order) ? 0xffffffffu : 0u;
+        const int32_t s = (int32_t)((uint32_t)x[i] + ((uint32_t)pred & use));
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
         hist[0] = s;
@@ -499,16 +501,20 @@ __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32
 
 template <bool ALIGNED>
 __device__ __forceinline__ void clx_row_load(const int32_t* __restrict__ row, uint32_t t, uint32_t n, int32_t (&v)[CLX_BLK]) {
+    // Unconditional loads from clamped indices (no control flow => the compiler can count them and keep the
+    // prefetch in flight); samples past the row's end are never stored, so what they hold does not matter.
     if (ALIGNED) {
+        const uint32_t last = n >= 4u ? n - 4u : 0u;
 #pragma unroll
         for (int q = 0; q < CLX_BLK / 4; ++q) {
-            int4 w = make_int4(0, 0, 0, 0);
-            if (t + 4u * q < n) w = *reinterpret_cast<const int4*>(row + t + 4 * q);
+            const uint32_t idx = t + 4u * q < last ? t + 4u * q : last;
+            const int4 w = *reinterpret_cast<const int4*>(row + idx);
             v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
         }
     } else {
+        const uint32_t last = n >= 1u ? n - 1u : 0u;
 #pragma unroll
-        for (int i = 0; i < CLX_BLK; ++i) v[i] = (t + (uint32_t)i < n) ? row[t + i] : 0;
+        for (int i = 0; i < CLX_BLK; ++i) { const uint32_t idx = t + (uint32_t)i < last ? t + (uint32_t)i : last; v[i] = row[idx]; }
     }
 }
 template <bool ALIGNED>
@@ -530,7 +536,7 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, cons
     int32_t c[OMAX], hist[OMAX];
 #pragma unroll
     for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)mydesc->coef[j] : 0; hist[j] = 0; }
-    int32_t* const row = out + mydesc->out_base;
+    int32_t* const row = out + (n != 0u ? mydesc->out_base : 0ull);       // empty slots read (never write) out[0..3]
     const bool odd = (lane & 1) != 0;
     const bool any_decor = __any(decor != CLX_CH_INDEPENDENT && pair_ok);
     // |s| <= lim proves the i32/i24 evaluation exact; lanes K1 could not prove (lim_log2 = 0xff) force the wide path
