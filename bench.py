@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-crc", action="store_true", help="also run the CRC-16 kernel inside the step")
+    ap.add_argument("--path", choices=["auto", "waves", "lanes"], default="auto", help="kernel path (default: library's choice)")
     args = ap.parse_args()
 
     import torch
@@ -56,7 +57,8 @@ def main():
 
     d_arena = torch.from_numpy(w.arena).to(dev)
     d_out = torch.zeros(w.pcm.size, dtype=torch.int32, device=dev)
-    batch = ctx.plan(descs, w.out_offs, verify_crc=args.verify_crc)
+    path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES}[args.path]
+    batch = ctx.plan(descs, w.out_offs, verify_crc=args.verify_crc, path=path)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
@@ -92,24 +94,24 @@ def main():
 
     # ---- per-kernel durations (HIP events recorded by the library on the launch stream)
     batch.set_profiling(True)
-    k_ms = [[], [], []]
-    for _ in range(max(5, min(args.steps, 20))):
+    acc = {}
+    reps = max(5, min(args.steps, 20))
+    for _ in range(reps):
         step()
         torch.cuda.synchronize()
-        for k in range(3 if args.verify_crc else 2):
-            k_ms[k].append(batch.kernel_ms(k))
+        for name, ms in batch.kernel_times().items():
+            acc.setdefault(name, []).append(ms)
     batch.set_profiling(False)
-    k1 = float(np.mean(k_ms[0])); k2 = float(np.mean(k_ms[1]))
-    names = ["clx_k_residual", "clx_k_predict"]
-    dom = 0 if k1 >= k2 else 1
-    dom_ms = max(k1, k2)
+    kernel_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+    dom_name = max(kernel_ms, key=kernel_ms.get)
+    dom_ms = kernel_ms[dom_name]
     alg_bytes = w.algorithmic_bytes          # compressed bytes read once + 4 B per decoded sample written once
     peak = 8000.0                            # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = _pmc_traffic(names[dom])
-    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+    traffic = _pmc_traffic(dom_name)
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "kernel_ms": {names[0]: round(k1, 4), names[1]: round(k2, 4)},
+                "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "step_achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / peak, 4)}
@@ -124,7 +126,7 @@ def main():
                    "frames_per_gpu": args.frames, "samples_per_step": samples_per_step_all,
                    "compressed_bytes_per_gpu": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
                    "parallelism": "frames sharded across %d GPU(s), no collective" % world,
-                   "bit_exact": True, "crc16_in_step": bool(args.verify_crc), "gen_seconds": round(gen_s, 1)},
+                   "bit_exact": True, "crc16_in_step": bool(args.verify_crc), "kernel_path": args.path, "gen_seconds": round(gen_s, 1)},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

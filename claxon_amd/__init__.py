@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libclaxon_hip.so")
 
 OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
 CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)
-ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16 = 1, 2, 4
+ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16, PATH_WAVES, PATH_LANES = 1, 2, 4, 8, 16
 
 
 class ClaxonError(RuntimeError):
@@ -74,7 +74,7 @@ EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
     "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes",
     "clx_batch_create", "clx_batch_run", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
-    "clx_batch_kernel_ms", "clx_batch_destroy", "clx_read_stream_header", "clx_reader_open", "clx_reader_new",
+    "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_reader_open", "clx_reader_new",
     "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames",
 ]
 
@@ -140,6 +140,8 @@ def lib():
     L.clx_batch_slots.argtypes = [vp]
     L.clx_batch_set_profiling.argtypes = [vp, C.c_int]
     L.clx_batch_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.clx_batch_kernel_name.restype = C.c_char_p
+    L.clx_batch_kernel_name.argtypes = [vp, C.c_int]
     L.clx_batch_destroy.argtypes = [vp]
     L.clx_batch_destroy.restype = None
     L.clx_read_stream_header.argtypes = [vp, sz, C.POINTER(StreamInfo), C.POINTER(sz), u32p]
@@ -305,7 +307,7 @@ class Context:
         if st != OK:
             raise ClaxonError(st, 0, self.last_error())
 
-    def decode_frames(self, arena, descs, out_offs, out=None, verify_crc=False):
+    def decode_frames(self, arena, descs, out_offs, out=None, verify_crc=False, path=0):
         """One-shot host->device->host decode.  Returns (out int32, results np FRAME_RESULT_DTYPE)."""
         a = _u8(arena)
         descs = np.ascontiguousarray(descs, dtype=FRAME_DESC_DTYPE)
@@ -317,7 +319,7 @@ class Context:
         assert out.dtype == np.int32 and out.size >= total
         res = np.zeros(n, dtype=FRAME_RESULT_DTYPE)
         st = lib().clx_decode_frames(self._h, _np_ptr(a), a.size, _np_ptr(descs), n, _np_ptr(out), _np_ptr(out_offs),
-                                     _np_ptr(res), VERIFY_CRC16 if verify_crc else 0)
+                                     _np_ptr(res), (VERIFY_CRC16 if verify_crc else 0) | path)
         self._check(st)
         return out, res
 
@@ -337,21 +339,22 @@ class Context:
         self._check(st)
         return out, res
 
-    def plan(self, descs, out_offs, verify_crc=False):
-        return Batch(self, descs, out_offs, verify_crc)
+    def plan(self, descs, out_offs, verify_crc=False, path=0):
+        """path: 0 = automatic, PATH_WAVES or PATH_LANES to force a kernel path."""
+        return Batch(self, descs, out_offs, verify_crc, path)
 
 
 class Batch:
     """clx_batch: a planned batch, run on device-resident buffers (what bench.py times)."""
 
-    def __init__(self, ctx, descs, out_offs, verify_crc=False):
+    def __init__(self, ctx, descs, out_offs, verify_crc=False, path=0):
         self.ctx = ctx
         descs = np.ascontiguousarray(descs, dtype=FRAME_DESC_DTYPE)
         out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
         self.n = descs.size
         self._h = C.c_void_p(None)
         st = lib().clx_batch_create(ctx._h, _np_ptr(descs), self.n, _np_ptr(out_offs),
-                                    VERIFY_CRC16 if verify_crc else 0, C.byref(self._h))
+                                    (VERIFY_CRC16 if verify_crc else 0) | path, C.byref(self._h))
         ctx._check(st)
 
     @property
@@ -376,6 +379,16 @@ class Batch:
         ms = C.c_float(0)
         self.ctx._check(lib().clx_batch_kernel_ms(self._h, kernel, C.byref(ms)))
         return float(ms.value)
+
+    def kernel_times(self):
+        """{kernel name: ms} of the last profiled run, in launch order."""
+        out, k = {}, 0
+        while True:
+            name = lib().clx_batch_kernel_name(self._h, k)
+            if not name:
+                return out
+            out[name.decode()] = self.kernel_ms(k)
+            k += 1
 
     def close(self):
         if self._h:

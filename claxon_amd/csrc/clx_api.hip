@@ -6,6 +6,7 @@
 // launches the HIP kernels for everything between header and footer.  There is no CPU decode path
 // in this library: without a usable HIP device every decode entry point fails with CLX_API_ERROR.
 #include "clx_kernels.hip"
+#include "clx_lanes.hip"
 
 #include <algorithm>
 #include <cstdio>
@@ -216,8 +217,19 @@ struct clx_batch {
     clx_dev_frame* d_frames = nullptr;
     clx_sf_desc* d_sfd = nullptr;
     clx_frame_result* d_results = nullptr;
+    // lane path
+    bool lanes = false;
+    uint32_t* d_slot_frame = nullptr;
+    uint32_t* d_multi = nullptr;
+    size_t n_multi = 0;
+    uint32_t* d_sf_start = nullptr;
+    uint32_t* d_errkey = nullptr;
+    uint64_t* d_endbits = nullptr;
     bool profiling = false;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    enum { kMaxKernels = 6 };
+    hipEvent_t ev[kMaxKernels + 1] = {};
+    const char* kname[kMaxKernels] = {};
+    int n_kernels = 0;
     bool ev_valid = false;
     hipStream_t last_stream = nullptr;
     size_t planned_arena_len = 0;
@@ -265,6 +277,11 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_frames) (void)hipFree(b->d_frames);
     if (b->d_sfd) (void)hipFree(b->d_sfd);
     if (b->d_results) (void)hipFree(b->d_results);
+    if (b->d_slot_frame) (void)hipFree(b->d_slot_frame);
+    if (b->d_multi) (void)hipFree(b->d_multi);
+    if (b->d_sf_start) (void)hipFree(b->d_sf_start);
+    if (b->d_errkey) (void)hipFree(b->d_errkey);
+    if (b->d_endbits) (void)hipFree(b->d_endbits);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
@@ -295,6 +312,22 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
         clx_batch_destroy(b); return CLX_API_ERROR;
     }
     for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
+    // path: explicit flag, else by batch shape -- the lane-serial kernels need many independent subframes to fill
+    // the machine (one lane each); below that the wave-per-frame kernels have the lower latency
+    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 2048);
+    if (b->lanes) {
+        std::vector<uint32_t> slot_frame(ns), multi(nf);
+        b->n_multi = clx_plan_lanes(b->h_frames.data(), n, slot, slot_frame.data(), multi.data());
+        if (!hip_ok(ctx, hipMalloc((void**)&b->d_slot_frame, ns * sizeof(uint32_t)), "hipMalloc slot_frame") ||
+            !hip_ok(ctx, hipMalloc((void**)&b->d_multi, nf * sizeof(uint32_t)), "hipMalloc multi") ||
+            !hip_ok(ctx, hipMalloc((void**)&b->d_sf_start, ns * sizeof(uint32_t)), "hipMalloc sf_start") ||
+            !hip_ok(ctx, hipMalloc((void**)&b->d_errkey, nf * sizeof(uint32_t)), "hipMalloc errkey") ||
+            !hip_ok(ctx, hipMalloc((void**)&b->d_endbits, nf * sizeof(uint64_t)), "hipMalloc endbits") ||
+            !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
+            !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) {
+            clx_batch_destroy(b); return CLX_API_ERROR;
+        }
+    }
     b->planned_arena_len = (size_t)-1;
     *out = b;
     return CLX_OK;
@@ -329,20 +362,44 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     }
     const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
 
-    HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
-    if (b->profiling) HIP_TRY(ctx, hipEventRecord(b->ev[0], stream));
-    hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), 0, stream,
-                       d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
-    if (b->profiling) HIP_TRY(ctx, hipEventRecord(b->ev[1], stream));
-    const unsigned k2_blocks = (unsigned)((b->n_slots + 63) / 64);
-    if (k2_blocks)
-        hipLaunchKernelGGL(clx_k_predict, dim3(k2_blocks), dim3(64), 0, stream, d_out, (const clx_sf_desc*)b->d_sfd,
-                           (uint32_t)b->n_slots);
-    if (b->profiling) HIP_TRY(ctx, hipEventRecord(b->ev[2], stream));
-    if (b->flags & CLX_VERIFY_CRC16)
+    int nk = 0;
+    auto mark = [&](const char* name) -> bool {          // event before each kernel (+ one after the last)
+        if (!b->profiling) return true;
+        if (name) b->kname[nk] = name;
+        return hip_ok(ctx, hipEventRecord(b->ev[nk++], stream), "hipEventRecord");
+    };
+    if (b->lanes) {
+        if ((uint64_t)arena_len + 32ull >= (1ull << 32)) { ctx->last_error = "CLX_PATH_LANES needs arena_len < 4 GiB"; return CLX_API_ERROR; }
+        HIP_TRY(ctx, hipMemsetAsync(b->d_errkey, 0xff, b->n * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, hipMemsetAsync(b->d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream));
+        if (b->n_multi) {
+            if (!mark("clx_k_scan")) return CLX_API_ERROR;
+            hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64)), dim3(64), 0, stream, d_arena,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi,
+                               b->d_sf_start, b->d_errkey);
+        }
+        if (!mark("clx_k_lanes")) return CLX_API_ERROR;
+        hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                           (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits);
+        if (!mark("clx_k_finalize")) return CLX_API_ERROR;
+        hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
+                           (const uint32_t*)b->d_errkey, (const uint64_t*)b->d_endbits, (uint32_t)b->n, b->d_results);
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
+        if (!mark("clx_k_residual")) return CLX_API_ERROR;
+        hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), 0, stream,
+                           d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
+        if (!mark("clx_k_predict")) return CLX_API_ERROR;
+        hipLaunchKernelGGL(clx_k_predict, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_out,
+                           (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots);
+    }
+    if (b->flags & CLX_VERIFY_CRC16) {
+        if (!mark("clx_k_crc16")) return CLX_API_ERROR;
         hipLaunchKernelGGL(clx_k_crc16, dim3((unsigned)b->n), dim3(64), 0, stream, d_arena,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, b->d_results);
-    if (b->profiling) { HIP_TRY(ctx, hipEventRecord(b->ev[3], stream)); b->ev_valid = true; }
+    }
+    if (b->profiling) { if (!mark(nullptr)) return CLX_API_ERROR; b->n_kernels = nk - 1; b->ev_valid = true; }
     HIP_TRY(ctx, hipGetLastError());
     return CLX_OK;
 }
@@ -359,11 +416,16 @@ extern "C" int clx_batch_results(clx_batch* b, clx_frame_result* results) {
 }
 
 extern "C" int clx_batch_kernel_ms(clx_batch* b, int kernel, float* ms) {
-    if (!b || !ms || kernel < 0 || kernel > 2 || !b->ev_valid) return CLX_API_ERROR;
+    if (!b || !ms || kernel < 0 || !b->ev_valid || kernel >= b->n_kernels) return CLX_API_ERROR;
     clx_ctx* ctx = b->ctx;
-    HIP_TRY(ctx, hipEventSynchronize(b->ev[3]));
+    HIP_TRY(ctx, hipEventSynchronize(b->ev[b->n_kernels]));
     HIP_TRY(ctx, hipEventElapsedTime(ms, b->ev[kernel], b->ev[kernel + 1]));
     return CLX_OK;
+}
+
+extern "C" const char* clx_batch_kernel_name(const clx_batch* b, int kernel) {
+    if (!b || !b->ev_valid || kernel < 0 || kernel >= b->n_kernels) return nullptr;
+    return b->kname[kernel];
 }
 
 extern "C" int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,

@@ -50,4 +50,16 @@ static inline void clx_plan_limits(const clx_frame_desc* frames, size_t n, size_
     }
 }
 
+// Lane path: slot -> frame map (0xffffffff for alignment padding) and the list of multi-channel frames.
+// slot_frame must hold n_slots entries, multi up to n; returns the number of multi-channel frames.
+static inline size_t clx_plan_lanes(const clx_dev_frame* dev, size_t n, uint64_t n_slots, uint32_t* slot_frame, uint32_t* multi) {
+    for (uint64_t s = 0; s < n_slots; ++s) slot_frame[s] = 0xffffffffu;
+    size_t n_multi = 0;
+    for (size_t i = 0; i < n; ++i) {
+        for (uint32_t c = 0; c < dev[i].n_channels; ++c) slot_frame[dev[i].first_slot + c] = (uint32_t)i;
+        if (dev[i].n_channels > 1) multi[n_multi++] = (uint32_t)i;
+    }
+    return n_multi;
+}
+
 #endif

@@ -14,8 +14,9 @@
  *
  * Memory: "device" pointers are HIP device pointers on the context's GPU.
  * A device arena must be 16-byte aligned and its ALLOCATION must cover
- * arena_len rounded up to a multiple of 16 bytes (the kernels stage the
- * bitstream with 16-byte granules; bytes past arena_len are never interpreted).
+ * arena_len + 16 bytes rounded up to a multiple of 16 (the kernels read the
+ * bitstream in aligned 8/16-byte granules; bytes past arena_len are never
+ * interpreted).
  */
 #ifndef CLAXON_HIP_H
 #define CLAXON_HIP_H
@@ -164,8 +165,14 @@ const char* clx_last_error(const clx_ctx* ctx);
 enum {
     CLX_ARENA_ON_DEVICE = 1u << 0,   /* arena is a device pointer (else host; copied H2D) */
     CLX_OUT_ON_DEVICE   = 1u << 1,   /* out is a device pointer (else host; copied D2H)   */
-    CLX_VERIFY_CRC16    = 1u << 2    /* also verify each frame's CRC-16 footer on device
+    CLX_VERIFY_CRC16    = 1u << 2,   /* also verify each frame's CRC-16 footer on device
                                         (frame.rs:752-763); mismatch -> CLX_MSG_FRAME_CRC_MISMATCH */
+    /* Kernel path.  Default (neither bit): chosen from the batch shape.
+     * WAVES: one wavefront per frame, wave-parallel Rice decode (lowest latency for a few frames).
+     * LANES: one lane per subframe, lane-serial fused decode (highest throughput for many frames;
+     *        needs arena_len < 4 GiB). */
+    CLX_PATH_WAVES      = 1u << 3,
+    CLX_PATH_LANES      = 1u << 4
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32
@@ -196,10 +203,11 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
 int  clx_batch_results(clx_batch* b, clx_frame_result* results);
 /* Number of predictor slots (subframes incl. alignment padding) in the plan. */
 uint64_t clx_batch_slots(const clx_batch* b);
-/* Per-kernel HIP-event timing of the LAST run made with profiling enabled.
- * kernel: 0 = rice_residual_decode, 1 = predict_decorrelate, 2 = crc16_verify. */
+/* Per-kernel HIP-event timing of the LAST run made with profiling enabled: kernels are numbered in
+ * launch order (clx_batch_kernel_name gives the name; NULL past the last one). */
 int  clx_batch_set_profiling(clx_batch* b, int enable);
 int  clx_batch_kernel_ms(clx_batch* b, int kernel, float* ms);
+const char* clx_batch_kernel_name(const clx_batch* b, int kernel);
 void clx_batch_destroy(clx_batch* b);
 
 /* ------------------------------------------------------------------------

@@ -39,9 +39,12 @@ def check_workload(oracle, backend, w, verify_crc=True):
 def check_truncations(oracle, backend, n_frames=8, cuts_per_frame=24, seed=1000):
     """EOF parity: every prefix of a frame must fail (or succeed) exactly as the reference does."""
     w = synth.small_mixed(n_frames, bs=64, seed_off=seed)
+    e = edge_workload()
+    pick = np.random.default_rng(seed).choice(e.n, size=min(e.n, max(4, n_frames // 2)), replace=False)
+    frames = [w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])] for i in range(w.n)] + \
+             [e.arena[int(e.offs[i]):int(e.offs[i] + e.lens[i])] for i in pick if e.lens[i] < 400]
     seen = set()
-    for i in range(w.n):
-        fr = w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])]
+    for i, fr in enumerate(frames):
         L = len(fr)
         rng = np.random.default_rng(seed + i)
         cuts = sorted(set(list(range(0, min(L, 12))) + rng.integers(0, L, cuts_per_frame).tolist() + [L - 3, L - 2, L - 1, L]))
@@ -122,3 +125,24 @@ def check_fuzz_corpus(oracle, backend):
             end, blocks, _ = stream_decode_both(oracle, backend, data, crc)
             seen.add(end)
     assert len(seen) >= 8
+
+
+def edge_workload():
+    """Block sizes equal to the predictor order (no residual samples at all, yet the residual header and
+    its partition parameter are still in the stream), tiny blocks, 32-tap predictors next to constants --
+    mixed into one batch so that lanes of one wave hit these edges at different sample indices."""
+    rng = np.random.default_rng(99)
+    ws = []
+    cases = [(8, 8, synth.SF_LPC, 16), (16, 16, synth.SF_LPC, 24), (4, 4, synth.SF_FIXED, 16), (32, 32, synth.SF_LPC, 16),
+             (1, 0, synth.SF_FIXED, 8), (1, 1, synth.SF_LPC, 12), (2, 1, synth.SF_FIXED, 20), (24, 3, synth.SF_FIXED, 16),
+             (4096, 32, synth.SF_LPC, 24), (40, 8, synth.SF_LPC, 16), (9, 8, synth.SF_LPC, 16), (12, 12, synth.SF_LPC, 16)]
+    for rep in range(3):
+        for bs, order, kind, bps in cases:
+            for ca, channels in ((0, 1), (3, 2), (1, 2), (2, 2), (0, 3)):
+                lim = 1 << (bps - 1)
+                pcm = rng.integers(-lim // 4, lim // 4, size=(1, channels, bs)).astype(np.int32)
+                fp = synth.FrameParams(ca, 0, int(rng.integers(0, 1000)))
+                for c in range(channels):
+                    fp.sf[c] = synth.sf(kind, order, int(rng.integers(2, 16)), 0, force_rice2=int(rng.integers(0, 2)))
+                ws.append(synth.encode_frames("e", pcm, channels, bs, bps, [fp]))
+    return synth.concat("edges", ws)

@@ -16,9 +16,12 @@ def pad16(data):
 class SimBackend:
     name = "wavesim"
 
+    def __init__(self, path=0):
+        self.path = path          # 0 auto (= waves in the simulator), cx.PATH_WAVES, cx.PATH_LANES
+
     def decode(self, arena, arena_len, descs, out_offs, verify_crc, fill=0):
         import simlib
-        out, res, _ = simlib.decode(arena, arena_len, descs, out_offs, verify_crc=verify_crc, fill=fill)
+        out, res, _ = simlib.decode(arena, arena_len, descs, out_offs, verify_crc=verify_crc, fill=fill, path=self.path)
         return out, res
 
 
@@ -26,10 +29,11 @@ class GpuBackend:
     """Planned-batch path on device-resident buffers (torch is only the allocator here)."""
     name = "gpu"
 
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, path=0):
         import torch
         self.torch = torch
         self.ctx = ctx or cx.Context(0)
+        self.path = path
 
     def decode(self, arena, arena_len, descs, out_offs, verify_crc, fill=0):
         torch = self.torch
@@ -39,7 +43,7 @@ class GpuBackend:
                      descs["block_size"].astype(np.uint64)).max()) if n else 0
         d_arena = torch.from_numpy(np.ascontiguousarray(arena)).to("cuda:0")
         d_out = torch.full((max(total, 1),), int(np.int32(fill)), dtype=torch.int32, device="cuda:0")
-        batch = self.ctx.plan(descs, out_offs, verify_crc=verify_crc)
+        batch = self.ctx.plan(descs, out_offs, verify_crc=verify_crc, path=self.path)
         torch.cuda.synchronize()
         batch.run(d_arena.data_ptr(), int(arena_len), d_out.data_ptr())
         res = batch.results()

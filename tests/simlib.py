@@ -18,7 +18,7 @@ assert SF_DESC_DTYPE.itemsize == 80
 
 def build(force=False):
     deps = [os.path.join(_DIR, f) for f in ("sim_lib.cpp", "wavesim.h")] + \
-           [os.path.join(_CSRC, f) for f in ("clx_kernels.hip", "clx_device.h", "clx_plan.h")]
+           [os.path.join(_CSRC, f) for f in ("clx_kernels.hip", "clx_lanes.hip", "clx_device.h", "clx_plan.h")]
     if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps):
         return _SO
     subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++",
@@ -39,7 +39,7 @@ def lib():
     return _lib
 
 
-def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_only=False, fill=0):
+def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_only=False, fill=0, path=0):
     """Run K1 (+K2, +K3) under simulation.  `arena` must be 16-byte padded beyond arena_len."""
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
     # the simulator reads the arena exactly like the GPU: 16-byte aligned base, padded allocation
@@ -56,7 +56,7 @@ def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_onl
     res = np.zeros(n, dtype=cx.FRAME_RESULT_DTYPE)
     nslots = C.c_uint64(0)
     sfd = np.zeros(int(descs["n_channels"].sum()) + n + 2, dtype=SF_DESC_DTYPE)
-    flags = (cx.VERIFY_CRC16 if verify_crc else 0) | (0x100 if k1_only else 0)
+    flags = (cx.VERIFY_CRC16 if verify_crc else 0) | (0x100 if k1_only else 0) | path
     st = lib().sim_decode_frames(al.ctypes.data, arena_len, descs.ctypes.data, n, out.ctypes.data, out_offs.ctypes.data,
                                  res.ctypes.data, flags, sfd.ctypes.data, C.byref(nslots))
     assert st == 0

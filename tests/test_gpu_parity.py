@@ -11,8 +11,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def gpu():
-    return GpuBackend(cx.Context(0, wait_s=120))
+def ctx():
+    return cx.Context(0, wait_s=120)
+
+
+@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES], ids=["waves", "lanes"])
+def gpu(ctx, request):
+    """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip)."""
+    return GpuBackend(ctx, request.param)
 
 
 @pytest.mark.parametrize("make", [
@@ -21,6 +27,10 @@ def gpu():
 ], ids=["config2", "config3", "config4", "config5", "small_mixed"])
 def test_gpu_workloads(oracle, gpu, make):
     pc.check_workload(oracle, gpu, make())
+
+
+def test_gpu_edges(oracle, gpu):
+    pc.check_workload(oracle, gpu, pc.edge_workload())
 
 
 def test_gpu_truncations(oracle, gpu):

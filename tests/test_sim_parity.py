@@ -10,11 +10,15 @@ import synth
 from parity_util import SimBackend
 
 
-@pytest.fixture(scope="module")
-def sim():
+import claxon_amd as cx
+
+
+@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES], ids=["waves", "lanes"])
+def sim(request):
+    """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip)."""
     import simlib
     simlib.build()
-    return SimBackend()
+    return SimBackend(request.param)
 
 
 @pytest.mark.parametrize("make", [
@@ -23,6 +27,10 @@ def sim():
 ], ids=["config2", "config3", "config4", "config5", "small_mixed"])
 def test_sim_workloads(oracle, sim, make):
     pc.check_workload(oracle, sim, make())
+
+
+def test_sim_edges(oracle, sim):
+    pc.check_workload(oracle, sim, pc.edge_workload())
 
 
 def test_sim_truncations(oracle, sim):

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE: runs the production kernel source under the wave simulator.
 #include <vector>
 #include "clx_kernels.hip"
+#include "clx_lanes.hip"
 #include "clx_plan.h"
 
 extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
@@ -13,6 +14,19 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
     std::vector<clx_sf_desc> sfd(n_slots ? n_slots : 1);
     memset(sfd.data(), 0, sfd.size() * sizeof(clx_sf_desc));
     const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
+    if (flags & CLX_PATH_LANES) {
+        std::vector<uint32_t> slot_frame(n_slots ? n_slots : 1), multi(n ? n : 1), sf_start(n_slots ? n_slots : 1, 0xffffffffu),
+            errkey(n ? n : 1, 0xffffffffu);
+        std::vector<uint64_t> endbits(n ? n : 1, 0);
+        const size_t n_multi = clx_plan_lanes(dev.data(), n, n_slots, slot_frame.data(), multi.data());
+        if (n_slots_out) *n_slots_out = n_slots;
+        if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, arena, dev.data(), multi.data(), (uint32_t)n_multi, sf_start.data(), errkey.data());
+        SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, arena, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
+                   errkey.data(), endbits.data());
+        SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, errkey.data(), endbits.data(), (uint32_t)n, results);
+        if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
+        return CLX_OK;
+    }
     SIM_LAUNCH(clx_k_residual, n, 64, arena, alloc_len, dev.data(), (uint32_t)n, out, sfd.data(), results);
     if (n_slots_out) *n_slots_out = n_slots;
     if (sfd_out) memcpy(sfd_out, sfd.data(), n_slots * sizeof(clx_sf_desc));
