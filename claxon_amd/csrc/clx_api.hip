@@ -360,7 +360,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         HIP_TRY(ctx, hipStreamSynchronize(stream));                    // `up` goes out of scope
         b->planned_arena_len = arena_len;
     }
-    const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
+    const uint64_t alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;   // claxon_hip.h: the allocation covers this
 
     int nk = 0;
     auto mark = [&](const char* name) -> bool {          // event before each kernel (+ one after the last)
@@ -374,12 +374,12 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         HIP_TRY(ctx, hipMemsetAsync(b->d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream));
         if (b->n_multi) {
             if (!mark("clx_k_scan")) return CLX_API_ERROR;
-            hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64)), dim3(64), 0, stream, d_arena,
+            hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
                                (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi,
                                b->d_sf_start, b->d_errkey);
         }
         if (!mark("clx_k_lanes")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena,
+        hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
                            (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits);
         if (!mark("clx_k_finalize")) return CLX_API_ERROR;

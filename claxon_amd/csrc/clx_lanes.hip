@@ -25,11 +25,12 @@
 
 #define CLX_LERR(status, msg) (((uint32_t)(status) << 16) | (uint32_t)(msg))
 
-// Per-lane MSB-first bit reader straight over the arena (served by the vector L1: a lane re-reads the
-// same 64/128-byte line for ~100 codes).  `pos` counts bits from the frame's 4-byte aligned origin.
+// Per-lane MSB-first bit reader straight over the arena (vector L1).  Used for headers and for the rare
+// "careful" steps; the per-code hot path reads through the LDS ring below.  `pos` counts bits from the
+// frame's 16-byte aligned origin.
 struct LaneReader {
     const uint8_t* arena;     // wave-uniform
-    uint32_t origin;          // byte offset of the origin from `arena` (multiple of 4); arena_len < 4 GiB on this path
+    uint32_t origin;          // byte offset of the origin from `arena` (multiple of 16); arena_len < 4 GiB on this path
     uint32_t pos;
     uint32_t limit;           // first unreadable bit
     uint32_t err;             // CLX_LERR(...) of the first error, 0 = none
@@ -149,76 +150,215 @@ __device__ __forceinline__ void clx_report_error(uint32_t* errkey, uint32_t fram
 }
 
 // ------------------------------------------------------------------------------------------------
+// Per-lane LDS ring: the next CLX_RING dwords of the lane's stream, byte-swapped, so that the per-code
+// peek is one ds_read2_b32 + a funnel shift instead of a dependent global load (an L1 hit with 64
+// divergent lines costs >300 cycles; the code chain is serial in the bit position).  The ring is
+// filled split-phase with 16-byte loads: a granule requested at one block boundary is written to LDS
+// at the next, so HBM/L2 latency never sits on the decode chain.  Row stride CLX_RING+1: slot CLX_RING
+// mirrors slot 0, so a pair read never wraps.
+// ------------------------------------------------------------------------------------------------
+#define CLX_RING 32u
+struct LanesLds { uint32_t ring[64][CLX_RING + 1u]; };
+
+struct Ring {
+    const uint32_t* src;      // arena + origin (16-byte aligned)
+    uint32_t avail_dw;        // dwords readable from src
+    uint32_t fill;            // stream dwords [fill-CLX_RING, fill) are in the ring; multiple of 4
+    uint32_t pend_at;
+    uint4 pend;
+    bool has_pend;
+};
+
+__device__ __forceinline__ uint4 clx_ring_fetch(const Ring& g, uint32_t dw) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (dw + 4u <= g.avail_dw) v = *reinterpret_cast<const uint4*>(g.src + dw);
+    return v;
+}
+__device__ __forceinline__ void clx_ring_put(uint32_t* row, uint32_t dw, const uint4 v) {
+    const uint32_t s = dw & (CLX_RING - 1u);
+    row[s] = __builtin_bswap32(v.x); row[s + 1u] = __builtin_bswap32(v.y);
+    row[s + 2u] = __builtin_bswap32(v.z); row[s + 3u] = __builtin_bswap32(v.w);
+    if (s == 0u) row[CLX_RING] = __builtin_bswap32(v.x);
+}
+// synchronous (re)fill starting at the granule that holds dword `dw` (start of a subframe, or after a jump)
+__device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t dw) {
+    const uint32_t f0 = dw & ~3u;
+    uint4 t[CLX_RING / 4u];
+#pragma unroll
+    for (uint32_t q = 0; q < CLX_RING / 4u; ++q) t[q] = clx_ring_fetch(g, f0 + 4u * q);
+#pragma unroll
+    for (uint32_t q = 0; q < CLX_RING / 4u; ++q) clx_ring_put(row, f0 + 4u * q, t[q]);
+    g.fill = f0 + CLX_RING;
+    g.has_pend = false;
+}
+// once per block: land the granule requested last time, request the next one when the lookahead runs low
+__device__ __forceinline__ void clx_ring_pump(Ring& g, uint32_t* row, uint32_t pos) {
+    const uint32_t dw = pos >> 5;
+    if (g.has_pend) { clx_ring_put(row, g.pend_at, g.pend); g.fill = g.pend_at + 4u; g.has_pend = false; }
+    if (dw + 2u > g.fill || dw + CLX_RING < g.fill) clx_ring_reset(g, row, dw);        // the position jumped (long run / careful steps)
+    else if (g.fill - dw <= CLX_RING - 12u) { g.pend_at = g.fill; g.pend = clx_ring_fetch(g, g.fill); g.has_pend = true; }
+}
+// a lane may run a fast block only if the ring covers the next `ahead` dwords
+__device__ __forceinline__ bool clx_ring_covers(const Ring& g, uint32_t pos, uint32_t ahead) {
+    const uint32_t dw = pos >> 5;
+    return dw + CLX_RING >= g.fill && dw + ahead + 2u <= g.fill;
+}
+__device__ __forceinline__ uint32_t clx_ring_peek32(const uint32_t* row, uint32_t pos) {
+    const uint32_t s = (pos >> 5) & (CLX_RING - 1u);
+    const uint64_t w = ((uint64_t)row[s] << 32) | row[s + 1u];
+    return (uint32_t)((w << (pos & 31u)) >> 32);
+}
+
+// ------------------------------------------------------------------------------------------------
 // P: locate subframes 1..C-1 of every multi-channel frame
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_scan(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames,
+void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
+                const clx_dev_frame* __restrict__ frames,
                 const uint32_t* __restrict__ multi, uint32_t n_multi,
                 uint32_t* __restrict__ sf_start, uint32_t* __restrict__ errkey) {
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    if (t >= n_multi) return;
-    const uint32_t f = multi[t];
-    const clx_dev_frame fr = frames[f];
+    __shared__ LanesLds L;
+    const int lane = (int)threadIdx.x;
+    uint32_t* const row = L.ring[lane];
+    const uint32_t t = blockIdx.x * 64u + (uint32_t)lane;
+    const bool active = t < n_multi;
+    const uint32_t f = active ? multi[t] : 0u;
+    clx_dev_frame fr;
+    fr.byte_off = 0; fr.out_off = 0; fr.limit_bits = 0; fr.first_slot = 0; fr.header_bytes = 0; fr.block_size = 0;
+    fr.n_channels = 0; fr.channel_assignment = 0; fr.bps = 1; fr.flags = 0;
+    if (active) fr = frames[f];
     LaneReader r;
     r.arena = arena;
-    r.origin = (uint32_t)(fr.byte_off & ~3ull);
-    const uint32_t o = 8u * (uint32_t)(fr.byte_off & 3ull);
+    r.origin = (uint32_t)(fr.byte_off & ~15ull);
+    const uint32_t o = 8u * (uint32_t)(fr.byte_off & 15ull);
     r.limit = o + fr.limit_bits;
     r.pos = o + 8u * (uint32_t)fr.header_bytes;
-    r.err = (r.pos > r.limit) ? CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF) : 0u;
+    r.err = active ? ((r.pos > r.limit) ? CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF) : 0u) : 1u;
+    Ring g;
+    g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
+    g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
+    g.fill = 0; g.has_pend = false; g.pend_at = 0; g.pend = make_uint4(0u, 0u, 0u, 0u);
     const uint32_t bs = fr.block_size;
-    for (uint32_t ch = 0; ch + 1u < fr.n_channels; ++ch) {
-        const SfHead h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
-        if (!r.err) {
-            if (h.kind == 0u) {                                    // decode_constant
-                (void)clx_lread(r, h.sf_bps);
-            } else if (h.kind == 1u) {                             // decode_verbatim
-                if ((uint64_t)r.pos + (uint64_t)bs * h.sf_bps > (uint64_t)r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-                else r.pos += bs * h.sf_bps;
-            } else {
-                if (bs < h.order) r.err = CLX_LERR(CLX_FORMAT_ERROR, h.kind == 2u ? CLX_MSG_FIXED_ORDER_GT_BLOCK : CLX_MSG_LPC_ORDER_GT_BLOCK);
-                if (!r.err) {
-                    if (r.pos + h.order * h.sf_bps > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-                    else r.pos += h.order * h.sf_bps;                // warm-up samples
-                }
-                if (!r.err && h.kind == 3u) {                      // decode_lpc, subframe.rs:669-701
-                    const uint32_t pm1 = clx_lread(r, 4);
-                    if (!r.err && pm1 == 15u) r.err = CLX_LERR(CLX_FORMAT_ERROR, CLX_MSG_QLP_PRECISION_INVALID);
-                    const uint32_t sh = clx_lread(r, 5);
-                    if (!r.err && (sh & 0x10u)) r.err = CLX_LERR(CLX_UNSUPPORTED, CLX_MSG_NEGATIVE_QLP_SHIFT);
+    uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
+    uint32_t nch_max = nch;
+#pragma unroll
+    for (int sx = 32; sx >= 1; sx >>= 1) { const uint32_t a = __shfl_xor(nch_max, sx, 64); nch_max = a > nch_max ? a : nch_max; }
+
+    for (uint32_t ch = 0; ch < nch_max; ++ch) {
+        const bool on = ch < nch && !r.err;
+        // ---- headers (per lane, generic reader)
+        uint32_t codes = 0, first = 0, per = 0, parts_left = 0, rice2 = 0;
+        if (on) {
+            const SfHead h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
+            if (!r.err) {
+                if (h.kind == 0u) (void)clx_lread(r, h.sf_bps);
+                else if (h.kind == 1u) {
+                    if ((uint64_t)r.pos + (uint64_t)bs * h.sf_bps > (uint64_t)r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                    else r.pos += bs * h.sf_bps;
+                } else {
+                    if (bs < h.order) r.err = CLX_LERR(CLX_FORMAT_ERROR, h.kind == 2u ? CLX_MSG_FIXED_ORDER_GT_BLOCK : CLX_MSG_LPC_ORDER_GT_BLOCK);
                     if (!r.err) {
-                        if (r.pos + h.order * (pm1 + 1u) > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-                        else r.pos += h.order * (pm1 + 1u);
+                        if (r.pos + h.order * h.sf_bps > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                        else r.pos += h.order * h.sf_bps;
                     }
-                }
-                if (!r.err) {
-                    const ResHead rh = clx_lparse_residual_header(r, bs, h.order);
-                    uint32_t len = rh.per - h.order;
-                    for (uint32_t part = 0; part < rh.n_part && !r.err; ++part) {
-                        const uint32_t k = clx_lread_rice_param(r, rh.rice2);
-                        const uint32_t k1 = k + 1u;
-                        for (uint32_t i = 0; i < len && !r.err; ++i) {
-                            const uint32_t v = clx_lpeek32(r, r.pos);
-                            const uint32_t n = (uint32_t)__clz((int)v) + k1;
-                            if (v != 0u && n <= 32u) {
-                                r.pos += n;
-                                if (r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-                            } else (void)clx_lrice_slow(r, k);
+                    if (!r.err && h.kind == 3u) {
+                        const uint32_t pm1 = clx_lread(r, 4);
+                        if (!r.err && pm1 == 15u) r.err = CLX_LERR(CLX_FORMAT_ERROR, CLX_MSG_QLP_PRECISION_INVALID);
+                        const uint32_t sh = clx_lread(r, 5);
+                        if (!r.err && (sh & 0x10u)) r.err = CLX_LERR(CLX_UNSUPPORTED, CLX_MSG_NEGATIVE_QLP_SHIFT);
+                        if (!r.err) {
+                            if (r.pos + h.order * (pm1 + 1u) > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                            else r.pos += h.order * (pm1 + 1u);
                         }
-                        len = rh.per;
+                    }
+                    if (!r.err) {
+                        const ResHead rh = clx_lparse_residual_header(r, bs, h.order);
+                        if (!r.err) { codes = bs - h.order; first = rh.per - h.order; per = rh.per; parts_left = rh.n_part; rice2 = rh.rice2; }
                     }
                 }
             }
         }
-        if (r.err) { clx_report_error(errkey, f, ch, r.err); return; }
-        sf_start[fr.first_slot + ch + 1u] = r.pos;
+        // ---- all Rice codes of this subframe: only their lengths matter here
+        uint32_t left = r.err ? 0u : codes;                 // codes still to skip
+        uint32_t pcnt = 0, next_cnt = first, k = 0, k1 = 1;
+        uint32_t lmax = left;
+#pragma unroll
+        for (int sx = 32; sx >= 1; sx >>= 1) { const uint32_t a = __shfl_xor(lmax, sx, 64); lmax = a > lmax ? a : lmax; }
+        if (lmax != 0u) clx_ring_reset(g, row, r.pos >> 5);
+        for (uint32_t i0 = 0; i0 < lmax; i0 += 4u) {
+            clx_ring_pump(g, row, r.pos);
+            // fast block: 4 codes through the ring, no EOF possible, every code <= 32 bits
+            const bool busy = left >= 4u && !r.err;
+            const bool can = !busy || (r.pos + 4u * 40u <= r.limit && clx_ring_covers(g, r.pos, 6u));
+            uint32_t pos2 = r.pos, pcnt2 = pcnt, k_2 = k, k1_2 = k1, parts2 = parts_left, next2 = next_cnt;
+            bool ok = can;
+            if (__all(can)) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    if (__any(busy && pcnt2 == 0u)) {
+                        if (busy && pcnt2 == 0u) {              // partition parameter (subframe.rs:314-319 / 362-367)
+                            const uint32_t pb = rice2 ? 5u : 4u;
+                            k_2 = clx_ring_peek32(row, pos2) >> (32u - pb);
+                            if (k_2 == (rice2 ? 31u : 15u) || parts2 == 0u || next2 == 0u) ok = false;
+                            k1_2 = k_2 + 1u; pos2 += pb; parts2 -= 1u; pcnt2 = next2; next2 = per;
+                        }
+                    }
+                    const uint32_t v = clx_ring_peek32(row, pos2);
+                    const uint32_t nb = (uint32_t)__clz((int)v) + k1_2;
+                    if (v == 0u || nb > 32u) ok = false;
+                    if (busy) { pos2 += nb; pcnt2 -= 1u; }
+                }
+            }
+            const bool all_ok = __all(ok);
+            if (all_ok && busy) { r.pos = pos2; pcnt = pcnt2; k = k_2; k1 = k1_2; parts_left = parts2; next_cnt = next2; left -= 4u; }
+            const bool tail = !r.err && left != 0u && left < 4u;
+            if (!all_ok || __any(tail)) {
+                // careful steps (rolled): empty partitions, escape codes, long runs, EOF, tails
+#pragma unroll 1
+                for (int ii = 0; ii < 4; ++ii) {
+                    if (!r.err && left != 0u && (!all_ok || left < 4u)) {
+                        while (!r.err && pcnt == 0u && parts_left != 0u) {
+                            k = clx_lread_rice_param(r, rice2); k1 = k + 1u; parts_left -= 1u; pcnt = next_cnt; next_cnt = per;
+                        }
+                        if (!r.err) {
+                            const uint32_t v = clx_lpeek32(r, r.pos);
+                            const uint32_t nb = (uint32_t)__clz((int)v) + k1;
+                            if (v != 0u && nb <= 32u) {
+                                r.pos += nb;
+                                if (r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                            } else (void)clx_lrice_slow(r, k);
+                            pcnt -= 1u; left -= 1u;
+                        }
+                    }
+                }
+            }
+        }
+        // partition parameters that belong to empty partitions at the very end (order == block size: subframe.rs:509, 706)
+        if (on && !r.err) {
+            while (!r.err && parts_left != 0u) { (void)clx_lread_rice_param(r, rice2); parts_left -= 1u; }
+        }
+        if (on) {
+            if (r.err) clx_report_error(errkey, f, ch, r.err);
+            else sf_start[fr.first_slot + ch + 1u] = r.pos;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // D: one lane per subframe, everything fused
 // ------------------------------------------------------------------------------------------------
-#define CLX_LB 8          // samples per block (two 16-byte stores per lane per block)
+template <int OMAX>
+struct LaneState {
+    LaneReader r;
+    uint32_t phase;            // 0 fixed-width fields (warm-up / verbatim), 1 rice, 2 constant, 3 idle
+    int32_t  cval;
+    uint32_t trans_at;         // sample index at which a predicted subframe switches to residuals
+    bool     transitioned;
+    uint32_t order, shift;     // predictor (active from the transition on)
+    int32_t  lim;              // |s| range in which the 24-bit / i32 evaluation is exact; -1: use i64
+    uint32_t k, k1, pcnt, next_cnt, per, parts_left, rice2;
+    int32_t  c[OMAX], hist[OMAX];
+};
 
 template <int OMAX, bool WIDE>
 __device__ __forceinline__ int32_t clx_lpredict(const int32_t (&c)[OMAX], const int32_t (&hist)[OMAX], uint32_t shift) {
@@ -235,199 +375,265 @@ __device__ __forceinline__ int32_t clx_lpredict(const int32_t (&c)[OMAX], const 
     }
 }
 
-template <int OMAX, bool ALIGNED>
-__device__ __forceinline__ void clx_lanes_body(LaneReader& r, const SfHead h, uint32_t bs, uint32_t decor, bool pair_ok,
-                                               int32_t* __restrict__ row, uint32_t nmax, int lane,
-                                               uint32_t* end_pos_out) {
-    int32_t c[OMAX], hist[OMAX];
+// LPC parameters + residual header (subframe.rs:669-701, 241-277): once per predicted subframe, at the sample index
+// where the warm-up ends -- also when that index is the block size (no residual samples at all: the residual
+// header and its partition parameter are still in the stream, subframe.rs:509, 706).
+template <int OMAX>
+__device__ __forceinline__ void clx_ltransition(LaneState<OMAX>& S, const SfHead& h, uint32_t bs) {
+    LaneReader& r = S.r;
+    uint32_t cabs = 0;
+    if (h.kind == 3u) {
+        const uint32_t pm1 = clx_lread(r, 4);
+        if (!r.err && pm1 == 15u) r.err = CLX_LERR(CLX_FORMAT_ERROR, CLX_MSG_QLP_PRECISION_INVALID);
+        const uint32_t sh = clx_lread(r, 5);
+        if (!r.err && (sh & 0x10u)) r.err = CLX_LERR(CLX_UNSUPPORTED, CLX_MSG_NEGATIVE_QLP_SHIFT);
+        S.shift = sh & 0xfu;
+        if (!r.err && r.pos + h.order * (pm1 + 1u) > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
 #pragma unroll
-    for (int j = 0; j < OMAX; ++j) { c[j] = 0; hist[j] = 0; }
-    const bool odd = (lane & 1) != 0;
-    const bool any_decor = __any(pair_ok);
-    const uint32_t n = r.err ? 0u : bs;              // a lane that failed in its header produces nothing
-
-    // phases: 0 fixed-width fields (warm-up / verbatim), 1 rice, 2 constant, 3 idle
-    uint32_t phase = 3u;
-    int32_t cval = 0;
-    uint32_t trans_at = 0xffffffffu;                 // sample index at which a predicted subframe switches to residuals
-    if (n) {
-        if (h.kind == 0u) { cval = clx_lread_signed(r, h.sf_bps); phase = 2u; }
-        else if (h.kind == 1u) phase = 0u;
-        else {
-            if (bs < h.order) r.err = CLX_LERR(CLX_FORMAT_ERROR, h.kind == 2u ? CLX_MSG_FIXED_ORDER_GT_BLOCK : CLX_MSG_LPC_ORDER_GT_BLOCK);
-            else { phase = 0u; trans_at = h.order; }
+        for (int j = 0; j < OMAX; ++j) {           // j-th coded coefficient applies to s[i-1-j] (subframe.rs:696-701)
+            if ((uint32_t)j < h.order && !r.err) S.c[j] = clx_lread_signed(r, pm1 + 1u);
+            cabs += (uint32_t)(S.c[j] < 0 ? -S.c[j] : S.c[j]);
         }
+    } else {                                       // fixed predictors as taps on s[i-1-j] (subframe.rs:427-431)
+        const uint32_t o = h.order;
+        S.c[0] = o == 1u ? 1 : o == 2u ? 2 : o == 3u ? 3 : o == 4u ? 4 : 0;
+        S.c[1] = o == 2u ? -1 : o == 3u ? -3 : o == 4u ? -6 : 0;
+        S.c[2] = o == 3u ? 1 : o == 4u ? 4 : 0;
+        S.c[3] = o == 4u ? -1 : 0;
+        cabs = o == 1u ? 1u : o == 2u ? 3u : o == 3u ? 7u : o == 4u ? 15u : 0u;
     }
-    uint32_t order = 0, shift = 0;                   // predictor becomes active at the transition
-    uint32_t k = 0, k1 = 1, pcnt = 0, per = 0, parts_left = 0, rice2 = 0;
-    int32_t lim = 0x7fffffff;                        // |s| range in which the 24-bit / i32 evaluation is exact; -1: use i64
-    bool wide = false;                               // wave-uniform, sticky
-    bool transitioned = false;
+    S.order = h.order;
+    S.lim = (h.sf_bps <= 24u && ((uint64_t)cabs << (h.sf_bps - 1u)) < (1ull << 31)) ? (int32_t)(1u << (h.sf_bps - 1u)) : -1;
+    const ResHead rh = clx_lparse_residual_header(r, bs, h.order);
+    S.rice2 = rh.rice2; S.per = rh.per; S.parts_left = rh.n_part;
+    S.pcnt = 0; S.next_cnt = rh.per - h.order;     // the first partition holds per - order codes (subframe.rs:283)
+    S.phase = 1u;
+    S.transitioned = true;
+}
 
-    // LPC parameters + residual header (subframe.rs:669-701, 241-277): executed once per predicted subframe, at the
-    // sample index where the warm-up ends -- also when that index is the block size (no residual samples at all:
-    // the residual header and its single partition parameter are still read, subframe.rs:509, 706).
-    auto transition = [&]() {
-        uint32_t cabs = 0;
-        if (h.kind == 3u) {
-            const uint32_t pm1 = clx_lread(r, 4);
-            if (!r.err && pm1 == 15u) r.err = CLX_LERR(CLX_FORMAT_ERROR, CLX_MSG_QLP_PRECISION_INVALID);
-            const uint32_t sh = clx_lread(r, 5);
-            if (!r.err && (sh & 0x10u)) r.err = CLX_LERR(CLX_UNSUPPORTED, CLX_MSG_NEGATIVE_QLP_SHIFT);
-            shift = sh & 0xfu;
-            if (!r.err && r.pos + h.order * (pm1 + 1u) > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-#pragma unroll
-            for (int j = 0; j < OMAX; ++j) {       // j-th coded coefficient applies to s[i-1-j] (subframe.rs:696-701)
-                if ((uint32_t)j < h.order && !r.err) c[j] = clx_lread_signed(r, pm1 + 1u);
-                cabs += (uint32_t)(c[j] < 0 ? -c[j] : c[j]);
+// One sample the careful way (generic reader over global memory, every rare case handled in line):
+// returns the sample's raw value (residual, warm-up / verbatim sample, or the constant).
+template <int OMAX>
+__device__ __forceinline__ int32_t clx_lcareful_raw(LaneState<OMAX>& S, const SfHead& h, uint32_t bs, uint32_t i, uint32_t n) {
+    LaneReader& r = S.r;
+    if (n != 0u && !r.err && i == S.trans_at) clx_ltransition<OMAX>(S, h, bs);
+    int32_t x = S.cval;
+    if (i < n && !r.err) {
+        if (S.phase == 0u) x = clx_lread_signed(r, h.sf_bps);                      // warm-up / verbatim (subframe.rs:397-415)
+        else if (S.phase == 1u) {
+            while (!r.err && S.pcnt == 0u && S.parts_left != 0u) {                   // partition parameter(s)
+                S.k = clx_lread_rice_param(r, S.rice2); S.k1 = S.k + 1u; S.parts_left -= 1u; S.pcnt = S.next_cnt; S.next_cnt = S.per;
             }
-        } else {                                   // fixed predictors as taps on s[i-1-j] (subframe.rs:427-431)
-            const uint32_t o = h.order;
-            c[0] = o == 1u ? 1 : o == 2u ? 2 : o == 3u ? 3 : o == 4u ? 4 : 0;
-            c[1] = o == 2u ? -1 : o == 3u ? -3 : o == 4u ? -6 : 0;
-            c[2] = o == 3u ? 1 : o == 4u ? 4 : 0;
-            c[3] = o == 4u ? -1 : 0;
-            cabs = o == 1u ? 1u : o == 2u ? 3u : o == 3u ? 7u : o == 4u ? 15u : 0u;
-        }
-        order = h.order;
-        lim = (h.sf_bps <= 24u && ((uint64_t)cabs << (h.sf_bps - 1u)) < (1ull << 31)) ? (int32_t)(1u << (h.sf_bps - 1u)) : -1;
-        const ResHead rh = clx_lparse_residual_header(r, bs, h.order);
-        rice2 = rh.rice2; per = rh.per; parts_left = rh.n_part;
-        pcnt = 0;
-        phase = 1u;
-        transitioned = true;
-        // the first partition holds per - order codes (subframe.rs:283); an empty first partition
-        // (per == order) still carries its parameter
-        if (!r.err) {
-            k = clx_lread_rice_param(r, rice2); k1 = k + 1u; parts_left -= 1u; pcnt = per - h.order;
-            while (!r.err && pcnt == 0u && parts_left != 0u) {
-                k = clx_lread_rice_param(r, rice2); k1 = k + 1u; parts_left -= 1u; pcnt = per;
-            }
-        }
-    };
-
-    int32_t y[CLX_LB], xs[CLX_LB];
-    for (uint32_t t0 = 0; t0 < nmax; t0 += CLX_LB) {
-        int32_t h0[OMAX];
-#pragma unroll
-        for (int j = 0; j < OMAX; ++j) h0[j] = hist[j];
-#pragma unroll
-        for (int ii = 0; ii < CLX_LB; ++ii) {
-            const uint32_t i = t0 + (uint32_t)ii;
-            const bool live = (n != 0u) && !r.err;          // the transition may fall on i == n (see above)
-            // ---- transition from warm-up to residuals
-            if (__any(live && i == trans_at)) {
-                if (live && i == trans_at) transition();
-            }
-            if (lim < 0 && live && i < n) wide = true;
-            // ---- the sample's raw value
-            int32_t x = cval;
-            const bool livenow = (i < n) && !r.err;
-            if (__any(livenow && phase == 0u)) {
-                if (livenow && phase == 0u) x = clx_lread_signed(r, h.sf_bps);          // warm-up / verbatim (subframe.rs:397-415)
-            }
-            if (livenow && phase == 1u) {
-                // one Rice code (subframe.rs:337-341)
+            if (!r.err) {
                 const uint32_t v = clx_lpeek32(r, r.pos);
                 const uint32_t z = (uint32_t)__clz((int)v);
-                const uint32_t nb = z + k1;
+                const uint32_t nb = z + S.k1;
                 uint32_t u;
                 if (v != 0u && nb <= 32u) {
-                    const uint32_t rem = k ? ((v << (z + 1u)) >> (32u - k)) : 0u;
-                    u = (z << k) | rem;
+                    const uint32_t rem = (v >> ((32u - nb) & 31u)) & ((1u << S.k) - 1u);
+                    u = (z << S.k) | rem;
                     r.pos += nb;
                     if (r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-                } else u = clx_lrice_slow(r, k);
-                x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                              // rice_to_signed (subframe.rs:157-170)
-                pcnt -= 1u;
-                while (!r.err && pcnt == 0u && parts_left != 0u) {                       // next partition's parameter
-                    k = clx_lread_rice_param(r, rice2); k1 = k + 1u; parts_left -= 1u; pcnt = per;
-                }
-            }
-            xs[ii] = x;
-        }
-        // ---- predictor over the block: fast 24-bit evaluation, verified; exact i64 re-run when out of the proven range
-        wide = __any(wide);
-        bool redo = wide;
-        if (!wide) {
-#pragma unroll
-            for (int ii = 0; ii < CLX_LB; ++ii) {
-                const uint32_t i = t0 + (uint32_t)ii;
-                const uint32_t ord_i = (i >= trans_at) ? order : 0u;
-                const int32_t pred = clx_lpredict<OMAX, false>(c, hist, shift);
-                const uint32_t use = (ord_i != 0u && i >= ord_i) ? 0xffffffffu : 0u;
-                const int32_t s = (int32_t)((uint32_t)xs[ii] + ((uint32_t)pred & use));
-#pragma unroll
-                for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
-                hist[0] = s;
-                y[ii] = s;
-            }
-            int32_t mx = y[0], mn = y[0];
-#pragma unroll
-            for (int ii = 1; ii < CLX_LB; ++ii) { mx = y[ii] > mx ? y[ii] : mx; mn = y[ii] < mn ? y[ii] : mn; }
-            const bool in_range = (order == 0u) || t0 >= n || r.err != 0u || (mx < lim && mn >= -lim);
-            if (!__all(in_range)) { redo = true; wide = true; }
-        }
-        if (redo) {
-#pragma unroll
-            for (int j = 0; j < OMAX; ++j) hist[j] = h0[j];
-#pragma unroll
-            for (int ii = 0; ii < CLX_LB; ++ii) {
-                const uint32_t i = t0 + (uint32_t)ii;
-                const uint32_t ord_i = (i >= trans_at) ? order : 0u;
-                const int32_t pred = clx_lpredict<OMAX, true>(c, hist, shift);
-                const uint32_t use = (ord_i != 0u && i >= ord_i) ? 0xffffffffu : 0u;
-                const int32_t s = (int32_t)((uint32_t)xs[ii] + ((uint32_t)pred & use));
-#pragma unroll
-                for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
-                hist[0] = s;
-                y[ii] = s;
+                } else u = clx_lrice_slow(r, S.k);
+                x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                          // rice_to_signed (subframe.rs:157-170)
+                S.pcnt -= 1u;
             }
         }
-        // ---- wasted-bits shift (subframe.rs:216-225), stereo decorrelation (frame.rs:319-389), store
+    }
+    return x;
+}
+
+// wasted-bits shift (subframe.rs:216-225) + stereo decorrelation (frame.rs:319-389) of one sample; wave-uniform call
+__device__ __forceinline__ int32_t clx_lfinish(int32_t s, uint32_t wasted, uint32_t decor, bool pair_ok, bool odd, bool any_decor) {
+    int32_t mine = (int32_t)((uint32_t)s << wasted);
+    if (any_decor) {
+        const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);       // lane ^ 1
+        const int32_t a = odd ? other : mine;                   // channel 0 as coded
+        const int32_t bb = odd ? mine : other;                  // channel 1 as coded
+        if (pair_ok) {
+            if (decor == CLX_CH_LEFT_SIDE) { if (odd) mine = (int32_t)((uint32_t)a - (uint32_t)bb); }
+            else if (decor == CLX_CH_RIGHT_SIDE) { if (!odd) mine = (int32_t)((uint32_t)a + (uint32_t)bb); }
+            else {
+                const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
+                // m +- side is even, so Rust's truncating `/ 2` equals an arithmetic shift
+                mine = odd ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1) : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
+            }
+        }
+    }
+    return mine;
+}
+
+template <int OMAX>
+__device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint32_t* ringrow, const SfHead h, uint32_t bs, uint32_t n,
+                                               uint32_t decor, bool pair_ok, int32_t* __restrict__ row, bool row_aligned,
+                                               uint32_t nmax, uint32_t omax, int lane) {
+    LaneReader& r = S.r;
+    const bool odd = (lane & 1) != 0;
+    const bool any_decor = __any(pair_ok);
+
+    // ---- careful prologue: warm-up samples, the transition, the first residuals (rolled loop, one sample per turn)
+    uint32_t i0 = ((omax + 3u) & ~3u) + 4u;
+    if (i0 > nmax) i0 = (nmax + 3u) & ~3u;
+#pragma unroll 1
+    for (uint32_t i = 0; i < i0; ++i) {
+        const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
+        const int32_t pred = clx_lpredict<OMAX, true>(S.c, S.hist, S.shift);
+        const uint32_t use = (S.order != 0u && i >= S.order && i >= S.trans_at) ? 0xffffffffu : 0u;
+        const int32_t s = (int32_t)((uint32_t)x + ((uint32_t)pred & use));
 #pragma unroll
-        for (int ii = 0; ii < CLX_LB; ++ii) y[ii] = (int32_t)((uint32_t)y[ii] << h.wasted);
-        if (any_decor) {
+        for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
+        S.hist[0] = s;
+        const int32_t v = clx_lfinish(s, h.wasted, decor, pair_ok, odd, any_decor);
+        if (i < n) row[i] = v;
+    }
+    // ---- steady state: blocks of 4 samples through the LDS ring, rolled back to careful steps when anything is unusual
+    if (i0 < nmax) clx_ring_reset(g, ringrow, r.pos >> 5);
+    bool wide = false;                                   // wave-uniform, sticky: i64 accumulate from now on
+    for (uint32_t t0 = i0; t0 < nmax; t0 += 4u) {
+        clx_ring_pump(g, ringrow, r.pos);
+        const bool live = (n != 0u) && !r.err && t0 < n;
+        const bool rice_on = live && S.phase == 1u;
+        const bool verb_on = live && S.phase == 0u;
+        bool can = true;
+        if (live) {
+            can = (t0 + 4u <= n) && S.phase != 3u;
+            if (S.phase != 2u) can = can && (r.pos + 4u * 40u <= r.limit) && clx_ring_covers(g, r.pos, 6u);
+            if (S.phase == 1u) can = can && S.transitioned;
+        }
+        if (S.lim < 0 && live && S.order != 0u) wide = true;
+        uint32_t pos2 = r.pos, pcnt2 = S.pcnt, k_2 = S.k, k1_2 = S.k1, parts2 = S.parts_left, next2 = S.next_cnt;
+        int32_t xs[4];
+        bool ok = can;
+        const bool any_verb = __any(verb_on);
+        if (__all(can)) {
 #pragma unroll
-            for (int ii = 0; ii < CLX_LB; ++ii) {
-                const int32_t mine = y[ii];
-                const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);   // lane ^ 1
-                const int32_t a = odd ? other : mine;
-                const int32_t bb = odd ? mine : other;
-                int32_t v = mine;
-                if (pair_ok) {
-                    if (decor == CLX_CH_LEFT_SIDE) { if (odd) v = (int32_t)((uint32_t)a - (uint32_t)bb); }
-                    else if (decor == CLX_CH_RIGHT_SIDE) { if (!odd) v = (int32_t)((uint32_t)a + (uint32_t)bb); }
-                    else {
-                        const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
-                        v = odd ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1) : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
+            for (int ii = 0; ii < 4; ++ii) {
+                if (__any(rice_on && pcnt2 == 0u)) {
+                    if (rice_on && pcnt2 == 0u) {                    // partition parameter (subframe.rs:314-319 / 362-367)
+                        const uint32_t pb = S.rice2 ? 5u : 4u;
+                        k_2 = clx_ring_peek32(ringrow, pos2) >> (32u - pb);
+                        if (k_2 == (S.rice2 ? 31u : 15u) || parts2 == 0u || next2 == 0u) ok = false;
+                        k1_2 = k_2 + 1u; pos2 += pb; parts2 -= 1u; pcnt2 = next2; next2 = S.per;
                     }
                 }
-                y[ii] = v;
+                const uint32_t v = clx_ring_peek32(ringrow, pos2);
+                const uint32_t z = (uint32_t)__clz((int)v);
+                const uint32_t nb = z + k1_2;
+                if (rice_on && (v == 0u || nb > 32u)) ok = false;
+                const uint32_t rem = (v >> ((32u - nb) & 31u)) & ((1u << (k_2 & 31u)) - 1u);
+                const uint32_t u = (z << (k_2 & 31u)) | rem;
+                int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                  // rice_to_signed (subframe.rs:157-170)
+                uint32_t adv = rice_on ? nb : 0u;
+                if (any_verb) {                                                      // verbatim rows ride along (subframe.rs:397-415)
+                    if (verb_on) { x = (int32_t)v >> ((32u - h.sf_bps) & 31u); adv = h.sf_bps; }
+                }
+                if (!rice_on && !verb_on) x = S.cval;
+                pos2 += adv;
+                if (rice_on) pcnt2 -= 1u;
+                xs[ii] = x;
             }
         }
-        if (ALIGNED) {
+        const bool all_ok = __all(ok);
+        int32_t y[4];
+        if (all_ok) {
+            if (live) { r.pos = pos2; S.pcnt = pcnt2; S.k = k_2; S.k1 = k1_2; S.parts_left = parts2; S.next_cnt = next2; }
+            // predictor over the block: 24-bit evaluation, range-checked; exact i64 re-run when outside the proven range
+            wide = __any(wide);
+            bool redo = wide;
+            int32_t h0[OMAX];
 #pragma unroll
-            for (int q = 0; q < CLX_LB / 4; ++q)
-                if (t0 + 4u * q < n) *reinterpret_cast<int4*>(row + t0 + 4 * q) = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+            for (int j = 0; j < OMAX; ++j) h0[j] = S.hist[j];
+            if (!wide) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int32_t pred = clx_lpredict<OMAX, false>(S.c, S.hist, S.shift);
+                    const int32_t s = (int32_t)((uint32_t)xs[ii] + (S.order != 0u ? (uint32_t)pred : 0u));
+#pragma unroll
+                    for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
+                    S.hist[0] = s;
+                    y[ii] = s;
+                }
+                int32_t mx = y[0] > y[1] ? y[0] : y[1], mn = y[0] < y[1] ? y[0] : y[1];
+                mx = y[2] > mx ? y[2] : mx; mx = y[3] > mx ? y[3] : mx;
+                mn = y[2] < mn ? y[2] : mn; mn = y[3] < mn ? y[3] : mn;
+                const bool in_range = !live || S.order == 0u || (mx < S.lim && mn >= -S.lim);
+                if (!__all(in_range)) { redo = true; wide = true; }
+            }
+            if (redo) {
+#pragma unroll
+                for (int j = 0; j < OMAX; ++j) S.hist[j] = h0[j];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int32_t pred = clx_lpredict<OMAX, true>(S.c, S.hist, S.shift);
+                    const int32_t s = (int32_t)((uint32_t)xs[ii] + (S.order != 0u ? (uint32_t)pred : 0u));
+#pragma unroll
+                    for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
+                    S.hist[0] = s;
+                    y[ii] = s;
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], h.wasted, decor, pair_ok, odd, any_decor);
+            if (live) {
+                if (row_aligned) *reinterpret_cast<int4*>(row + t0) = make_int4(y[0], y[1], y[2], y[3]);
+                else { row[t0] = y[0]; row[t0 + 1] = y[1]; row[t0 + 2] = y[2]; row[t0 + 3] = y[3]; }
+            }
         } else {
+#pragma unroll 1
+            for (uint32_t ii = 0; ii < 4u; ++ii) {
+                const uint32_t i = t0 + ii;
+                const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
+                const int32_t pred = clx_lpredict<OMAX, true>(S.c, S.hist, S.shift);
+                const uint32_t use = (S.order != 0u && i >= S.order && i >= S.trans_at) ? 0xffffffffu : 0u;
+                const int32_t s = (int32_t)((uint32_t)x + ((uint32_t)pred & use));
 #pragma unroll
-            for (int ii = 0; ii < CLX_LB; ++ii) if (t0 + (uint32_t)ii < n) row[t0 + ii] = y[ii];
+                for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
+                S.hist[0] = s;
+                const int32_t v = clx_lfinish(s, h.wasted, decor, pair_ok, odd, any_decor);
+                if (i < n) row[i] = v;
+            }
         }
     }
-    // subframes whose warm-up fills the whole block (order == block size) switch after the last sample
-    {
-        const bool late = (n != 0u) && !r.err && trans_at != 0xffffffffu && trans_at == n && !transitioned;
-        if (__any(late)) { if (late) transition(); }
+    // ---- a subframe whose warm-up fills the whole block switches after its last sample; trailing parameters of
+    //      empty partitions are consumed (they are part of the stream: they move the next subframe / the CRC)
+    if (n != 0u && !r.err && S.trans_at != 0xffffffffu && S.trans_at == n && !S.transitioned) clx_ltransition<OMAX>(S, h, bs);
+    if (n != 0u && !r.err && S.transitioned) {
+        while (!r.err && S.parts_left != 0u) { (void)clx_lread_rice_param(r, S.rice2); S.parts_left -= 1u; }
     }
-    *end_pos_out = r.pos;
+}
+
+template <int OMAX>
+__device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* ringrow, const SfHead h, uint32_t bs, uint32_t decor, bool pair_ok,
+                                              int32_t* __restrict__ row, bool row_aligned, uint32_t nmax, uint32_t omax, int lane,
+                                              uint32_t* end_pos, uint32_t* err_out) {
+    LaneState<OMAX> S;
+    S.r = r;
+#pragma unroll
+    for (int j = 0; j < OMAX; ++j) { S.c[j] = 0; S.hist[j] = 0; }
+    const uint32_t n = r.err ? 0u : bs;              // a lane that failed in its header produces nothing
+    S.phase = 3u; S.cval = 0; S.trans_at = 0xffffffffu; S.transitioned = false;
+    S.order = 0; S.shift = 0; S.lim = 0x7fffffff;
+    S.k = 0; S.k1 = 1; S.pcnt = 0; S.next_cnt = 0; S.per = 0; S.parts_left = 0; S.rice2 = 0;
+    if (n) {
+        if (h.kind == 0u) { S.cval = clx_lread_signed(S.r, h.sf_bps); S.phase = 2u; }              // decode_constant (subframe.rs:382-394)
+        else if (h.kind == 1u) S.phase = 0u;
+        else {
+            if (bs < h.order) S.r.err = CLX_LERR(CLX_FORMAT_ERROR, h.kind == 2u ? CLX_MSG_FIXED_ORDER_GT_BLOCK : CLX_MSG_LPC_ORDER_GT_BLOCK);
+            else { S.phase = 0u; S.trans_at = h.order; }
+        }
+    }
+    clx_lanes_body<OMAX>(S, g, ringrow, h, bs, n, decor, pair_ok, row, row_aligned, nmax, omax, lane);
+    *end_pos = S.r.pos;
+    *err_out = S.r.err;
 }
 
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_lanes(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames,
+void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
+                 const clx_dev_frame* __restrict__ frames,
                  const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
                  const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
                  uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits) {
+    __shared__ LanesLds L;
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
     uint32_t f = 0xffffffffu;
@@ -441,8 +647,8 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, const clx_dev_frame* __restr
 
     LaneReader r;
     r.arena = arena;
-    r.origin = (uint32_t)(fr.byte_off & ~3ull);
-    const uint32_t o = 8u * (uint32_t)(fr.byte_off & 3ull);
+    r.origin = (uint32_t)(fr.byte_off & ~15ull);
+    const uint32_t o = 8u * (uint32_t)(fr.byte_off & 15ull);
     r.limit = o + fr.limit_bits;
     r.pos = o + 8u * (uint32_t)fr.header_bytes;
     r.err = 0u;
@@ -454,6 +660,10 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, const clx_dev_frame* __restr
     }
     if (active && r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
     if (!active) { bs = 0; r.err = 1u; }                 // idle lane: produces nothing, reports nothing
+    Ring g;
+    g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
+    g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
+    g.fill = 0; g.has_pend = false; g.pend_at = 0; g.pend = make_uint4(0u, 0u, 0u, 0u);
 
     SfHead h = { 1u, 0u, 0u, 1u };
     if (active && !r.err) h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
@@ -472,23 +682,16 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, const clx_dev_frame* __restr
         uint32_t b = __shfl_xor(omax, s, 64); omax = b > omax ? b : omax;
     }
     int32_t* const row = out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
-    const bool al = !active || ((((uintptr_t)row) & 15u) == 0u && (bs & 3u) == 0u);
-    uint32_t end_pos = r.pos;
+    const bool row_aligned = (((uintptr_t)row) & 15u) == 0u;
+    uint32_t end_pos = r.pos, err = r.err;
     if (nmax != 0u) {
-        if (__all(al)) {
-            if (omax <= 4u)       clx_lanes_body<4, true>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-            else if (omax <= 8u)  clx_lanes_body<8, true>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-            else if (omax <= 12u) clx_lanes_body<12, true>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-            else                  clx_lanes_body<32, true>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-        } else {
-            if (omax <= 4u)       clx_lanes_body<4, false>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-            else if (omax <= 8u)  clx_lanes_body<8, false>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-            else if (omax <= 12u) clx_lanes_body<12, false>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-            else                  clx_lanes_body<32, false>(r, h, bs, decor, pair_ok, row, nmax, lane, &end_pos);
-        }
+        if (omax <= 4u)       clx_lanes_run<4>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        else if (omax <= 8u)  clx_lanes_run<8>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        else if (omax <= 12u) clx_lanes_run<12>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        else                  clx_lanes_run<32>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
     }
     if (active) {
-        if (r.err) clx_report_error(errkey, f, ch, r.err);
+        if (err) clx_report_error(errkey, f, ch, err);
         else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(end_pos - o);
     }
 }

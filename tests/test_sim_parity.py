@@ -71,3 +71,29 @@ def test_sim_detects_divergent_collectives():
                                os.path.join(d, "t.cpp")])
         r = subprocess.run([exe], capture_output=True)
         assert r.returncode != 0 and b"divergent" in r.stderr
+
+
+def test_sim_collectives_semantics():
+    """Lanes that leave the kernel AFTER taking part in a vote must still count in it (a bug here once made
+    the simulator disagree with the hardware); lanes that left before are neutral."""
+    import os, subprocess, tempfile, textwrap
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = textwrap.dedent("""
+        #include <hip/hip_runtime.h>
+        __global__ void k(int* out) { int lane = threadIdx.x;
+          if (lane >= 60) return;                       // early leavers are neutral
+          int a = __all(lane != 4);                     // lane 4 vetoes
+          int b = __any(lane == 61);                    // nobody left says yes
+          unsigned long long m = __ballot(lane & 1);
+          int c = __all(lane != 4);                     // still vetoed although early finishers exit while others read
+          int d = __shfl_xor(lane, 1, 64);
+          out[lane] = a * 8 + b * 4 + c * 2 + (m == 0x0aaaaaaaaaaaaaaaull) + 16 * d; }
+        int main() { static int out[64]; SIM_LAUNCH(k, 1, 64, out);
+          for (int i = 0; i < 60; i++) if (out[i] != 1 + 16 * (i ^ 1)) return 1; return 0; }
+    """)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(here, "wavesim", "fake"), "-o", exe,
+                               os.path.join(d, "t.cpp")])
+        assert subprocess.run([exe]).returncode == 0

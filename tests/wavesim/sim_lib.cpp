@@ -20,8 +20,8 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         std::vector<uint64_t> endbits(n ? n : 1, 0);
         const size_t n_multi = clx_plan_lanes(dev.data(), n, n_slots, slot_frame.data(), multi.data());
         if (n_slots_out) *n_slots_out = n_slots;
-        if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, arena, dev.data(), multi.data(), (uint32_t)n_multi, sf_start.data(), errkey.data());
-        SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, arena, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
+        if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, arena, alloc_len + 16, dev.data(), multi.data(), (uint32_t)n_multi, sf_start.data(), errkey.data());
+        SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
                    errkey.data(), endbits.data());
         SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, errkey.data(), endbits.data(), (uint32_t)n, results);
         if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);

@@ -135,13 +135,14 @@ template <typename T> inline uint64_t to_bits(T v) { uint64_t b = 0; memcpy(&b, 
 template <typename T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
 
 // all-to-all exchange inside a wave: returns a pointer to the 64 published values
-template <typename T> inline const uint64_t* exchange(T v, const void* site) {
+template <typename T> inline const uint64_t* exchange(T v, const void* site, uint64_t neutral = 0) {
     State& s = S();
     const int me = s.cur, w = me / 64;
     const unsigned par = s.wave_gen[w] & 1u;
     s.slot[par][me] = to_bits(v);
-    // lanes that already exited publish nothing: clear their slots once per generation (by the first arriver)
-    if (s.wave_arrived[w] == 0) for (int l = 0; l < 64; ++l) if (w * 64 + l >= s.nthreads || s.done[w * 64 + l]) s.slot[par][w * 64 + l] = 0;
+    // lanes that exited BEFORE this rendezvous publish the operation's neutral value (filled in once, by the first
+    // arriver); a lane that exits after taking part keeps what it published
+    if (s.wave_arrived[w] == 0) for (int l = 0; l < 64; ++l) if (w * 64 + l >= s.nthreads || s.done[w * 64 + l]) s.slot[par][w * 64 + l] = neutral;
     wave_rendezvous(site);
     return &s.slot[par][w * 64];
 }
@@ -190,11 +191,9 @@ static int any_(int line, int pred) {
     return 0;
 }
 static int all_(int line, int pred) {
-    // inactive (exited) lanes do not veto
-    const uint64_t* all = exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE(line));
-    State& s = S();
-    const int w = s.cur / 64;
-    for (int l = 0; l < 64; ++l) { const int t = w * 64 + l; if (t < s.nthreads && !s.done[t] && !all[l]) return 0; }
+    // inactive (exited) lanes do not veto: their neutral value is 1
+    const uint64_t* all = exchange<uint32_t>(pred ? 1u : 0u, WAVESIM_SITE(line), 1);
+    for (int l = 0; l < 64; ++l) if (!all[l]) return 0;
     return 1;
 }
 // DPP quad_perm (dpp_ctrl 0x00-0xFF), full row/bank masks: lane l reads lane (l & ~3) | perm[l & 3]
