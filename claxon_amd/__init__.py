@@ -81,14 +81,14 @@ EXPORTS = [
 
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_device.h", "clx_plan.h",
-                                            os.path.join("host", "claxon.hpp"))]
+    srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_lanes.hip", "clx_device.h", "clx_plan.h",
+                                            os.path.join("intrin", "clx_intrin.h"), os.path.join("host", "claxon.hpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "claxon_hip.h"))
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_CSRC, "intrin"),
            os.path.join(_CSRC, "clx_api.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

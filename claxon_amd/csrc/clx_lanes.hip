@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <clx_intrin.h>
+
 #include "../../include/claxon_hip.h"
 #include "clx_device.h"
 
@@ -154,11 +156,12 @@ __device__ __forceinline__ void clx_report_error(uint32_t* errkey, uint32_t fram
 // peek is one ds_read2_b32 + a funnel shift instead of a dependent global load (an L1 hit with 64
 // divergent lines costs >300 cycles; the code chain is serial in the bit position).  The ring is
 // filled split-phase with 16-byte loads: a granule requested at one block boundary is written to LDS
-// at the next, so HBM/L2 latency never sits on the decode chain.  Row stride CLX_RING+1: slot CLX_RING
-// mirrors slot 0, so a pair read never wraps.
+// at the next, so HBM/L2 latency never sits on the decode chain.  Slots CLX_RING..CLX_RING+4 mirror slots
+// 0..4, so reading six consecutive dwords (one block's 160-bit register window) never wraps.
 // ------------------------------------------------------------------------------------------------
 #define CLX_RING 32u
-struct LanesLds { uint32_t ring[64][CLX_RING + 1u]; };
+#define CLX_ROW (CLX_RING + 5u)
+struct LanesLds { uint32_t ring[64][CLX_ROW]; };
 
 struct Ring {
     const uint32_t* src;      // arena + origin (16-byte aligned)
@@ -178,7 +181,10 @@ __device__ __forceinline__ void clx_ring_put(uint32_t* row, uint32_t dw, const u
     const uint32_t s = dw & (CLX_RING - 1u);
     row[s] = __builtin_bswap32(v.x); row[s + 1u] = __builtin_bswap32(v.y);
     row[s + 2u] = __builtin_bswap32(v.z); row[s + 3u] = __builtin_bswap32(v.w);
-    if (s == 0u) row[CLX_RING] = __builtin_bswap32(v.x);
+    if (s == 0u) {
+        row[CLX_RING] = __builtin_bswap32(v.x); row[CLX_RING + 1u] = __builtin_bswap32(v.y);
+        row[CLX_RING + 2u] = __builtin_bswap32(v.z); row[CLX_RING + 3u] = __builtin_bswap32(v.w);
+    } else if (s == 4u) row[CLX_RING + 4u] = __builtin_bswap32(v.x);
 }
 // synchronous (re)fill starting at the granule that holds dword `dw` (start of a subframe, or after a jump)
 __device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t dw) {
@@ -207,6 +213,27 @@ __device__ __forceinline__ uint32_t clx_ring_peek32(const uint32_t* row, uint32_
     const uint32_t s = (pos >> 5) & (CLX_RING - 1u);
     const uint64_t w = ((uint64_t)row[s] << 32) | row[s + 1u];
     return (uint32_t)((w << (pos & 31u)) >> 32);
+}
+
+// 160-bit register window over the stream, `a` = the next 32 bits.  Loaded from the ring once per block of four
+// codes (three ds_read2_b32, one LDS round trip), then advanced with funnel shifts: no memory access per code.
+struct Win { uint32_t a, b, c, d, e; };
+__device__ __forceinline__ Win clx_win_load(const uint32_t* row, uint32_t pos) {
+    const uint32_t s = (pos >> 5) & (CLX_RING - 1u);
+    const uint32_t w0 = row[s], w1 = row[s + 1u], w2 = row[s + 2u], w3 = row[s + 3u], w4 = row[s + 4u], w5 = row[s + 5u];
+    const uint32_t off = pos & 31u;
+    const uint32_t sh = (32u - off) & 31u;
+    Win w;
+    w.a = off ? clx_alignbit(w0, w1, sh) : w0; w.b = off ? clx_alignbit(w1, w2, sh) : w1;
+    w.c = off ? clx_alignbit(w2, w3, sh) : w2; w.d = off ? clx_alignbit(w3, w4, sh) : w3;
+    w.e = off ? clx_alignbit(w4, w5, sh) : w4;
+    return w;
+}
+// drop nb (1..32) bits
+__device__ __forceinline__ void clx_win_skip(Win& w, uint32_t nb) {
+    const uint32_t sh = 32u - nb;                         // alignbit uses sh & 31: nb = 32 -> whole-register move
+    w.a = clx_alignbit(w.a, w.b, sh); w.b = clx_alignbit(w.b, w.c, sh); w.c = clx_alignbit(w.c, w.d, sh);
+    w.d = clx_alignbit(w.d, w.e, sh); w.e = clx_alignbit(w.e, 0u, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,20 +320,22 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
             uint32_t pos2 = r.pos, pcnt2 = pcnt, k_2 = k, k1_2 = k1, parts2 = parts_left, next2 = next_cnt;
             bool ok = can;
             if (__all(can)) {
+                Win w = clx_win_load(row, pos2);
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     if (__any(busy && pcnt2 == 0u)) {
-                        if (busy && pcnt2 == 0u) {              // partition parameter (subframe.rs:314-319 / 362-367)
+                        if (pcnt2 == 0u) {                      // partition parameter (subframe.rs:314-319 / 362-367)
                             const uint32_t pb = rice2 ? 5u : 4u;
-                            k_2 = clx_ring_peek32(row, pos2) >> (32u - pb);
+                            k_2 = w.a >> (32u - pb);
                             if (k_2 == (rice2 ? 31u : 15u) || parts2 == 0u || next2 == 0u) ok = false;
                             k1_2 = k_2 + 1u; pos2 += pb; parts2 -= 1u; pcnt2 = next2; next2 = per;
+                            clx_win_skip(w, pb);
                         }
                     }
-                    const uint32_t v = clx_ring_peek32(row, pos2);
-                    const uint32_t nb = (uint32_t)__clz((int)v) + k1_2;
-                    if (v == 0u || nb > 32u) ok = false;
-                    if (busy) { pos2 += nb; pcnt2 -= 1u; }
+                    const uint32_t nb = (uint32_t)__clz((int)w.a) + k1_2;      // 32 + k1 when the window is all zeros
+                    if (nb > 32u) ok = false;
+                    clx_win_skip(w, nb);
+                    pos2 += nb; pcnt2 -= 1u;
                 }
             }
             const bool all_ok = __all(ok);
@@ -506,30 +535,32 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
         bool ok = can;
         const bool any_verb = __any(verb_on);
         if (__all(can)) {
+            Win w = clx_win_load(ringrow, pos2);
+            const uint32_t vsh = (32u - h.sf_bps) & 31u;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 if (__any(rice_on && pcnt2 == 0u)) {
                     if (rice_on && pcnt2 == 0u) {                    // partition parameter (subframe.rs:314-319 / 362-367)
                         const uint32_t pb = S.rice2 ? 5u : 4u;
-                        k_2 = clx_ring_peek32(ringrow, pos2) >> (32u - pb);
+                        k_2 = w.a >> (32u - pb);
                         if (k_2 == (S.rice2 ? 31u : 15u) || parts2 == 0u || next2 == 0u) ok = false;
                         k1_2 = k_2 + 1u; pos2 += pb; parts2 -= 1u; pcnt2 = next2; next2 = S.per;
+                        clx_win_skip(w, pb);
                     }
                 }
-                const uint32_t v = clx_ring_peek32(ringrow, pos2);
-                const uint32_t z = (uint32_t)__clz((int)v);
-                const uint32_t nb = z + k1_2;
-                if (rice_on && (v == 0u || nb > 32u)) ok = false;
-                const uint32_t rem = (v >> ((32u - nb) & 31u)) & ((1u << (k_2 & 31u)) - 1u);
-                const uint32_t u = (z << (k_2 & 31u)) | rem;
-                int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                  // rice_to_signed (subframe.rs:157-170)
-                uint32_t adv = rice_on ? nb : 0u;
-                if (any_verb) {                                                      // verbatim rows ride along (subframe.rs:397-415)
-                    if (verb_on) { x = (int32_t)v >> ((32u - h.sf_bps) & 31u); adv = h.sf_bps; }
+                // one Rice code (subframe.rs:337-341): z zeros, a one, k remainder bits
+                const uint32_t z = (uint32_t)__clz((int)w.a);        // 32 when the window is all zeros
+                uint32_t nb = z + k1_2;
+                if (rice_on && nb > 32u) ok = false;
+                const uint32_t u = (z << (k_2 & 31u)) | clx_bfe(w.a, 32u - nb, k_2);
+                int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);  // rice_to_signed (subframe.rs:157-170)
+                if (any_verb) {                                      // verbatim rows ride along (subframe.rs:397-415)
+                    if (verb_on) { x = (int32_t)w.a >> vsh; nb = h.sf_bps; }
                 }
-                if (!rice_on && !verb_on) x = S.cval;
-                pos2 += adv;
-                if (rice_on) pcnt2 -= 1u;
+                if (!rice_on && !verb_on) { x = S.cval; nb = 32u; }  // constant / idle lanes: window contents are irrelevant
+                clx_win_skip(w, nb);
+                if (rice_on || verb_on) pos2 += nb;
+                pcnt2 -= 1u;
                 xs[ii] = x;
             }
         }

@@ -1,0 +1,14 @@
+// TEST INFRASTRUCTURE: host definitions of the instruction wrappers in claxon_amd/csrc/intrin/clx_intrin.h,
+// with the gfx950 instructions' documented semantics, for the wave simulator build.
+#ifndef CLX_INTRIN_H
+#define CLX_INTRIN_H
+#include <stdint.h>
+static inline uint32_t clx_alignbit(uint32_t hi, uint32_t lo, uint32_t shift) {
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (shift & 31u));
+}
+static inline uint32_t clx_bfe(uint32_t src, uint32_t offset, uint32_t width) {
+    offset &= 31u; width &= 31u;
+    if (width == 0u) return 0u;
+    return (src >> offset) & (width >= 32u ? 0xffffffffu : ((1u << width) - 1u));
+}
+#endif
