@@ -161,7 +161,10 @@ __device__ __forceinline__ void clx_report_error(uint32_t* errkey, uint32_t fram
 // ------------------------------------------------------------------------------------------------
 #define CLX_RING 32u
 #define CLX_ROW (CLX_RING + 5u)
-struct LanesLds { uint32_t ring[64][CLX_ROW]; };
+struct LanesLds {
+    uint32_t ring[64][CLX_ROW];
+    int4 stage[64][4];         // per lane: the last (up to) 16 output samples, flushed as one 64-byte segment
+};
 
 struct Ring {
     const uint32_t* src;      // arena + origin (16-byte aligned)
@@ -493,7 +496,7 @@ __device__ __forceinline__ int32_t clx_lfinish(int32_t s, uint32_t wasted, uint3
 }
 
 template <int OMAX>
-__device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint32_t* ringrow, const SfHead h, uint32_t bs, uint32_t n,
+__device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint32_t* ringrow, int4* stage, const SfHead h, uint32_t bs, uint32_t n,
                                                uint32_t decor, bool pair_ok, int32_t* __restrict__ row, bool row_aligned,
                                                uint32_t nmax, uint32_t omax, int lane) {
     LaneReader& r = S.r;
@@ -501,8 +504,8 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     const bool any_decor = __any(pair_ok);
 
     // ---- careful prologue: warm-up samples, the transition, the first residuals (rolled loop, one sample per turn)
-    uint32_t i0 = ((omax + 3u) & ~3u) + 4u;
-    if (i0 > nmax) i0 = (nmax + 3u) & ~3u;
+    uint32_t i0 = (omax + 4u + 15u) & ~15u;              // multiple of 16: output segments are flushed 64 bytes at a time
+    if (i0 > nmax) i0 = (nmax + 15u) & ~15u;
 #pragma unroll 1
     for (uint32_t i = 0; i < i0; ++i) {
         const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
@@ -605,11 +608,8 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
             }
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], h.wasted, decor, pair_ok, odd, any_decor);
-            if (live) {
-                if (row_aligned) *reinterpret_cast<int4*>(row + t0) = make_int4(y[0], y[1], y[2], y[3]);
-                else { row[t0] = y[0]; row[t0 + 1] = y[1]; row[t0 + 2] = y[2]; row[t0 + 3] = y[3]; }
-            }
         } else {
+            int32_t* const ys = reinterpret_cast<int32_t*>(&stage[(t0 >> 2) & 3u]);
 #pragma unroll 1
             for (uint32_t ii = 0; ii < 4u; ++ii) {
                 const uint32_t i = t0 + ii;
@@ -620,8 +620,29 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
 #pragma unroll
                 for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
                 S.hist[0] = s;
-                const int32_t v = clx_lfinish(s, h.wasted, decor, pair_ok, odd, any_decor);
-                if (i < n) row[i] = v;
+                ys[ii] = clx_lfinish(s, h.wasted, decor, pair_ok, odd, any_decor);
+            }
+            const int4 yv = stage[(t0 >> 2) & 3u];
+            y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
+        }
+        // ---- output: stage 16 bytes per block, write the row one full 64-byte segment at a time (scattered 16-byte
+        //      stores issued microseconds apart reach HBM as partial-line writes: 2.8x write traffic when measured)
+        stage[(t0 >> 2) & 3u] = make_int4(y[0], y[1], y[2], y[3]);
+        if ((t0 & 12u) == 12u || t0 + 4u >= nmax) {
+            const uint32_t base = t0 & ~15u;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) {
+                const uint32_t idx = base + 4u * q;
+                if (idx <= t0) {
+                    const int4 v = stage[q];
+                    if (row_aligned && idx + 4u <= n) *reinterpret_cast<int4*>(row + idx) = v;
+                    else {
+                        if (idx < n) row[idx] = v.x;
+                        if (idx + 1u < n) row[idx + 1u] = v.y;
+                        if (idx + 2u < n) row[idx + 2u] = v.z;
+                        if (idx + 3u < n) row[idx + 3u] = v.w;
+                    }
+                }
             }
         }
     }
@@ -634,7 +655,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
 }
 
 template <int OMAX>
-__device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* ringrow, const SfHead h, uint32_t bs, uint32_t decor, bool pair_ok,
+__device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* ringrow, int4* stage, const SfHead h, uint32_t bs, uint32_t decor, bool pair_ok,
                                               int32_t* __restrict__ row, bool row_aligned, uint32_t nmax, uint32_t omax, int lane,
                                               uint32_t* end_pos, uint32_t* err_out) {
     LaneState<OMAX> S;
@@ -653,7 +674,7 @@ __device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* r
             else { S.phase = 0u; S.trans_at = h.order; }
         }
     }
-    clx_lanes_body<OMAX>(S, g, ringrow, h, bs, n, decor, pair_ok, row, row_aligned, nmax, omax, lane);
+    clx_lanes_body<OMAX>(S, g, ringrow, stage, h, bs, n, decor, pair_ok, row, row_aligned, nmax, omax, lane);
     *end_pos = S.r.pos;
     *err_out = S.r.err;
 }
@@ -716,10 +737,10 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     const bool row_aligned = (((uintptr_t)row) & 15u) == 0u;
     uint32_t end_pos = r.pos, err = r.err;
     if (nmax != 0u) {
-        if (omax <= 4u)       clx_lanes_run<4>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
-        else if (omax <= 8u)  clx_lanes_run<8>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
-        else if (omax <= 12u) clx_lanes_run<12>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
-        else                  clx_lanes_run<32>(r, g, L.ring[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        if (omax <= 4u)       clx_lanes_run<4>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        else if (omax <= 8u)  clx_lanes_run<8>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        else if (omax <= 12u) clx_lanes_run<12>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        else                  clx_lanes_run<32>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
     }
     if (active) {
         if (err) clx_report_error(errkey, f, ch, err);
