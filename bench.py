@@ -35,12 +35,14 @@ def main():
     import torch
     import claxon_amd as cx
     import synth
+    dist = None
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        import torch.distributed as dist
+        import torch.distributed as dist_mod
+        dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
@@ -84,12 +86,14 @@ def main():
         step()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # whole-job figures: MAX elapsed over ranks, SUM of samples per step, SUM of failed frames (must be 0)
+    from claxon_amd import shard
+    res = batch.results()
+    elapsed, samples_per_step_all, n_bad = shard.reduce_job(dist if world > 1 else None, elapsed, w.total_samples,
+                                                            int((res["status"] != 0).sum()), device=dev)
+    if n_bad:
+        raise SystemExit("bench: %d frames failed to decode in the timed region" % n_bad)
     ms_per_step = 1e3 * elapsed / args.steps
-    samples_per_step_all = w.total_samples * world
     value = samples_per_step_all / (ms_per_step * 1e-3) / 1e6
 
     # ---- per-kernel durations (HIP events recorded by the library on the launch stream)
