@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <clx_intrin.h>
+
 #include "../../include/claxon_hip.h"
 #include "clx_device.h"
 
@@ -472,7 +474,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 // ------------------------------------------------------------------------------------------------
 #define CLX_BLK 16
 
-template <int OMAX, bool WIDE>
+template <int OMAX, bool WIDE, bool MASKED>
 __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32_t (&y)[CLX_BLK], int32_t (&hist)[OMAX],
                                               const int32_t (&c)[OMAX], uint32_t t0, uint32_t order, uint32_t shift) {
 #pragma unroll
@@ -486,12 +488,14 @@ __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32
         } else {
             int32_t acc = 0;
 #pragma unroll
-            for (int j = OMAX - 1; j >= 0; --j) acc = __mul24(c[j], hist[j]) + acc;        // v_mad_i32_i24
+            for (int j = OMAX - 1; j >= 0; --j) acc = clx_mad24(c[j], hist[j], acc);       // v_mad_i32_i24 chain, newest tap last
             pred = acc >> shift;
         }
-        // warm-up samples (i < order) pass through; branch-free so the block stays one straight line of code
-        const uint32_t use = (t0 + (uint32_t)i >= order) ? 0xffffffffu : 0u;
-        const int32_t s = (int32_t)((uint32_t)x[i] + ((uint32_t)pred & use));
+        int32_t s;
+        if (MASKED) {   // warm-up samples (i < order) pass through; branch-free so the block stays one straight line of code
+            const uint32_t use = (t0 + (uint32_t)i >= order) ? 0xffffffffu : 0u;
+            s = (int32_t)((uint32_t)x[i] + ((uint32_t)pred & use));
+        } else s = (int32_t)((uint32_t)x[i] + (uint32_t)pred);
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
         hist[0] = s;
@@ -539,6 +543,9 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, cons
     int32_t* const row = out + (n != 0u ? mydesc->out_base : 0ull);       // empty slots read (never write) out[0..3]
     const bool odd = (lane & 1) != 0;
     const bool any_decor = __any(decor != CLX_CH_INDEPENDENT && pair_ok);
+    const bool all_ms = __all(pair_ok && decor == CLX_CH_MID_SIDE);    // the common case gets a shorter instruction sequence
+    const bool any_wasted = __any(wasted != 0u);
+    const uint32_t sgn = odd ? 0xffffffffu : 0u;                       // (x ^ sgn) - sgn = odd ? -x : x
     // |s| <= lim proves the i32/i24 evaluation exact; lanes K1 could not prove (lim_log2 = 0xff) force the wide path
     // (range is [-lim, lim-1]: the 24-bit signed factor range when lim = 2^23)
     const int32_t lim = (lim_log2 <= 23u) ? (int32_t)(1u << lim_log2) : -1;
@@ -554,10 +561,12 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, cons
             int32_t h0[OMAX];
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) h0[j] = hist[j];
-            clx_iir_block<OMAX, false>(cur, y, hist, c, t0, order, shift);
+            if (t0 < (uint32_t)OMAX) clx_iir_block<OMAX, false, true>(cur, y, hist, c, t0, order, shift);
+            else                     clx_iir_block<OMAX, false, false>(cur, y, hist, c, t0, order, shift);      // every lane is past its warm-up
             int32_t mx = y[0], mn = y[0];
 #pragma unroll
-            for (int i = 1; i < CLX_BLK; ++i) { mx = y[i] > mx ? y[i] : mx; mn = y[i] < mn ? y[i] : mn; }
+            for (int i = 1; i + 1 < CLX_BLK; i += 2) { mx = clx_max3(mx, y[i], y[i + 1]); mn = clx_min3(mn, y[i], y[i + 1]); }
+            mx = y[CLX_BLK - 1] > mx ? y[CLX_BLK - 1] : mx; mn = y[CLX_BLK - 1] < mn ? y[CLX_BLK - 1] : mn;
             const bool in_range = trivial || t0 >= n || (mx < lim && mn >= -lim);
             if (__all(in_range)) done = true;
             else {
@@ -566,16 +575,28 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, cons
             }
         }
         if (!done) {
-            clx_iir_block<OMAX, true>(cur, y, hist, c, t0, order, shift);
+            clx_iir_block<OMAX, true, true>(cur, y, hist, c, t0, order, shift);
             bool ok = lim >= 0;
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) ok = ok && hist[j] < lim && hist[j] >= -lim;
             h_ok = ok || trivial || t0 + CLX_BLK >= n;
         }
         // wasted-bits shift (subframe.rs:216-225) and stereo decorrelation (frame.rs:319-389) on the finished block
+        if (any_wasted) {
 #pragma unroll
-        for (int i = 0; i < CLX_BLK; ++i) y[i] = (int32_t)((uint32_t)y[i] << wasted);
-        if (any_decor) {
+            for (int i = 0; i < CLX_BLK; ++i) y[i] = (int32_t)((uint32_t)y[i] << wasted);
+        }
+        if (all_ms) {
+            // every lane belongs to a mid/side pair: two DPP broadcasts give (mid, side) to both lanes of the pair
+#pragma unroll
+            for (int i = 0; i < CLX_BLK; ++i) {
+                const int32_t mid = __builtin_amdgcn_update_dpp(0, y[i], 0xA0, 0xF, 0xF, false);     // quad_perm [0,0,2,2]
+                const int32_t side = __builtin_amdgcn_update_dpp(0, y[i], 0xF5, 0xF, 0xF, false);    // quad_perm [1,1,3,3]
+                const uint32_t m = ((uint32_t)mid << 1) | ((uint32_t)side & 1u);
+                // left = (m + side) >> 1, right = (m - side) >> 1 (frame.rs:382-384; m +- side is even)
+                y[i] = (int32_t)(m + (((uint32_t)side ^ sgn) - sgn)) >> 1;
+            }
+        } else if (any_decor) {
 #pragma unroll
             for (int i = 0; i < CLX_BLK; ++i) {
                 const int32_t mine = y[i];

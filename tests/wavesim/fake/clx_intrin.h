@@ -11,4 +11,9 @@ static inline uint32_t clx_bfe(uint32_t src, uint32_t offset, uint32_t width) {
     if (width == 0u) return 0u;
     return (src >> offset) & (width >= 32u ? 0xffffffffu : ((1u << width) - 1u));
 }
+static inline int32_t clx_mad24(int32_t a, int32_t b, int32_t c) {
+    return (int32_t)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8) + (uint32_t)c);
+}
+static inline int32_t clx_max3(int32_t a, int32_t b, int32_t c) { int32_t m = a > b ? a : b; return m > c ? m : c; }
+static inline int32_t clx_min3(int32_t a, int32_t b, int32_t c) { int32_t m = a < b ? a : b; return m < c ? m : c; }
 #endif
