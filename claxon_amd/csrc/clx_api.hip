@@ -217,6 +217,7 @@ struct clx_batch {
     clx_dev_frame* d_frames = nullptr;
     clx_sf_desc* d_sfd = nullptr;
     clx_frame_result* d_results = nullptr;
+    int32_t* d_dump = nullptr;       // wave path: 64 bytes per predictor lane for out-of-row stores
     // lane path
     bool lanes = false;
     uint32_t* d_slot_frame = nullptr;
@@ -277,6 +278,7 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_frames) (void)hipFree(b->d_frames);
     if (b->d_sfd) (void)hipFree(b->d_sfd);
     if (b->d_results) (void)hipFree(b->d_results);
+    if (b->d_dump) (void)hipFree(b->d_dump);
     if (b->d_slot_frame) (void)hipFree(b->d_slot_frame);
     if (b->d_multi) (void)hipFree(b->d_multi);
     if (b->d_sf_start) (void)hipFree(b->d_sf_start);
@@ -317,6 +319,10 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     // are faster.  Measured crossover on MI355X: 20k subframes 1.80 ms (waves) vs 2.34 ms (lanes); 80k subframes
     // 4.71 ms vs 3.47 ms.
     b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 40000);
+    if (!b->lanes) {
+        const size_t lanes64 = ((ns + 63) / 64) * 64;
+        if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
+    }
     if (b->lanes) {
         std::vector<uint32_t> slot_frame(ns), multi(nf);
         b->n_multi = clx_plan_lanes(b->h_frames.data(), n, slot, slot_frame.data(), multi.data());
@@ -394,7 +400,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
                            d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
         if (!mark("clx_k_predict")) return CLX_API_ERROR;
         hipLaunchKernelGGL(clx_k_predict, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_out,
-                           (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots);
+                           (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
     }
     if (b->flags & CLX_VERIFY_CRC16) {
         if (!mark("clx_k_crc16")) return CLX_API_ERROR;

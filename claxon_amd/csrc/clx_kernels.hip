@@ -521,20 +521,26 @@ __device__ __forceinline__ void clx_row_load(const int32_t* __restrict__ row, ui
         for (int i = 0; i < CLX_BLK; ++i) { const uint32_t idx = t + (uint32_t)i < last ? t + (uint32_t)i : last; v[i] = row[idx]; }
     }
 }
+// Unconditional stores: samples past the row's end go to a per-lane dump area instead of being branched around
+// (any branch around a memory operation makes the compiler fall back to s_waitcnt vmcnt(0), which ties every use
+// of prefetched data to the completion of all older stores).
 template <bool ALIGNED>
-__device__ __forceinline__ void clx_row_store(int32_t* __restrict__ row, uint32_t t, uint32_t n, const int32_t (&v)[CLX_BLK]) {
+__device__ __forceinline__ void clx_row_store(int32_t* __restrict__ row, int32_t* __restrict__ dump, uint32_t t, uint32_t n,
+                                              const int32_t (&v)[CLX_BLK]) {
     if (ALIGNED) {
 #pragma unroll
-        for (int q = 0; q < CLX_BLK / 4; ++q)
-            if (t + 4u * q < n) *reinterpret_cast<int4*>(row + t + 4 * q) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int q = 0; q < CLX_BLK / 4; ++q) {
+            int32_t* p = (t + 4u * q < n) ? row + t + 4 * q : dump + 4 * q;
+            *reinterpret_cast<int4*>(p) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < CLX_BLK; ++i) if (t + (uint32_t)i < n) row[t + i] = v[i];
+        for (int i = 0; i < CLX_BLK; ++i) { int32_t* p = (t + (uint32_t)i < n) ? row + t + i : dump + i; *p = v[i]; }
     }
 }
 
 template <int OMAX, bool ALIGNED>
-__device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ mydesc,
+__device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, int32_t* __restrict__ dump, const clx_sf_desc* __restrict__ mydesc,
                                                  uint32_t n, uint32_t order, uint32_t shift, uint32_t wasted,
                                                  uint32_t decor, bool pair_ok, uint32_t lim_log2, uint32_t nmax, int lane) {
     int32_t c[OMAX], hist[OMAX];
@@ -552,10 +558,14 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, cons
     const bool trivial = (n == 0u) || (order == 0u);          // nothing is predicted: any evaluation is exact
     bool h_ok = (lim >= 0) || trivial;
 
-    int32_t cur[CLX_BLK], nxt[CLX_BLK], y[CLX_BLK];
-    clx_row_load<ALIGNED>(row, 0u, n, cur);
-    for (uint32_t t0 = 0; t0 < nmax; t0 += CLX_BLK) {
-        if (t0 + CLX_BLK < nmax) clx_row_load<ALIGNED>(row, t0 + CLX_BLK, n, nxt);
+    // Three row buffers rotate through a loop unrolled by three: the block computed in turn t was requested in turn
+    // t-2, so a scattered 16-byte-per-lane load has two blocks of compute to come back.  The trip count is padded to
+    // a multiple of three blocks (loads are clamped, stores of padding go to `dump`), so the loop body is branch-free
+    // around its memory operations and the compiler keeps counted s_waitcnt vmcnt(N).
+    int32_t bufA[CLX_BLK], bufB[CLX_BLK], bufC[CLX_BLK], y[CLX_BLK];
+    clx_row_load<ALIGNED>(row, 0u, n, bufA);
+    clx_row_load<ALIGNED>(row, CLX_BLK, n, bufB);
+    auto block = [&](const int32_t (&cur)[CLX_BLK], uint32_t t0) {
         bool done = false;
         if (__all(h_ok)) {
             int32_t h0[OMAX];
@@ -616,14 +626,20 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, cons
                 y[i] = v;
             }
         }
-        clx_row_store<ALIGNED>(row, t0, n, y);
-#pragma unroll
-        for (int i = 0; i < CLX_BLK; ++i) cur[i] = nxt[i];
+        clx_row_store<ALIGNED>(row, dump, t0, n, y);
+    };
+    for (uint32_t t0 = 0; t0 < nmax; t0 += 3u * CLX_BLK) {
+        clx_row_load<ALIGNED>(row, t0 + 2u * CLX_BLK, n, bufC);
+        block(bufA, t0);
+        clx_row_load<ALIGNED>(row, t0 + 3u * CLX_BLK, n, bufA);
+        block(bufB, t0 + CLX_BLK);
+        clx_row_load<ALIGNED>(row, t0 + 4u * CLX_BLK, n, bufB);
+        block(bufC, t0 + 2u * CLX_BLK);
     }
 }
 
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots) {
+void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
     uint32_t n = 0, order = 0, shift = 0, wasted = 0, decor = 0, lim_log2 = 0;
@@ -644,21 +660,22 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
         uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
         uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
     }
+    int32_t* const dump = dump_all + (size_t)(blockIdx.x * 64u + (uint32_t)lane) * CLX_BLK;      // 64 bytes per lane
     const bool work = (order != 0u) || (wasted != 0u) || pair_ok;
     // a wave of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits is already final
     if (nmax == 0u || !__any(work)) return;
     // 16-byte row accesses need 16-byte aligned rows whose length is a multiple of 4 samples
     const bool al = (n == 0u) || ((((uintptr_t)(out + base)) & 15u) == 0u && (n & 3u) == 0u);
     if (__all(al)) {
-        if (omax <= 4u)       clx_predict_rows<4, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, true>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        if (omax <= 4u)       clx_predict_rows<4, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
     } else {
-        if (omax <= 4u)       clx_predict_rows<4, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, false>(out, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        if (omax <= 4u)       clx_predict_rows<4, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
     }
 }
 
