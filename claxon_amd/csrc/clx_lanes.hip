@@ -170,9 +170,9 @@ struct Ring {
     const uint32_t* src;      // arena + origin (16-byte aligned)
     uint32_t avail_dw;        // dwords readable from src
     uint32_t fill;            // stream dwords [fill-CLX_RING, fill) are in the ring; multiple of 4
-    uint32_t pend_at;
-    uint4 pend;
-    bool has_pend;
+    uint32_t npend;           // granules requested at the last pump (0..2), stored in pend0 / pend1
+    uint4 pend0, pend1;
+    uint32_t fast_lim;        // a fast block may start at any bit position <= fast_lim (ring coverage and EOF margin)
 };
 
 __device__ __forceinline__ uint4 clx_ring_fetch(const Ring& g, uint32_t dw) {
@@ -189,8 +189,15 @@ __device__ __forceinline__ void clx_ring_put(uint32_t* row, uint32_t dw, const u
         row[CLX_RING + 2u] = __builtin_bswap32(v.z); row[CLX_RING + 3u] = __builtin_bswap32(v.w);
     } else if (s == 4u) row[CLX_RING + 4u] = __builtin_bswap32(v.x);
 }
+// A fast block (4 codes, <= 32 bits each, + partition parameters) reads at most 160+ bits: it may start at `pos` when
+// the ring holds 8 more dwords and the readable stream 160 more bits.
+__device__ __forceinline__ void clx_ring_set_lim(Ring& g, uint32_t limit) {
+    const uint32_t by_ring = g.fill >= 8u ? 32u * (g.fill - 8u) : 0u;
+    const uint32_t by_eof = limit >= 160u ? limit - 160u : 0u;
+    g.fast_lim = by_ring < by_eof ? by_ring : by_eof;
+}
 // synchronous (re)fill starting at the granule that holds dword `dw` (start of a subframe, or after a jump)
-__device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t dw) {
+__device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t dw, uint32_t limit) {
     const uint32_t f0 = dw & ~3u;
     uint4 t[CLX_RING / 4u];
 #pragma unroll
@@ -198,19 +205,22 @@ __device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t 
 #pragma unroll
     for (uint32_t q = 0; q < CLX_RING / 4u; ++q) clx_ring_put(row, f0 + 4u * q, t[q]);
     g.fill = f0 + CLX_RING;
-    g.has_pend = false;
+    g.npend = 0;
+    clx_ring_set_lim(g, limit);
 }
-// once per block: land the granule requested last time, request the next one when the lookahead runs low
-__device__ __forceinline__ void clx_ring_pump(Ring& g, uint32_t* row, uint32_t pos) {
+// every 4th block: land the granules requested last time, request new ones while the ring has room
+__device__ __forceinline__ void clx_ring_pump(Ring& g, uint32_t* row, uint32_t pos, uint32_t limit) {
     const uint32_t dw = pos >> 5;
-    if (g.has_pend) { clx_ring_put(row, g.pend_at, g.pend); g.fill = g.pend_at + 4u; g.has_pend = false; }
-    if (dw + 2u > g.fill || dw + CLX_RING < g.fill) clx_ring_reset(g, row, dw);        // the position jumped (long run / careful steps)
-    else if (g.fill - dw <= CLX_RING - 12u) { g.pend_at = g.fill; g.pend = clx_ring_fetch(g, g.fill); g.has_pend = true; }
-}
-// a lane may run a fast block only if the ring covers the next `ahead` dwords
-__device__ __forceinline__ bool clx_ring_covers(const Ring& g, uint32_t pos, uint32_t ahead) {
-    const uint32_t dw = pos >> 5;
-    return dw + CLX_RING >= g.fill && dw + ahead + 2u <= g.fill;
+    if (g.npend >= 1u) { clx_ring_put(row, g.fill, g.pend0); g.fill += 4u; }
+    if (g.npend >= 2u) { clx_ring_put(row, g.fill, g.pend1); g.fill += 4u; }
+    g.npend = 0;
+    if (dw + 8u > g.fill || dw + CLX_RING < g.fill) clx_ring_reset(g, row, dw, limit);       // ran dry, or the position jumped
+    else {
+        const uint32_t room = CLX_RING - (g.fill - dw);                                     // dwords that may be overwritten
+        if (room >= 4u) { g.pend0 = clx_ring_fetch(g, g.fill); g.npend = 1u; }
+        if (room >= 8u) { g.pend1 = clx_ring_fetch(g, g.fill + 4u); g.npend = 2u; }
+        clx_ring_set_lim(g, limit);
+    }
 }
 __device__ __forceinline__ uint32_t clx_ring_peek32(const uint32_t* row, uint32_t pos) {
     const uint32_t s = (pos >> 5) & (CLX_RING - 1u);
@@ -267,7 +277,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     Ring g;
     g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
     g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-    g.fill = 0; g.has_pend = false; g.pend_at = 0; g.pend = make_uint4(0u, 0u, 0u, 0u);
+    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0;
     const uint32_t bs = fr.block_size;
     uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
     uint32_t nch_max = nch;
@@ -314,15 +324,15 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         uint32_t lmax = left;
 #pragma unroll
         for (int sx = 32; sx >= 1; sx >>= 1) { const uint32_t a = __shfl_xor(lmax, sx, 64); lmax = a > lmax ? a : lmax; }
-        if (lmax != 0u) clx_ring_reset(g, row, r.pos >> 5);
+        if (lmax != 0u) clx_ring_reset(g, row, r.pos >> 5, r.limit);
         for (uint32_t i0 = 0; i0 < lmax; i0 += 4u) {
-            clx_ring_pump(g, row, r.pos);
-            // fast block: 4 codes through the ring, no EOF possible, every code <= 32 bits
-            const bool busy = left >= 4u && !r.err;
-            const bool can = !busy || (r.pos + 4u * 40u <= r.limit && clx_ring_covers(g, r.pos, 6u));
+            if ((i0 & 12u) == 0u && i0 != 0u) clx_ring_pump(g, row, r.pos, r.limit);
+            // fast block: 4 codes from a register window, no EOF possible, every code <= 32 bits; committed only if
+            // every lane stayed on the common path
+            const bool busy = left >= 4u;
             uint32_t pos2 = r.pos, pcnt2 = pcnt, k_2 = k, k1_2 = k1, parts2 = parts_left, next2 = next_cnt;
-            bool ok = can;
-            if (__all(can)) {
+            bool ok = !busy || r.pos <= g.fast_lim;
+            {
                 Win w = clx_win_load(row, pos2);
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
@@ -341,7 +351,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                     pos2 += nb; pcnt2 -= 1u;
                 }
             }
-            const bool all_ok = __all(ok);
+            const bool all_ok = __all(ok || !busy);
             if (all_ok && busy) { r.pos = pos2; pcnt = pcnt2; k = k_2; k1 = k1_2; parts_left = parts2; next_cnt = next2; left -= 4u; }
             const bool tail = !r.err && left != 0u && left < 4u;
             if (!all_ok || __any(tail)) {
@@ -519,17 +529,17 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
         if (i < n) row[i] = v;
     }
     // ---- steady state: blocks of 4 samples through the LDS ring, rolled back to careful steps when anything is unusual
-    if (i0 < nmax) clx_ring_reset(g, ringrow, r.pos >> 5);
+    if (i0 < nmax) clx_ring_reset(g, ringrow, r.pos >> 5, r.limit);
     bool wide = false;                                   // wave-uniform, sticky: i64 accumulate from now on
     for (uint32_t t0 = i0; t0 < nmax; t0 += 4u) {
-        clx_ring_pump(g, ringrow, r.pos);
+        if ((t0 & 12u) == 0u && t0 != i0) clx_ring_pump(g, ringrow, r.pos, r.limit);
         const bool live = (n != 0u) && !r.err && t0 < n;
         const bool rice_on = live && S.phase == 1u;
         const bool verb_on = live && S.phase == 0u;
         bool can = true;
         if (live) {
             can = (t0 + 4u <= n) && S.phase != 3u;
-            if (S.phase != 2u) can = can && (r.pos + 4u * 40u <= r.limit) && clx_ring_covers(g, r.pos, 6u);
+            if (S.phase != 2u) can = can && r.pos <= g.fast_lim;
             if (S.phase == 1u) can = can && S.transitioned;
         }
         if (S.lim < 0 && live && S.order != 0u) wide = true;
@@ -537,7 +547,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
         int32_t xs[4];
         bool ok = can;
         const bool any_verb = __any(verb_on);
-        if (__all(can)) {
+        {
             Win w = clx_win_load(ringrow, pos2);
             const uint32_t vsh = (32u - h.sf_bps) & 31u;
 #pragma unroll
@@ -715,7 +725,7 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     Ring g;
     g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
     g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-    g.fill = 0; g.has_pend = false; g.pend_at = 0; g.pend = make_uint4(0u, 0u, 0u, 0u);
+    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0;
 
     SfHead h = { 1u, 0u, 0u, 1u };
     if (active && !r.err) h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
