@@ -412,7 +412,7 @@ __device__ __forceinline__ int32_t clx_lpredict(const int32_t (&c)[OMAX], const 
     } else {
         int32_t acc = 0;
 #pragma unroll
-        for (int j = OMAX - 1; j >= 0; --j) acc = __mul24(c[j], hist[j]) + acc;
+        for (int j = OMAX - 1; j >= 0; --j) acc = clx_mad24(c[j], hist[j], acc);      // v_mad_i32_i24 chain, newest tap last
         return acc >> shift;
     }
 }
@@ -486,19 +486,31 @@ __device__ __forceinline__ int32_t clx_lcareful_raw(LaneState<OMAX>& S, const Sf
 }
 
 // wasted-bits shift (subframe.rs:216-225) + stereo decorrelation (frame.rs:319-389) of one sample; wave-uniform call
-__device__ __forceinline__ int32_t clx_lfinish(int32_t s, uint32_t wasted, uint32_t decor, bool pair_ok, bool odd, bool any_decor) {
-    int32_t mine = (int32_t)((uint32_t)s << wasted);
-    if (any_decor) {
+struct Finish {
+    uint32_t wasted, decor, sgn;      // sgn: all ones in odd lanes ((x ^ sgn) - sgn = odd ? -x : x)
+    bool pair_ok, odd, any_decor, all_ms, any_wasted;
+};
+__device__ __forceinline__ int32_t clx_lfinish(int32_t s, const Finish& F) {
+    int32_t mine = F.any_wasted ? (int32_t)((uint32_t)s << F.wasted) : s;
+    if (F.all_ms) {
+        // every lane belongs to a mid/side pair: two DPP broadcasts give (mid, side) to both lanes of the pair
+        const int32_t mid = __builtin_amdgcn_update_dpp(0, mine, 0xA0, 0xF, 0xF, false);      // quad_perm [0,0,2,2]
+        const int32_t side = __builtin_amdgcn_update_dpp(0, mine, 0xF5, 0xF, 0xF, false);     // quad_perm [1,1,3,3]
+        const uint32_t m = ((uint32_t)mid << 1) | ((uint32_t)side & 1u);
+        // left = (m + side) >> 1, right = (m - side) >> 1 (frame.rs:382-384; m +- side is even)
+        return (int32_t)(m + (((uint32_t)side ^ F.sgn) - F.sgn)) >> 1;
+    }
+    if (F.any_decor) {
         const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);       // lane ^ 1
-        const int32_t a = odd ? other : mine;                   // channel 0 as coded
-        const int32_t bb = odd ? mine : other;                  // channel 1 as coded
-        if (pair_ok) {
-            if (decor == CLX_CH_LEFT_SIDE) { if (odd) mine = (int32_t)((uint32_t)a - (uint32_t)bb); }
-            else if (decor == CLX_CH_RIGHT_SIDE) { if (!odd) mine = (int32_t)((uint32_t)a + (uint32_t)bb); }
+        const int32_t a = F.odd ? other : mine;                 // channel 0 as coded
+        const int32_t bb = F.odd ? mine : other;                // channel 1 as coded
+        if (F.pair_ok) {
+            if (F.decor == CLX_CH_LEFT_SIDE) { if (F.odd) mine = (int32_t)((uint32_t)a - (uint32_t)bb); }
+            else if (F.decor == CLX_CH_RIGHT_SIDE) { if (!F.odd) mine = (int32_t)((uint32_t)a + (uint32_t)bb); }
             else {
                 const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
                 // m +- side is even, so Rust's truncating `/ 2` equals an arithmetic shift
-                mine = odd ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1) : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
+                mine = F.odd ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1) : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
             }
         }
     }
@@ -510,8 +522,12 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                                                uint32_t decor, bool pair_ok, int32_t* __restrict__ row, bool row_aligned,
                                                uint32_t nmax, uint32_t omax, int lane) {
     LaneReader& r = S.r;
-    const bool odd = (lane & 1) != 0;
-    const bool any_decor = __any(pair_ok);
+    Finish F;
+    F.wasted = h.wasted; F.decor = decor; F.pair_ok = pair_ok; F.odd = (lane & 1) != 0;
+    F.sgn = F.odd ? 0xffffffffu : 0u;
+    F.any_decor = __any(pair_ok);
+    F.all_ms = __all(pair_ok && decor == CLX_CH_MID_SIDE);
+    F.any_wasted = __any(n != 0u && h.wasted != 0u);
 
     // ---- careful prologue: warm-up samples, the transition, the first residuals (rolled loop, one sample per turn)
     uint32_t i0 = (omax + 4u + 15u) & ~15u;              // multiple of 16: output segments are flushed 64 bytes at a time
@@ -525,7 +541,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
-        const int32_t v = clx_lfinish(s, h.wasted, decor, pair_ok, odd, any_decor);
+        const int32_t v = clx_lfinish(s, F);
         if (i < n) row[i] = v;
     }
     // ---- steady state: blocks of 4 samples through the LDS ring, rolled back to careful steps when anything is unusual
@@ -597,9 +613,8 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                     S.hist[0] = s;
                     y[ii] = s;
                 }
-                int32_t mx = y[0] > y[1] ? y[0] : y[1], mn = y[0] < y[1] ? y[0] : y[1];
-                mx = y[2] > mx ? y[2] : mx; mx = y[3] > mx ? y[3] : mx;
-                mn = y[2] < mn ? y[2] : mn; mn = y[3] < mn ? y[3] : mn;
+                int32_t mx = clx_max3(y[0], y[1], y[2]), mn = clx_min3(y[0], y[1], y[2]);
+                mx = y[3] > mx ? y[3] : mx; mn = y[3] < mn ? y[3] : mn;
                 const bool in_range = !live || S.order == 0u || (mx < S.lim && mn >= -S.lim);
                 if (!__all(in_range)) { redo = true; wide = true; }
             }
@@ -617,7 +632,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                 }
             }
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], h.wasted, decor, pair_ok, odd, any_decor);
+            for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], F);
         } else {
             int32_t* const ys = reinterpret_cast<int32_t*>(&stage[(t0 >> 2) & 3u]);
 #pragma unroll 1
@@ -630,7 +645,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
 #pragma unroll
                 for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
                 S.hist[0] = s;
-                ys[ii] = clx_lfinish(s, h.wasted, decor, pair_ok, odd, any_decor);
+                ys[ii] = clx_lfinish(s, F);
             }
             const int4 yv = stage[(t0 >> 2) & 3u];
             y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
