@@ -146,22 +146,28 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
     uint32_t done = 0;
     while (done < count) {
         const uint32_t remaining = count - done;
-        const uint32_t expect = remaining * (k + 2u);
-        uint32_t B = expect <= 256u ? 4u : expect <= 512u ? 8u : expect <= 1024u ? 16u : 32u;
-        if (k == 0u && B == 32u) B = 16u;                   // at most CLX_STAGE codes per span
+        // chunk width: sized so that one span of 64 chunks usually covers the whole partition (a code with an
+        // optimal parameter averages ~k+2.2 bits; k+3 leaves headroom) and every lane has work
+        uint32_t B = (remaining * (k + 3u) + 63u) >> 6;
+        B = B < 4u ? 4u : B > 32u ? 32u : B;
+        if (k == 0u && B > 16u) B = 16u;                    // at most CLX_STAGE codes per span
         clx_window_ensure(L, b, pos, 64u * B + 64u, lane);
 
         const uint32_t cpos = pos + B * (uint32_t)lane;
-        uint32_t c = clx_peek32(L, b, cpos);
+        const uint32_t c_raw = clx_peek32(L, b, cpos);       // my chunk and the 32 bits after it: codes that start in
+        const uint32_t c_next = clx_peek32(L, b, cpos + 32u);  // my chunk are extracted from this 64-bit register window
+        uint32_t c = c_raw;
         if (B < 32u) c &= ~(0xffffffffu >> B);
 
         // (1) exit-state tables
+        const uint32_t ex0 = clx_chunk_exit(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
             uint32_t packed = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-                uint32_t m = 4u * g + j;
-                uint32_t ex = (m < ns) ? clx_chunk_exit(c, B, k, m) : 0u;
+                const uint32_t m = 4u * g + j;
+                // entering inside a run (SC) walks exactly like entering at a code start (state 0)
+                const uint32_t ex = (m == 0u || m == SC) ? ex0 : (m < ns) ? clx_chunk_exit(c, B, k, m) : 0u;
                 packed |= ex << (8u * j);
             }
             L.tab[g][lane] = packed;
@@ -231,7 +237,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                 const uint32_t s = cpos + p;
                 const uint32_t idx = prefix + j;
                 if (idx < ntake) {
-                    uint32_t v = clx_peek32(L, b, s);
+                    uint32_t v = p ? clx_alignbit(c_raw, c_next, 32u - p) : c_raw;            // 32 bits at the code's start
                     uint32_t t = s;                          // terminator position
                     if (v == 0u) {                           // long unary run (subframe.rs:326-328: rare)
                         t = s + 32u;
@@ -246,8 +252,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                         const uint32_t q = t - s;
                         end = t + 1u + k;
                         uint32_t r;
-                        if (k == 0u) r = 0u;
-                        else if (z + 1u + k <= 32u) r = (v << (z + 1u)) >> (32u - k);         // whole code inside the 32-bit peek
+                        if (z + 1u + k <= 32u) r = clx_bfe(v, 32u - (z + 1u + k), k);         // whole code inside the 32-bit view
                         else r = clx_peek_bits(L, b, t + 1u, k);
                         const uint32_t u = (q << k) | r;     // u32 wrapping shift, subframe.rs:340
                         val = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                         // rice_to_signed, subframe.rs:157-170
