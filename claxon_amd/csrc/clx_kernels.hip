@@ -526,29 +526,17 @@ __device__ __forceinline__ void clx_row_load(const int32_t* __restrict__ row, ui
         for (int i = 0; i < CLX_BLK; ++i) { const uint32_t idx = t + (uint32_t)i < last ? t + (uint32_t)i : last; v[i] = row[idx]; }
     }
 }
-// Output stores.  A 16-byte store per lane into 64 different rows reaches L2 as 64 partial-line writes; measured,
-// those stores alone doubled the kernel's time.  So the finished block is transposed through LDS: lane 4j+m writes
-// piece m (16 bytes) of row 4j+r in store r, i.e. every quad of lanes writes one row's full 64-byte segment.
-// Stores are unconditional: pieces past a row's end go to a per-lane dump area instead of being branched around
-// (a branch around a memory operation makes the compiler fall back to s_waitcnt vmcnt(0)).
-struct K2Tile { int4 t[64][5]; };          // one padded 64-byte record per lane
-
-struct QuadRows { int32_t* base[4]; uint32_t n[4]; };     // the four rows of this lane's quad
-
+// Unconditional stores: samples past the row's end go to a per-lane dump area instead of being branched around
+// (any branch around a memory operation makes the compiler fall back to s_waitcnt vmcnt(0), which ties every use
+// of prefetched data to the completion of all older stores).
 template <bool ALIGNED>
-__device__ __forceinline__ void clx_row_store(K2Tile& T, const QuadRows& Q, int32_t* __restrict__ row, int32_t* __restrict__ dump,
-                                              uint32_t t, uint32_t n, const int32_t (&v)[CLX_BLK], int lane) {
+__device__ __forceinline__ void clx_row_store(int32_t* __restrict__ row, int32_t* __restrict__ dump, uint32_t t, uint32_t n,
+                                              const int32_t (&v)[CLX_BLK]) {
     if (ALIGNED) {
-        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < CLX_BLK / 4; ++q) T.t[lane][q] = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        __syncthreads();
-        const int m = lane & 3;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int4 w = T.t[(lane & ~3) + r][m];
-            int32_t* p = (t + 4u * (uint32_t)m < Q.n[r]) ? Q.base[r] + t + 4 * m : dump + 4 * r;
-            *reinterpret_cast<int4*>(p) = w;
+        for (int q = 0; q < CLX_BLK / 4; ++q) {
+            int32_t* p = (t + 4u * q < n) ? row + t + 4 * q : dump + 4 * q;
+            *reinterpret_cast<int4*>(p) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
     } else {
 #pragma unroll
@@ -557,26 +545,13 @@ __device__ __forceinline__ void clx_row_store(K2Tile& T, const QuadRows& Q, int3
 }
 
 template <int OMAX, bool ALIGNED>
-__device__ __forceinline__ void clx_predict_rows(K2Tile& T, int32_t* __restrict__ out, int32_t* __restrict__ dump, const clx_sf_desc* __restrict__ mydesc,
+__device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, int32_t* __restrict__ dump, const clx_sf_desc* __restrict__ mydesc,
                                                  uint32_t n, uint32_t order, uint32_t shift, uint32_t wasted,
                                                  uint32_t decor, bool pair_ok, uint32_t lim_log2, uint32_t nmax, int lane) {
     int32_t c[OMAX], hist[OMAX];
 #pragma unroll
     for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)mydesc->coef[j] : 0; hist[j] = 0; }
     int32_t* const row = out + (n != 0u ? mydesc->out_base : 0ull);       // empty slots read (never write) out[0..3]
-    QuadRows Q;
-    {
-        const uint32_t lo = (uint32_t)(uintptr_t)row, hi = (uint32_t)((uintptr_t)row >> 32);
-        // quad_perm broadcasts of lane 0..3 of the quad: 0x00, 0x55, 0xAA, 0xFF
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x00, 0xF, 0xF, false), h0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x00, 0xF, 0xF, false);
-        const uint32_t l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x55, 0xF, 0xF, false), h1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x55, 0xF, 0xF, false);
-        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xAA, 0xF, 0xF, false), h2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xAA, 0xF, 0xF, false);
-        const uint32_t l3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xFF, 0xF, 0xF, false), h3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xFF, 0xF, 0xF, false);
-        Q.base[0] = reinterpret_cast<int32_t*>(((uintptr_t)h0 << 32) | l0); Q.base[1] = reinterpret_cast<int32_t*>(((uintptr_t)h1 << 32) | l1);
-        Q.base[2] = reinterpret_cast<int32_t*>(((uintptr_t)h2 << 32) | l2); Q.base[3] = reinterpret_cast<int32_t*>(((uintptr_t)h3 << 32) | l3);
-        Q.n[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x00, 0xF, 0xF, false); Q.n[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0x55, 0xF, 0xF, false);
-        Q.n[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0xAA, 0xF, 0xF, false); Q.n[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0xFF, 0xF, 0xF, false);
-    }
     const bool odd = (lane & 1) != 0;
     const bool any_decor = __any(decor != CLX_CH_INDEPENDENT && pair_ok);
     const bool all_ms = __all(pair_ok && decor == CLX_CH_MID_SIDE);    // the common case gets a shorter instruction sequence
@@ -656,7 +631,7 @@ __device__ __forceinline__ void clx_predict_rows(K2Tile& T, int32_t* __restrict_
                 y[i] = v;
             }
         }
-        clx_row_store<ALIGNED>(T, Q, row, dump, t0, n, y, lane);
+        clx_row_store<ALIGNED>(row, dump, t0, n, y);
     };
     for (uint32_t t0 = 0; t0 < nmax; t0 += 3u * CLX_BLK) {
         clx_row_load<ALIGNED>(row, t0 + 2u * CLX_BLK, n, bufC);
@@ -690,7 +665,6 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
         uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
         uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
     }
-    __shared__ K2Tile T;
     int32_t* const dump = dump_all + (size_t)(blockIdx.x * 64u + (uint32_t)lane) * CLX_BLK;      // 64 bytes per lane
     const bool work = (order != 0u) || (wasted != 0u) || pair_ok;
     // a wave of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits is already final
@@ -698,15 +672,15 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
     // 16-byte row accesses need 16-byte aligned rows whose length is a multiple of 4 samples
     const bool al = (n == 0u) || ((((uintptr_t)(out + base)) & 15u) == 0u && (n & 3u) == 0u);
     if (__all(al)) {
-        if (omax <= 4u)       clx_predict_rows<4, true>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, true>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, true>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, true>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        if (omax <= 4u)       clx_predict_rows<4, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
     } else {
-        if (omax <= 4u)       clx_predict_rows<4, false>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, false>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, false>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, false>(T, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        if (omax <= 4u)       clx_predict_rows<4, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
     }
 }
 
