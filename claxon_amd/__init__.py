@@ -89,7 +89,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_CSRC, "intrin"),
-           os.path.join(_CSRC, "clx_api.hip"), "-o", LIB_PATH]
+           os.path.join(_CSRC, "clx_api.hip"), "-o", LIB_PATH] + os.environ.get("CLX_EXTRA_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)

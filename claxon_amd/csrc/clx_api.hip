@@ -824,3 +824,11 @@ extern "C" int clx_reader_next_block(clx_reader* r, int32_t* buffer, size_t cap,
 }
 
 extern "C" void clx_reader_close(clx_reader* r) { delete r; }
+
+#ifdef CLX_TIMELINE
+// debug aid, see clx_device.h / tools/timeline.py: kernel 0 = residual, 1 = predict, 2 = scan, 3 = lanes
+extern "C" int clx_debug_timeline(int kernel, void* host, size_t n_waves) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clx_timeline_buf), n_waves * 5 * sizeof(uint64_t),
+                                    (size_t)kernel * CLX_TL_WAVES * 5 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+}
+#endif

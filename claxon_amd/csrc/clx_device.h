@@ -40,6 +40,28 @@ struct clx_sf_desc {
 #ifdef __cplusplus
 static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
 static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
+
+// Debug aid (tools/timeline.py): with -DCLX_TIMELINE every wave of an instrumented kernel records when it started and
+// ended (s_memrealtime, 100 MHz), its shader clock ticks and where it ran.  Not part of the product build.
+#if defined(CLX_TIMELINE) && defined(__HIPCC__)
+#define CLX_TL_WAVES 65536
+__device__ uint64_t clx_timeline_buf[4][CLX_TL_WAVES][5];
+#define CLX_TL_BEGIN() const uint64_t tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime()
+#define CLX_TL_END(kid, wave) do { \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (threadIdx.x == 0 && (wave) < CLX_TL_WAVES) { \
+            uint32_t hwid, xcc; \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+            uint64_t* tl = clx_timeline_buf[kid][wave]; \
+            tl[0] = tl_r0; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[2] = tl_c0; tl[3] = __builtin_amdgcn_s_memtime(); \
+            tl[4] = ((uint64_t)xcc << 32) | hwid; \
+        } } while (0)
+#else
+#define CLX_TL_BEGIN() do {} while (0)
+#define CLX_TL_END(kid, wave) do {} while (0)
+#endif
+
 #endif
 
 #endif

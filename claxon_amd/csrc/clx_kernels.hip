@@ -295,6 +295,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     const int lane = (int)threadIdx.x;
     const uint32_t f = blockIdx.x;
     if (f >= n_frames) return;
+    CLX_TL_BEGIN();
     const clx_dev_frame fr = frames[f];
 
     BitSrc b;
@@ -459,6 +460,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         r.end_bit = (uint64_t)(h.pos - o);
         results[f] = r;
     }
+    CLX_TL_END(0, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,7 +547,7 @@ __device__ __forceinline__ void clx_row_store(int32_t* __restrict__ row, int32_t
 }
 
 template <int OMAX, bool ALIGNED>
-__device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, int32_t* __restrict__ dump, const clx_sf_desc* __restrict__ mydesc,
+__device__ __forceinline__ void clx_predict_rows(int4 (*ring)[4][64], int32_t* __restrict__ out, int32_t* __restrict__ dump, const clx_sf_desc* __restrict__ mydesc,
                                                  uint32_t n, uint32_t order, uint32_t shift, uint32_t wasted,
                                                  uint32_t decor, bool pair_ok, uint32_t lim_log2, uint32_t nmax, int lane) {
     int32_t c[OMAX], hist[OMAX];
@@ -554,23 +556,28 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, int3
     int32_t* const row = out + (n != 0u ? mydesc->out_base : 0ull);       // empty slots read (never write) out[0..3]
     const bool odd = (lane & 1) != 0;
     const bool any_decor = __any(decor != CLX_CH_INDEPENDENT && pair_ok);
-    const bool all_ms = __all(pair_ok && decor == CLX_CH_MID_SIDE);    // the common case gets a shorter instruction sequence
+    // the common case gets a shorter instruction sequence; empty slots (the tail of the last wave) do not spoil it
+    const bool all_ms = __all(n == 0u || (pair_ok && decor == CLX_CH_MID_SIDE));
     const bool any_wasted = __any(wasted != 0u);
     const uint32_t sgn = odd ? 0xffffffffu : 0u;                       // (x ^ sgn) - sgn = odd ? -x : x
+    // per-lane constants of the generic decorrelation formula (see compute)
+    const bool d_ms = pair_ok && decor == CLX_CH_MID_SIDE;
+    const bool d_ls = pair_ok && decor == CLX_CH_LEFT_SIDE && odd;       // this lane holds the side channel, becomes right
+    const bool d_rs = pair_ok && decor == CLX_CH_RIGHT_SIDE && !odd;     // this lane holds the side channel, becomes left
+    const bool g_p_other = (d_ms && odd) || d_ls;
+    const bool g_r_other = (d_ms && !odd) || d_rs;
+    const uint32_t g_rmask = (d_ms || d_ls || d_rs) ? 0xffffffffu : 0u;
+    const uint32_t g_s1 = d_ms ? 1u : 0u, g_bit = d_ms ? 1u : 0u;
+    const uint32_t g_sg = ((d_ms && odd) || d_ls) ? 0xffffffffu : 0u;
     // |s| <= lim proves the i32/i24 evaluation exact; lanes K1 could not prove (lim_log2 = 0xff) force the wide path
     // (range is [-lim, lim-1]: the 24-bit signed factor range when lim = 2^23)
     const int32_t lim = (lim_log2 <= 23u) ? (int32_t)(1u << lim_log2) : -1;
     const bool trivial = (n == 0u) || (order == 0u);          // nothing is predicted: any evaluation is exact
     bool h_ok = (lim >= 0) || trivial;
 
-    // Three row buffers rotate through a loop unrolled by three: the block computed in turn t was requested in turn
-    // t-2, so a scattered 16-byte-per-lane load has two blocks of compute to come back.  The trip count is padded to
-    // a multiple of three blocks (loads are clamped, stores of padding go to `dump`), so the loop body is branch-free
-    // around its memory operations and the compiler keeps counted s_waitcnt vmcnt(N).
-    int32_t bufA[CLX_BLK], bufB[CLX_BLK], bufC[CLX_BLK], y[CLX_BLK];
-    clx_row_load<ALIGNED>(row, 0u, n, bufA);
-    clx_row_load<ALIGNED>(row, CLX_BLK, n, bufB);
-    auto block = [&](const int32_t (&cur)[CLX_BLK], uint32_t t0) {
+    int32_t y[CLX_BLK];
+    // one block of CLX_BLK samples: x (residuals / warm-up samples) -> y (final samples of this channel)
+    auto compute = [&](const int32_t (&cur)[CLX_BLK], uint32_t t0) __attribute__((always_inline)) {
         bool done = false;
         if (__all(h_ok)) {
             int32_t h0[OMAX];
@@ -612,34 +619,111 @@ __device__ __forceinline__ void clx_predict_rows(int32_t* __restrict__ out, int3
                 y[i] = (int32_t)(m + (((uint32_t)side ^ sgn) - sgn)) >> 1;
             }
         } else if (any_decor) {
+            // mixed wave: one branch-free formula with per-lane constants (set up once, below) covers every role
+            //   v = ((P << s1 | Q & bit) + (R ^ sg) - sg) >> s1
+            //   mid/side  even: P = mid (mine),  Q = R = side (other), s1 = 1          frame.rs:382-384
+            //             odd : P = mid (other), Q = R = side (mine),  s1 = 1, minus
+            //   left/side odd : right = left (other) - side (mine)                     frame.rs:327-330
+            //   right/side even: left = side (mine) + right (other)                    frame.rs:352-355
+            //   anything else : v = mine
 #pragma unroll
             for (int i = 0; i < CLX_BLK; ++i) {
                 const int32_t mine = y[i];
                 const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);   // lane ^ 1
-                const int32_t a = odd ? other : mine;                       // channel 0 as coded
-                const int32_t bb = odd ? mine : other;                      // channel 1 as coded
-                int32_t v = mine;
-                if (pair_ok) {
-                    if (decor == CLX_CH_LEFT_SIDE) { if (odd) v = (int32_t)((uint32_t)a - (uint32_t)bb); }
-                    else if (decor == CLX_CH_RIGHT_SIDE) { if (!odd) v = (int32_t)((uint32_t)a + (uint32_t)bb); }
-                    else if (decor == CLX_CH_MID_SIDE) {
-                        const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
-                        // m +- side is even, so Rust's truncating `/ 2` equals an arithmetic shift
-                        v = odd ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1) : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
-                    }
-                }
-                y[i] = v;
+                const uint32_t P = (uint32_t)(g_p_other ? other : mine);
+                const uint32_t R = (uint32_t)(g_r_other ? other : mine) & g_rmask;
+                const uint32_t m = (P << g_s1) | (R & g_bit);
+                y[i] = (int32_t)(m + ((R ^ g_sg) - g_sg)) >> g_s1;
             }
         }
-        clx_row_store<ALIGNED>(row, dump, t0, n, y);
     };
-    for (uint32_t t0 = 0; t0 < nmax; t0 += 3u * CLX_BLK) {
-        clx_row_load<ALIGNED>(row, t0 + 2u * CLX_BLK, n, bufC);
-        block(bufA, t0);
-        clx_row_load<ALIGNED>(row, t0 + 3u * CLX_BLK, n, bufA);
-        block(bufB, t0 + CLX_BLK);
-        clx_row_load<ALIGNED>(row, t0 + 4u * CLX_BLK, n, bufB);
-        block(bufC, t0 + 2u * CLX_BLK);
+    if (ALIGNED) {
+        // Memory side of the aligned path (tools/ubench/storeshape.hip, rowrmw.hip measure the shapes on MI355X):
+        // a store instruction whose 64 lanes write 16 B to 64 different rows moves 0.8 TB/s, the same bytes as 64 B to
+        // 16 rows move 3.9 TB/s -- the per-lane row walk is fine for the arithmetic but not for the memory pipeline.
+        // So a block (16 samples = 64 B of each of the wave's 64 rows = 4 KiB) crosses HBM as four instructions of
+        // "4 adjacent lanes = one row's 64 B, 16 rows", and is transposed to "lane = row" through a per-wave LDS tile:
+        //   in : global_load_lds_dwordx4 (LDS-DMA, no VGPRs, asynchronous) into a ring of DEPTH tiles; with one wave
+        //        per SIMD and ~2 us of memory latency the ring is what keeps DEPTH x 4 KiB per wave in flight
+        //   out: the lane writes its 64 B back into the tile it came from, four ds_read_b128 + global_store_dwordx4
+        //        take it out in the 64 B x 16 rows shape, then the next DMA refills the tile
+        // Tile layout: int4 [row][pos], pos = piece ^ ((row >> 2) & 3): both the lane = row view (64-byte stride) and the
+        // instruction view (contiguous) are LDS-bank-conflict free.
+        //   turn i: wait DMA(i+1) | read x(i+1) | compute(i) | y -> tile | 4x (ds_read, store) S(i) | DMA(i+DEPTH)
+        //   VMEM ops younger than DMA(i+1) when turn i waits: turns i+2-DEPTH .. i-1, 8 each = 8*(DEPTH-2)
+        constexpr int DEPTH = 8;
+        const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // this lane's row swizzle (lane = row view)
+        const uint32_t pc = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u);     // piece this lane moves (instruction view)
+        const int32_t* rp[4]; uint32_t rn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                                  // instruction k moves rows 16k .. 16k+15
+            const int src = k * 16 + (lane >> 2);
+            const uint64_t ro = __shfl((unsigned long long)(row - out), src, 64);
+            rp[k] = out + ro; rn[k] = __shfl(n, src, 64);
+        }
+        auto dma = [&](uint32_t blk) __attribute__((always_inline)) {
+            const uint32_t t = blk * CLX_BLK + 4u * pc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t last = rn[k] >= 4u ? rn[k] - 4u : 0u;                  // clamped: what lies past a row's end is never stored
+                clx_glds16(rp[k] + (t < last ? t : last), clx_lds_addr(&ring[blk % DEPTH][k][0]));
+            }
+        };
+        auto fetch = [&](int32_t (&x)[CLX_BLK], uint32_t blk) __attribute__((always_inline)) {
+            const int4* tile = &ring[blk % DEPTH][0][0];
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) {
+                const int4 w = tile[(uint32_t)lane * 4u + (q ^ sw)];
+                x[4 * q] = w.x; x[4 * q + 1] = w.y; x[4 * q + 2] = w.z; x[4 * q + 3] = w.w;
+            }
+        };
+        auto drain = [&](uint32_t blk) __attribute__((always_inline)) {
+            int4* tile = &ring[blk % DEPTH][0][0];
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) tile[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+            clx_wave_sync();
+            const uint32_t t = blk * CLX_BLK + 4u * pc;
+            int4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = ring[blk % DEPTH][k][lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int32_t* p = t < rn[k] ? const_cast<int32_t*>(rp[k]) + t : dump + 4 * k;
+                *reinterpret_cast<int4*>(p) = w[k];
+            }
+            clx_wait_lds();                      // the tile has been read: the DMA may overwrite it
+        };
+        const uint32_t nblk = (nmax + CLX_BLK - 1u) / CLX_BLK;
+        int32_t xa[CLX_BLK], xb[CLX_BLK];
+        for (uint32_t i = 0; i < (uint32_t)DEPTH; ++i) dma(i);
+        clx_wait_vmcnt<4 * (DEPTH - 1)>();
+        clx_wave_sync();
+        fetch(xa, 0u);
+        // two turns per trip so that the "current" and "next" blocks alternate between xa and xb without copies
+        auto turn = [&](int32_t (&xc)[CLX_BLK], int32_t (&xn)[CLX_BLK], uint32_t i) __attribute__((always_inline)) {
+            if (i + 2u <= (uint32_t)DEPTH) clx_wait_vmcnt<4 * (DEPTH - 2)>(); else clx_wait_vmcnt<8 * (DEPTH - 2)>();
+            clx_wave_sync();
+            fetch(xn, i + 1u);
+            compute(xc, i * CLX_BLK);
+            drain(i);
+            dma(i + DEPTH);
+        };
+        for (uint32_t i = 0; i < nblk; i += 2u) { turn(xa, xb, i); turn(xb, xa, i + 1u); }
+        clx_wait_vmcnt<0>();
+    } else {
+        // rows that are not 16-byte aligned / a multiple of 4 samples long: per-lane element accesses, three row buffers
+        // rotating through a loop unrolled by three (the block computed in turn t was requested in turn t-2)
+        int32_t bufA[CLX_BLK], bufB[CLX_BLK], bufC[CLX_BLK];
+        clx_row_load<false>(row, 0u, n, bufA);
+        clx_row_load<false>(row, CLX_BLK, n, bufB);
+        for (uint32_t t0 = 0; t0 < nmax; t0 += 3u * CLX_BLK) {
+            clx_row_load<false>(row, t0 + 2u * CLX_BLK, n, bufC);
+            compute(bufA, t0); clx_row_store<false>(row, dump, t0, n, y);
+            clx_row_load<false>(row, t0 + 3u * CLX_BLK, n, bufA);
+            compute(bufB, t0 + CLX_BLK); clx_row_store<false>(row, dump, t0 + CLX_BLK, n, y);
+            clx_row_load<false>(row, t0 + 4u * CLX_BLK, n, bufB);
+            compute(bufC, t0 + 2u * CLX_BLK); clx_row_store<false>(row, dump, t0 + 2u * CLX_BLK, n, y);
+        }
     }
 }
 
@@ -665,6 +749,8 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
         uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
         uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
     }
+    CLX_TL_BEGIN();
+    __shared__ int4 ring[8][4][64];    // 32 KiB: 8 blocks x 64 B of each of the wave's 64 rows, filled by LDS-DMA
     int32_t* const dump = dump_all + (size_t)(blockIdx.x * 64u + (uint32_t)lane) * CLX_BLK;      // 64 bytes per lane
     const bool work = (order != 0u) || (wasted != 0u) || pair_ok;
     // a wave of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits is already final
@@ -672,16 +758,17 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
     // 16-byte row accesses need 16-byte aligned rows whose length is a multiple of 4 samples
     const bool al = (n == 0u) || ((((uintptr_t)(out + base)) & 15u) == 0u && (n & 3u) == 0u);
     if (__all(al)) {
-        if (omax <= 4u)       clx_predict_rows<4, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, true>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        if (omax <= 4u)       clx_predict_rows<4, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
     } else {
-        if (omax <= 4u)       clx_predict_rows<4, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, false>(out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        if (omax <= 4u)       clx_predict_rows<4, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 8u)  clx_predict_rows<8, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else if (omax <= 12u) clx_predict_rows<12, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        else                  clx_predict_rows<32, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
     }
+    CLX_TL_END(1, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

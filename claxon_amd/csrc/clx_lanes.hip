@@ -258,6 +258,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                 const uint32_t* __restrict__ multi, uint32_t n_multi,
                 uint32_t* __restrict__ sf_start, uint32_t* __restrict__ errkey) {
     __shared__ LanesLds L;
+    CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
     uint32_t* const row = L.ring[lane];
     const uint32_t t = blockIdx.x * 64u + (uint32_t)lane;
@@ -384,6 +385,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
             else sf_start[fr.first_slot + ch + 1u] = r.pos;
         }
     }
+    CLX_TL_END(2, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,9 +489,29 @@ __device__ __forceinline__ int32_t clx_lcareful_raw(LaneState<OMAX>& S, const Sf
 
 // wasted-bits shift (subframe.rs:216-225) + stereo decorrelation (frame.rs:319-389) of one sample; wave-uniform call
 struct Finish {
-    uint32_t wasted, decor, sgn;      // sgn: all ones in odd lanes ((x ^ sgn) - sgn = odd ? -x : x)
-    bool pair_ok, odd, any_decor, all_ms, any_wasted;
+    uint32_t wasted, sgn;             // sgn: all ones in odd lanes ((x ^ sgn) - sgn = odd ? -x : x)
+    // per-lane constants of the generic formula  v = ((P << s1 | R & bit) + (R ^ sg) - sg) >> s1  (see clx_k_predict)
+    uint32_t rmask, s1, bit, sg;
+    bool p_other, r_other;
+    bool any_decor, all_ms, any_wasted;
 };
+__device__ __forceinline__ Finish clx_lfinish_setup(uint32_t n, uint32_t wasted, uint32_t decor, bool pair_ok, int lane) {
+    Finish F;
+    const bool odd = (lane & 1) != 0;
+    F.wasted = wasted; F.sgn = odd ? 0xffffffffu : 0u;
+    const bool d_ms = pair_ok && decor == CLX_CH_MID_SIDE;
+    const bool d_ls = pair_ok && decor == CLX_CH_LEFT_SIDE && odd;       // side channel -> right = left - side (frame.rs:327-330)
+    const bool d_rs = pair_ok && decor == CLX_CH_RIGHT_SIDE && !odd;     // side channel -> left = side + right (frame.rs:352-355)
+    F.p_other = (d_ms && odd) || d_ls;
+    F.r_other = (d_ms && !odd) || d_rs;
+    F.rmask = (d_ms || d_ls || d_rs) ? 0xffffffffu : 0u;
+    F.s1 = d_ms ? 1u : 0u; F.bit = F.s1;
+    F.sg = ((d_ms && odd) || d_ls) ? 0xffffffffu : 0u;
+    F.any_decor = __any(pair_ok);
+    F.all_ms = __all(n == 0u || d_ms);        // idle lanes (the tail of the last wave) do not spoil the short sequence
+    F.any_wasted = __any(n != 0u && wasted != 0u);
+    return F;
+}
 __device__ __forceinline__ int32_t clx_lfinish(int32_t s, const Finish& F) {
     int32_t mine = F.any_wasted ? (int32_t)((uint32_t)s << F.wasted) : s;
     if (F.all_ms) {
@@ -502,17 +524,10 @@ __device__ __forceinline__ int32_t clx_lfinish(int32_t s, const Finish& F) {
     }
     if (F.any_decor) {
         const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);       // lane ^ 1
-        const int32_t a = F.odd ? other : mine;                 // channel 0 as coded
-        const int32_t bb = F.odd ? mine : other;                // channel 1 as coded
-        if (F.pair_ok) {
-            if (F.decor == CLX_CH_LEFT_SIDE) { if (F.odd) mine = (int32_t)((uint32_t)a - (uint32_t)bb); }
-            else if (F.decor == CLX_CH_RIGHT_SIDE) { if (!F.odd) mine = (int32_t)((uint32_t)a + (uint32_t)bb); }
-            else {
-                const int32_t m = (int32_t)(((uint32_t)a << 1) | ((uint32_t)bb & 1u));
-                // m +- side is even, so Rust's truncating `/ 2` equals an arithmetic shift
-                mine = F.odd ? ((int32_t)((uint32_t)m - (uint32_t)bb) >> 1) : ((int32_t)((uint32_t)m + (uint32_t)bb) >> 1);
-            }
-        }
+        const uint32_t P = (uint32_t)(F.p_other ? other : mine);
+        const uint32_t R = (uint32_t)(F.r_other ? other : mine) & F.rmask;
+        const uint32_t m = (P << F.s1) | (R & F.bit);
+        mine = (int32_t)(m + ((R ^ F.sg) - F.sg)) >> F.s1;
     }
     return mine;
 }
@@ -522,12 +537,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                                                uint32_t decor, bool pair_ok, int32_t* __restrict__ row, bool row_aligned,
                                                uint32_t nmax, uint32_t omax, int lane) {
     LaneReader& r = S.r;
-    Finish F;
-    F.wasted = h.wasted; F.decor = decor; F.pair_ok = pair_ok; F.odd = (lane & 1) != 0;
-    F.sgn = F.odd ? 0xffffffffu : 0u;
-    F.any_decor = __any(pair_ok);
-    F.all_ms = __all(pair_ok && decor == CLX_CH_MID_SIDE);
-    F.any_wasted = __any(n != 0u && h.wasted != 0u);
+    const Finish F = clx_lfinish_setup(n, h.wasted, decor, pair_ok, lane);
 
     // ---- careful prologue: warm-up samples, the transition, the first residuals (rolled loop, one sample per turn)
     uint32_t i0 = (omax + 4u + 15u) & ~15u;              // multiple of 16: output segments are flushed 64 bytes at a time
@@ -711,6 +721,7 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                  const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
                  uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits) {
     __shared__ LanesLds L;
+    CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
     uint32_t f = 0xffffffffu;
@@ -771,6 +782,7 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         if (err) clx_report_error(errkey, f, ch, err);
         else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(end_pos - o);
     }
+    CLX_TL_END(3, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -28,4 +28,22 @@ __device__ __forceinline__ int32_t clx_min3(int32_t a, int32_t b, int32_t c) {
     asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at lds_base + 16*lane (no VGPR
+// round trip, asynchronous, counted by vmcnt).  Inline asm on purpose: hipcc drains vmcnt(0) before the next LDS read
+// when it can see the DMA, which would serialise a prefetch ring; with asm the waits are placed by hand
+// (clx_wait_vmcnt).  M0 carries the LDS base and is saved / restored inside the statement (it is compiler-reserved).
+__device__ __forceinline__ void clx_glds16(const void* gsrc, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+// byte address of a __shared__ object inside the workgroup's LDS allocation (wave-uniform)
+__device__ __forceinline__ uint32_t clx_lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p);
+}
+template <int N> __device__ __forceinline__ void clx_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void clx_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// wave-level ordering point for LDS traffic of a one-wave workgroup: no instruction, only stops the compiler from
+// moving LDS accesses across it (the LDS queue itself is in order per wave)
+__device__ __forceinline__ void clx_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 #endif

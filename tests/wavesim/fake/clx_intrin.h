@@ -16,4 +16,12 @@ static inline int32_t clx_mad24(int32_t a, int32_t b, int32_t c) {
 }
 static inline int32_t clx_max3(int32_t a, int32_t b, int32_t c) { int32_t m = a > b ? a : b; return m > c ? m : c; }
 static inline int32_t clx_min3(int32_t a, int32_t b, int32_t c) { int32_t m = a < b ? a : b; return m < c ? m : c; }
+// LDS-DMA in the simulator: synchronous copy; the "LDS address" is simply the host pointer of the shared object.
+static inline uintptr_t clx_lds_addr(const void* p) { return (uintptr_t)p; }
+static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {
+    memcpy((char*)lds_base + 16 * (wavesim::S().cur & 63), gsrc, 16);
+}
+template <int N> static inline void clx_wait_vmcnt() {}
+static inline void clx_wait_lds() {}
+#define clx_wave_sync() __syncthreads()
 #endif
