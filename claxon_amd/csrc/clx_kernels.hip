@@ -23,7 +23,7 @@
 #include "clx_device.h"
 
 #define CLX_NW 512u            // LDS bitstream window: 512 big-endian-normalised dwords = 2 KiB per wave
-#define CLX_STAGE 1024u        // LDS residual staging (values per span)
+#define CLX_NPOS 1152u         // code start positions of one span (u16, span relative); shares LDS with the exit tables
 
 // ------------------------------------------------------------------------------------------------
 // Bit window: a 2 KiB slice of the frame's bytes staged in LDS with coalesced 16-byte loads.  Dwords
@@ -33,9 +33,15 @@
 // ------------------------------------------------------------------------------------------------
 struct K1Lds {
     uint32_t W[CLX_NW + 4];
-    uint32_t tab[8][64];       // tab[g][lane]: exit states of that lane's chunk for entry states 4g..4g+3
-    uint8_t  gtab[8][32];      // gtab[g][s]: exit state of lane group g (8 lanes) for entry state s
-    int32_t  stage[CLX_STAGE];
+    // The two phases of a span never overlap: first the exit-state tables resolve where every lane's chunk is entered,
+    // then the positions of the codes are listed.  4.4 KiB per wave in all = 8 waves per SIMD.
+    union {
+        struct {
+            uint32_t tab[8][64];   // tab[g][lane]: exit states of that lane's chunk for entry states 4g..4g+3
+            uint8_t  gtab[8][32];  // gtab[g][s]: exit state of lane group g (8 lanes) for entry state s
+        } t;
+        uint16_t P[CLX_NPOS];      // P[i]: bit position (relative to the span) where code i of the span starts
+    } u;
 };
 
 struct BitSrc {
@@ -150,7 +156,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         // optimal parameter averages ~k+2.2 bits; k+3 leaves headroom) and every lane has work
         uint32_t B = (remaining * (k + 3u) + 63u) >> 6;
         B = B < 4u ? 4u : B > 32u ? 32u : B;
-        if (k == 0u && B > 16u) B = 16u;                    // at most CLX_STAGE codes per span
+        if (k == 0u && B > 16u) B = 16u;                    // at most 1024 <= CLX_NPOS codes per span
         clx_window_ensure(L, b, pos, 64u * B + 64u, lane);
 
         const uint32_t cpos = pos + B * (uint32_t)lane;
@@ -170,7 +176,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                 const uint32_t ex = (m == 0u || m == SC) ? ex0 : (m < ns) ? clx_chunk_exit(c, B, k, m) : 0u;
                 packed |= ex << (8u * j);
             }
-            L.tab[g][lane] = packed;
+            L.u.t.tab[g][lane] = packed;
         }
         __syncthreads();
         // (2a) group tables: lane (g8, e) walks group g8's 8 chunks for entry states e, e+8, ...
@@ -180,8 +186,8 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                 uint32_t m = st;
 #pragma unroll
                 for (uint32_t i = 0; i < 8; ++i)
-                    m = (L.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
-                L.gtab[g8][st] = (uint8_t)m;
+                    m = (L.u.t.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
+                L.u.t.gtab[g8][st] = (uint8_t)m;
             }
         }
         __syncthreads();
@@ -192,14 +198,14 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
 #pragma unroll
             for (uint32_t g = 0; g < 8; ++g) {
                 if (((uint32_t)lane >> 3) == g) mine = m;
-                m = L.gtab[g][m];
+                m = L.u.t.gtab[g][m];
             }
             m = mine;
             const uint32_t g8 = (uint32_t)lane >> 3;
 #pragma unroll
             for (uint32_t i = 0; i < 8; ++i) {
                 if (((uint32_t)lane & 7u) == i) my_entry = m;
-                m = (L.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
+                m = (L.u.t.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
             }
         }
         // (3) starts in my chunk
@@ -220,53 +226,49 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         const uint32_t prefix = clx_wave_excl_scan(cnt, lane, &total);
         const uint32_t ntake = total < remaining ? total : remaining;
 
-        // (4) extraction
-        uint32_t maxcnt = cnt;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            uint32_t o = __shfl_xor(maxcnt, d, 64);
-            maxcnt = o > maxcnt ? o : maxcnt;
-        }
-        bool eof = false;
-        uint32_t edge_pos = 0; bool have_edge = false;      // start #remaining, or end of code #total-1
-        uint32_t Sit = S;
-        for (uint32_t j = 0; j < maxcnt; ++j) {
-            if (Sit != 0u) {
+        // (4a) list the span-relative start position of every code (ascending inside a lane, lanes in order)
+        {
+            uint32_t Sit = S, idx = prefix;
+            while (Sit != 0u) {
                 const uint32_t p = (uint32_t)__ffs((int)Sit) - 1u;
                 Sit &= Sit - 1u;
-                const uint32_t s = cpos + p;
-                const uint32_t idx = prefix + j;
-                if (idx < ntake) {
-                    uint32_t v = p ? clx_alignbit(c_raw, c_next, 32u - p) : c_raw;            // 32 bits at the code's start
-                    uint32_t t = s;                          // terminator position
-                    if (v == 0u) {                           // long unary run (subframe.rs:326-328: rare)
-                        t = s + 32u;
-                        while (t < limit) { v = clx_peek32(L, b, t); if (v != 0u) break; t += 32u; }
-                    }
-                    uint32_t end;
-                    int32_t val = 0;
-                    if (v == 0u) { eof = true; end = limit + 1u; }
-                    else {
-                        const uint32_t z = (uint32_t)__clz((int)v);
-                        t += z;
-                        const uint32_t q = t - s;
-                        end = t + 1u + k;
-                        uint32_t r;
-                        if (z + 1u + k <= 32u) r = clx_bfe(v, 32u - (z + 1u + k), k);         // whole code inside the 32-bit view
-                        else r = clx_peek_bits(L, b, t + 1u, k);
-                        const uint32_t u = (q << k) | r;     // u32 wrapping shift, subframe.rs:340
-                        val = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                         // rice_to_signed, subframe.rs:157-170
-                        if (end > limit) eof = true;
-                    }
-                    L.stage[idx] = val;
-                    if (idx + 1u == total && total <= remaining) { edge_pos = end; have_edge = true; }
-                } else if (idx == remaining) { edge_pos = s; have_edge = true; }
+                L.u.P[idx] = (uint16_t)(B * (uint32_t)lane + p);
+                ++idx;
             }
         }
         __syncthreads();
-        for (uint32_t i = (uint32_t)lane; i < ntake; i += 64u) dst[done + i] = L.stage[i];
-        const uint32_t newpos = clx_pick(edge_pos, have_edge, limit + 1u);
-        if (__any(eof)) { *err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); return newpos; }
+        // (4b) where the taken codes end.  A code ends where the next one starts; only the span's very last code has to
+        // be delimited the slow way (zeros, a one, k bits), by the one lane that holds its start.
+        uint32_t newpos;
+        if (total <= remaining) {
+            const bool owner = cnt != 0u && prefix + cnt == total;
+            uint32_t e = 0;
+            if (owner) {
+                const uint32_t p = 31u - (uint32_t)__clz((int)S);
+                const uint32_t s = cpos + p;
+                uint32_t v = p ? clx_alignbit(c_raw, c_next, 32u - p) : c_raw;                // 32 bits at the code's start
+                uint32_t t = s;
+                if (v == 0u) {                               // long unary run (subframe.rs:326-328: rare)
+                    t = s + 32u;
+                    while (t < limit) { v = clx_peek32(L, b, t); if (v != 0u) break; t += 32u; }
+                }
+                e = (v == 0u) ? limit + 1u : t + (uint32_t)__clz((int)v) + 1u + k;
+            }
+            newpos = clx_pick(e, owner, limit + 1u);
+        } else newpos = pos + L.u.P[remaining];              // start of the first code that is not taken
+        // (4c) extraction, balanced over the lanes and written straight to HBM (coalesced): code i has
+        // q = start(i+1) - start(i) - 1 - k zeros and its k remainder bits end where code i+1 starts
+        const uint32_t end_rel = newpos - pos;
+        for (uint32_t i = (uint32_t)lane; i < ntake; i += 64u) {
+            const uint32_t s = L.u.P[i];
+            const uint32_t e = (i + 1u < ntake) ? (uint32_t)L.u.P[i + 1u] : end_rel;
+            const uint32_t q = e - s - 1u - k;
+            const uint32_t r = clx_peek_bits(L, b, pos + e - k, k);
+            const uint32_t u = (q << k) | r;                 // u32 wrapping shift, subframe.rs:340
+            dst[done + i] = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                           // rice_to_signed, subframe.rs:157-170
+        }
+        // ends grow with the code index: the last taken code is past the limit iff any is (input.rs EOF)
+        if (newpos > limit) { *err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); return newpos; }
         done += ntake;
         pos = newpos;
         __syncthreads();
