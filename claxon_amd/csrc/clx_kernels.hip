@@ -288,7 +288,7 @@ __device__ __forceinline__ bool clx_hdr_bits(const K1Lds& L, const BitSrc& b, Hd
     return true;
 }
 
-extern "C" __global__ __launch_bounds__(64)
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                     const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
                     int32_t* __restrict__ out, clx_sf_desc* __restrict__ sfd,
