@@ -495,9 +495,7 @@ __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32
             for (int j = OMAX - 1; j >= 0; --j) acc += (int64_t)c[j] * (int64_t)hist[j];   // newest tap last: shortest dependent chain
             pred = (int32_t)(acc >> shift);
         } else {
-            int32_t acc = 0;
-#pragma unroll
-            for (int j = OMAX - 1; j >= 0; --j) acc = clx_mad24(c[j], hist[j], acc);       // v_mad_i32_i24 chain, newest tap last
+            const int32_t acc = clx_dot24<OMAX>(c, hist, 0);                               // v_mad_i32_i24 chain, newest tap last
             pred = acc >> shift;
         }
         int32_t s;

@@ -412,10 +412,7 @@ __device__ __forceinline__ int32_t clx_lpredict(const int32_t (&c)[OMAX], const 
         for (int j = OMAX - 1; j >= 0; --j) acc += (int64_t)c[j] * (int64_t)hist[j];
         return (int32_t)(acc >> shift);
     } else {
-        int32_t acc = 0;
-#pragma unroll
-        for (int j = OMAX - 1; j >= 0; --j) acc = clx_mad24(c[j], hist[j], acc);      // v_mad_i32_i24 chain, newest tap last
-        return acc >> shift;
+        return clx_dot24<OMAX>(c, hist, 0) >> shift;                              // v_mad_i32_i24 chain, newest tap last
     }
 }
 

@@ -28,6 +28,30 @@ __device__ __forceinline__ int32_t clx_min3(int32_t a, int32_t b, int32_t c) {
     asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// Dot product of N 24-bit factors pairs as ONE asm statement: acc = sum_j c[j]*h[j], evaluated oldest tap (j = N-1) first
+// so that the newest sample h[0] is needed last.  One statement per chain because hipcc pads every boundary between
+// dependent asm statements with an s_nop (it cannot see what the instruction inside is): a mad per statement costs a
+// wasted issue slot for every two mads.
+template <int N> __device__ __forceinline__ int32_t clx_dot24(const int32_t* c, const int32_t* h, int32_t acc);
+template <> __device__ __forceinline__ int32_t clx_dot24<4>(const int32_t* c, const int32_t* h, int32_t acc) {
+    asm volatile("v_mad_i32_i24 %0, %1, %2, %0\n\tv_mad_i32_i24 %0, %3, %4, %0\n\tv_mad_i32_i24 %0, %5, %6, %0\n\tv_mad_i32_i24 %0, %7, %8, %0"
+                 : "+v"(acc) : "v"(c[3]), "v"(h[3]), "v"(c[2]), "v"(h[2]), "v"(c[1]), "v"(h[1]), "v"(c[0]), "v"(h[0]));
+    return acc;
+}
+template <> __device__ __forceinline__ int32_t clx_dot24<8>(const int32_t* c, const int32_t* h, int32_t acc) {
+    asm volatile("v_mad_i32_i24 %0, %1, %2, %0\n\tv_mad_i32_i24 %0, %3, %4, %0\n\tv_mad_i32_i24 %0, %5, %6, %0\n\tv_mad_i32_i24 %0, %7, %8, %0\n\t"
+                 "v_mad_i32_i24 %0, %9, %10, %0\n\tv_mad_i32_i24 %0, %11, %12, %0\n\tv_mad_i32_i24 %0, %13, %14, %0\n\tv_mad_i32_i24 %0, %15, %16, %0"
+                 : "+v"(acc) : "v"(c[7]), "v"(h[7]), "v"(c[6]), "v"(h[6]), "v"(c[5]), "v"(h[5]), "v"(c[4]), "v"(h[4]),
+                               "v"(c[3]), "v"(h[3]), "v"(c[2]), "v"(h[2]), "v"(c[1]), "v"(h[1]), "v"(c[0]), "v"(h[0]));
+    return acc;
+}
+template <> __device__ __forceinline__ int32_t clx_dot24<12>(const int32_t* c, const int32_t* h, int32_t acc) {
+    return clx_dot24<8>(c, h, clx_dot24<4>(c + 8, h + 8, acc));
+}
+template <> __device__ __forceinline__ int32_t clx_dot24<32>(const int32_t* c, const int32_t* h, int32_t acc) {
+    acc = clx_dot24<8>(c + 24, h + 24, acc); acc = clx_dot24<8>(c + 16, h + 16, acc);
+    acc = clx_dot24<8>(c + 8, h + 8, acc);   return clx_dot24<8>(c, h, acc);
+}
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at lds_base + 16*lane (no VGPR
 // round trip, asynchronous, counted by vmcnt).  Inline asm on purpose: hipcc drains vmcnt(0) before the next LDS read
 // when it can see the DMA, which would serialise a prefetch ring; with asm the waits are placed by hand

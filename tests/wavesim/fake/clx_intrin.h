@@ -16,6 +16,10 @@ static inline int32_t clx_mad24(int32_t a, int32_t b, int32_t c) {
 }
 static inline int32_t clx_max3(int32_t a, int32_t b, int32_t c) { int32_t m = a > b ? a : b; return m > c ? m : c; }
 static inline int32_t clx_min3(int32_t a, int32_t b, int32_t c) { int32_t m = a < b ? a : b; return m < c ? m : c; }
+template <int N> static inline int32_t clx_dot24(const int32_t* c, const int32_t* h, int32_t acc) {
+    for (int j = N - 1; j >= 0; --j) acc = clx_mad24(c[j], h[j], acc);
+    return acc;
+}
 // LDS-DMA in the simulator: synchronous copy; the "LDS address" is simply the host pointer of the shared object.
 static inline uintptr_t clx_lds_addr(const void* p) { return (uintptr_t)p; }
 static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {
