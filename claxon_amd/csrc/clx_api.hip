@@ -320,7 +320,7 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     // 4.71 ms vs 3.47 ms.
     b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 40000);
     if (!b->lanes) {
-        const size_t lanes64 = ((ns + 63) / 64) * 64;
+        const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
     }
     if (b->lanes) {
@@ -399,7 +399,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), 0, stream,
                            d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
         if (!mark("clx_k_predict")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_predict, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_out,
+        hipLaunchKernelGGL(clx_k_predict, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_out,
                            (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
     }
     if (b->flags & CLX_VERIFY_CRC16) {
@@ -828,7 +828,7 @@ extern "C" void clx_reader_close(clx_reader* r) { delete r; }
 #ifdef CLX_TIMELINE
 // debug aid, see clx_device.h / tools/timeline.py: kernel 0 = residual, 1 = predict, 2 = scan, 3 = lanes
 extern "C" int clx_debug_timeline(int kernel, void* host, size_t n_waves) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clx_timeline_buf), n_waves * 5 * sizeof(uint64_t),
-                                    (size_t)kernel * CLX_TL_WAVES * 5 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clx_timeline_buf), n_waves * 6 * sizeof(uint64_t),
+                                    (size_t)kernel * CLX_TL_WAVES * 6 * sizeof(uint64_t), hipMemcpyDeviceToHost);
 }
 #endif

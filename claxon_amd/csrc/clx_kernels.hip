@@ -483,9 +483,13 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 // ------------------------------------------------------------------------------------------------
 #define CLX_BLK 16
 
-template <int OMAX, bool WIDE, bool MASKED>
+struct K2NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// `hook(i)` runs after sample i: the caller's memory instructions are issued in between the arithmetic instead of in
+// one burst (a burst of scattered 64-lane VMEM instructions stalls the wave's issue for hundreds of cycles).
+template <int OMAX, bool WIDE, bool MASKED, typename Hook>
 __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32_t (&y)[CLX_BLK], int32_t (&hist)[OMAX],
-                                              const int32_t (&c)[OMAX], uint32_t t0, uint32_t order, uint32_t shift) {
+                                              const int32_t (&c)[OMAX], uint32_t t0, uint32_t order, uint32_t shift, Hook&& hook) {
 #pragma unroll
     for (int i = 0; i < CLX_BLK; ++i) {
         int32_t pred;
@@ -507,6 +511,7 @@ __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32
         for (int j = OMAX - 1; j > 0; --j) hist[j] = hist[j - 1];
         hist[0] = s;
         y[i] = s;
+        hook(i);
     }
 }
 
@@ -546,45 +551,44 @@ __device__ __forceinline__ void clx_row_store(int32_t* __restrict__ row, int32_t
     }
 }
 
-template <int OMAX, bool ALIGNED>
-__device__ __forceinline__ void clx_predict_rows(int4 (*ring)[4][64], int32_t* __restrict__ out, int32_t* __restrict__ dump, const clx_sf_desc* __restrict__ mydesc,
-                                                 uint32_t n, uint32_t order, uint32_t shift, uint32_t wasted,
-                                                 uint32_t decor, bool pair_ok, uint32_t lim_log2, uint32_t nmax, int lane) {
-    int32_t c[OMAX], hist[OMAX];
-#pragma unroll
-    for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)mydesc->coef[j] : 0; hist[j] = 0; }
-    int32_t* const row = out + (n != 0u ? mydesc->out_base : 0ull);       // empty slots read (never write) out[0..3]
-    const bool odd = (lane & 1) != 0;
-    const bool any_decor = __any(decor != CLX_CH_INDEPENDENT && pair_ok);
-    // the common case gets a shorter instruction sequence; empty slots (the tail of the last wave) do not spoil it
-    const bool all_ms = __all(n == 0u || (pair_ok && decor == CLX_CH_MID_SIDE));
-    const bool any_wasted = __any(wasted != 0u);
-    const uint32_t sgn = odd ? 0xffffffffu : 0u;                       // (x ^ sgn) - sgn = odd ? -x : x
-    // per-lane constants of the generic decorrelation formula (see compute)
-    const bool d_ms = pair_ok && decor == CLX_CH_MID_SIDE;
-    const bool d_ls = pair_ok && decor == CLX_CH_LEFT_SIDE && odd;       // this lane holds the side channel, becomes right
-    const bool d_rs = pair_ok && decor == CLX_CH_RIGHT_SIDE && !odd;     // this lane holds the side channel, becomes left
-    const bool g_p_other = (d_ms && odd) || d_ls;
-    const bool g_r_other = (d_ms && !odd) || d_rs;
-    const uint32_t g_rmask = (d_ms || d_ls || d_rs) ? 0xffffffffu : 0u;
-    const uint32_t g_s1 = d_ms ? 1u : 0u, g_bit = d_ms ? 1u : 0u;
-    const uint32_t g_sg = ((d_ms && odd) || d_ls) ? 0xffffffffu : 0u;
-    // |s| <= lim proves the i32/i24 evaluation exact; lanes K1 could not prove (lim_log2 = 0xff) force the wide path
-    // (range is [-lim, lim-1]: the 24-bit signed factor range when lim = 2^23)
-    const int32_t lim = (lim_log2 <= 23u) ? (int32_t)(1u << lim_log2) : -1;
-    const bool trivial = (n == 0u) || (order == 0u);          // nothing is predicted: any evaluation is exact
-    bool h_ok = (lim >= 0) || trivial;
+// What one lane knows about its predictor slot (a row of `out`).
+struct K2Slot {
+    const clx_sf_desc* d;
+    int32_t* row;              // first sample of the row; empty slots point at out[0] (read, never written)
+    uint32_t n, order, shift, wasted, decor, lim_log2;
+    bool pair_ok;
+};
 
-    int32_t y[CLX_BLK];
-    // one block of CLX_BLK samples: x (residuals / warm-up samples) -> y (final samples of this channel)
-    auto compute = [&](const int32_t (&cur)[CLX_BLK], uint32_t t0) __attribute__((always_inline)) {
-        bool done = false;
+// The recurrence of one row, a block of CLX_BLK samples at a time: 24-bit fast evaluation with a range check, exact i64
+// re-run of a block that leaves the proven range (see the header comment of this section).
+template <int OMAX>
+struct K2Predictor {
+    int32_t c[OMAX], hist[OMAX];
+    int32_t lim;
+    uint32_t n, order, shift;
+    bool trivial, h_ok;
+    __device__ __forceinline__ void init(const K2Slot& S) {
+        n = S.n; order = S.order; shift = S.shift;
+#pragma unroll
+        for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)S.d->coef[j] : 0; hist[j] = 0; }
+        // |s| <= lim proves the i32/i24 evaluation exact; lanes K1 could not prove (lim_log2 = 0xff) force the wide path
+        // (range is [-lim, lim-1]: the 24-bit signed factor range when lim = 2^23)
+        lim = (S.lim_log2 <= 23u) ? (int32_t)(1u << S.lim_log2) : -1;
+        trivial = (n == 0u) || (order == 0u);                 // nothing is predicted: any evaluation is exact
+        h_ok = (lim >= 0) || trivial;
+    }
+    // x: residuals / warm-up samples of samples t0 .. t0+15  ->  y: the channel's samples before shift / decorrelation
+    // hook(i), i = 0..15, is called exactly once per block, after sample i of the first evaluation
+    template <typename Hook>
+    __device__ __forceinline__ void block(const int32_t (&x)[CLX_BLK], int32_t (&y)[CLX_BLK], uint32_t t0, Hook&& hook) {
+        bool done = false, hooked = false;
         if (__all(h_ok)) {
+            hooked = true;
             int32_t h0[OMAX];
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) h0[j] = hist[j];
-            if (t0 < (uint32_t)OMAX) clx_iir_block<OMAX, false, true>(cur, y, hist, c, t0, order, shift);
-            else                     clx_iir_block<OMAX, false, false>(cur, y, hist, c, t0, order, shift);      // every lane is past its warm-up
+            if (t0 < (uint32_t)OMAX) clx_iir_block<OMAX, false, true>(x, y, hist, c, t0, order, shift, hook);
+            else                     clx_iir_block<OMAX, false, false>(x, y, hist, c, t0, order, shift, hook);      // every lane is past its warm-up
             int32_t mx = y[0], mn = y[0];
 #pragma unroll
             for (int i = 1; i + 1 < CLX_BLK; i += 2) { mx = clx_max3(mx, y[i], y[i + 1]); mn = clx_min3(mn, y[i], y[i + 1]); }
@@ -597,178 +601,290 @@ __device__ __forceinline__ void clx_predict_rows(int4 (*ring)[4][64], int32_t* _
             }
         }
         if (!done) {
-            clx_iir_block<OMAX, true, true>(cur, y, hist, c, t0, order, shift);
+            if (hooked) clx_iir_block<OMAX, true, true>(x, y, hist, c, t0, order, shift, K2NoHook());
+            else        clx_iir_block<OMAX, true, true>(x, y, hist, c, t0, order, shift, hook);
             bool ok = lim >= 0;
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) ok = ok && hist[j] < lim && hist[j] >= -lim;
             h_ok = ok || trivial || t0 + CLX_BLK >= n;
         }
-        // wasted-bits shift (subframe.rs:216-225) and stereo decorrelation (frame.rs:319-389) on the finished block
+    }
+};
+
+// wasted-bits shift (subframe.rs:216-225) and stereo decorrelation (frame.rs:319-389) of a finished block
+struct K2Finisher {
+    uint32_t wasted, sgn, rmask, s1, bit, sg;
+    bool p_other, r_other, any_decor, all_ms, any_wasted;
+    __device__ __forceinline__ void init(const K2Slot& S, int lane) {
+        const bool odd = (lane & 1) != 0;
+        wasted = S.wasted;
+        sgn = odd ? 0xffffffffu : 0u;                          // (x ^ sgn) - sgn = odd ? -x : x
+        // per-lane constants of the generic formula  v = ((P << s1 | R & bit) + (R ^ sg) - sg) >> s1
+        //   mid/side  even: P = mid (mine),  R = side (other), s1 = 1              frame.rs:382-384
+        //             odd : P = mid (other), R = side (mine),  s1 = 1, minus
+        //   left/side odd : right = left (other) - side (mine)                     frame.rs:327-330
+        //   right/side even: left = side (mine) + right (other)                    frame.rs:352-355
+        //   anything else : v = mine
+        const bool d_ms = S.pair_ok && S.decor == CLX_CH_MID_SIDE;
+        const bool d_ls = S.pair_ok && S.decor == CLX_CH_LEFT_SIDE && odd;
+        const bool d_rs = S.pair_ok && S.decor == CLX_CH_RIGHT_SIDE && !odd;
+        p_other = (d_ms && odd) || d_ls;
+        r_other = (d_ms && !odd) || d_rs;
+        rmask = (d_ms || d_ls || d_rs) ? 0xffffffffu : 0u;
+        s1 = d_ms ? 1u : 0u; bit = s1;
+        sg = ((d_ms && odd) || d_ls) ? 0xffffffffu : 0u;
+        any_decor = __any(S.decor != CLX_CH_INDEPENDENT && S.pair_ok);
+        // the common case gets a shorter instruction sequence; empty slots (the tail of the last wave) do not spoil it
+        all_ms = __all(S.n == 0u || d_ms);
+        any_wasted = __any(wasted != 0u);
+    }
+    // hook(i), i = 0..15, is called exactly once, after sample i is finished.  MODE (wave-uniform, picked once per
+    // wave so that no branch surrounds the hook's memory instructions -- hipcc answers a memory operation under a
+    // branch with s_waitcnt vmcnt(0), which would drain the prefetch ring): 0 all mid/side, 1 mixed, 2 no decorrelation
+    template <int MODE, typename Hook>
+    __device__ __forceinline__ void block(int32_t (&y)[CLX_BLK], Hook&& hook) const {
         if (any_wasted) {
 #pragma unroll
             for (int i = 0; i < CLX_BLK; ++i) y[i] = (int32_t)((uint32_t)y[i] << wasted);
         }
-        if (all_ms) {
-            // every lane belongs to a mid/side pair: two DPP broadcasts give (mid, side) to both lanes of the pair
 #pragma unroll
-            for (int i = 0; i < CLX_BLK; ++i) {
+        for (int i = 0; i < CLX_BLK; ++i) {
+            if (MODE == 0) {
+                // every lane belongs to a mid/side pair: two DPP broadcasts give (mid, side) to both lanes of the pair
                 const int32_t mid = __builtin_amdgcn_update_dpp(0, y[i], 0xA0, 0xF, 0xF, false);     // quad_perm [0,0,2,2]
                 const int32_t side = __builtin_amdgcn_update_dpp(0, y[i], 0xF5, 0xF, 0xF, false);    // quad_perm [1,1,3,3]
                 const uint32_t m = ((uint32_t)mid << 1) | ((uint32_t)side & 1u);
                 // left = (m + side) >> 1, right = (m - side) >> 1 (frame.rs:382-384; m +- side is even)
                 y[i] = (int32_t)(m + (((uint32_t)side ^ sgn) - sgn)) >> 1;
-            }
-        } else if (any_decor) {
-            // mixed wave: one branch-free formula with per-lane constants (set up once, below) covers every role
-            //   v = ((P << s1 | Q & bit) + (R ^ sg) - sg) >> s1
-            //   mid/side  even: P = mid (mine),  Q = R = side (other), s1 = 1          frame.rs:382-384
-            //             odd : P = mid (other), Q = R = side (mine),  s1 = 1, minus
-            //   left/side odd : right = left (other) - side (mine)                     frame.rs:327-330
-            //   right/side even: left = side (mine) + right (other)                    frame.rs:352-355
-            //   anything else : v = mine
-#pragma unroll
-            for (int i = 0; i < CLX_BLK; ++i) {
+            } else if (MODE == 1) {
                 const int32_t mine = y[i];
                 const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);   // lane ^ 1
-                const uint32_t P = (uint32_t)(g_p_other ? other : mine);
-                const uint32_t R = (uint32_t)(g_r_other ? other : mine) & g_rmask;
-                const uint32_t m = (P << g_s1) | (R & g_bit);
-                y[i] = (int32_t)(m + ((R ^ g_sg) - g_sg)) >> g_s1;
+                const uint32_t P = (uint32_t)(p_other ? other : mine);
+                const uint32_t R = (uint32_t)(r_other ? other : mine) & rmask;
+                const uint32_t m = (P << s1) | (R & bit);
+                y[i] = (int32_t)(m + ((R ^ sg) - sg)) >> s1;
             }
+            hook(i);
         }
-    };
-    if (ALIGNED) {
-        // Memory side of the aligned path (tools/ubench/storeshape.hip, rowrmw.hip measure the shapes on MI355X):
-        // a store instruction whose 64 lanes write 16 B to 64 different rows moves 0.8 TB/s, the same bytes as 64 B to
-        // 16 rows move 3.9 TB/s -- the per-lane row walk is fine for the arithmetic but not for the memory pipeline.
-        // So a block (16 samples = 64 B of each of the wave's 64 rows = 4 KiB) crosses HBM as four instructions of
-        // "4 adjacent lanes = one row's 64 B, 16 rows", and is transposed to "lane = row" through a per-wave LDS tile:
-        //   in : global_load_lds_dwordx4 (LDS-DMA, no VGPRs, asynchronous) into a ring of DEPTH tiles; with one wave
-        //        per SIMD and ~2 us of memory latency the ring is what keeps DEPTH x 4 KiB per wave in flight
-        //   out: the lane writes its 64 B back into the tile it came from, four ds_read_b128 + global_store_dwordx4
-        //        take it out in the 64 B x 16 rows shape, then the next DMA refills the tile
-        // Tile layout: int4 [row][pos], pos = piece ^ ((row >> 2) & 3): both the lane = row view (64-byte stride) and the
-        // instruction view (contiguous) are LDS-bank-conflict free.
-        //   turn i: wait DMA(i+1) | read x(i+1) | compute(i) | y -> tile | 4x (ds_read, store) S(i) | DMA(i+DEPTH)
-        //   VMEM ops younger than DMA(i+1) when turn i waits: turns i+2-DEPTH .. i-1, 8 each = 8*(DEPTH-2)
-        constexpr int DEPTH = 8;
-        const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // this lane's row swizzle (lane = row view)
-        const uint32_t pc = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u);     // piece this lane moves (instruction view)
-        const int32_t* rp[4]; uint32_t rn[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                                                  // instruction k moves rows 16k .. 16k+15
-            const int src = k * 16 + (lane >> 2);
-            const uint64_t ro = __shfl((unsigned long long)(row - out), src, 64);
-            rp[k] = out + ro; rn[k] = __shfl(n, src, 64);
-        }
-        auto dma = [&](uint32_t blk) __attribute__((always_inline)) {
-            const uint32_t t = blk * CLX_BLK + 4u * pc;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t last = rn[k] >= 4u ? rn[k] - 4u : 0u;                  // clamped: what lies past a row's end is never stored
-                clx_glds16(rp[k] + (t < last ? t : last), clx_lds_addr(&ring[blk % DEPTH][k][0]));
-            }
-        };
-        auto fetch = [&](int32_t (&x)[CLX_BLK], uint32_t blk) __attribute__((always_inline)) {
-            const int4* tile = &ring[blk % DEPTH][0][0];
-#pragma unroll
-            for (uint32_t q = 0; q < 4u; ++q) {
-                const int4 w = tile[(uint32_t)lane * 4u + (q ^ sw)];
-                x[4 * q] = w.x; x[4 * q + 1] = w.y; x[4 * q + 2] = w.z; x[4 * q + 3] = w.w;
-            }
-        };
-        auto drain = [&](uint32_t blk) __attribute__((always_inline)) {
-            int4* tile = &ring[blk % DEPTH][0][0];
-#pragma unroll
-            for (uint32_t q = 0; q < 4u; ++q) tile[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-            clx_wave_sync();
-            const uint32_t t = blk * CLX_BLK + 4u * pc;
-            int4 w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = ring[blk % DEPTH][k][lane];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int32_t* p = t < rn[k] ? const_cast<int32_t*>(rp[k]) + t : dump + 4 * k;
-                *reinterpret_cast<int4*>(p) = w[k];
-            }
-            clx_wait_lds();                      // the tile has been read: the DMA may overwrite it
-        };
-        const uint32_t nblk = (nmax + CLX_BLK - 1u) / CLX_BLK;
-        int32_t xa[CLX_BLK], xb[CLX_BLK];
-        for (uint32_t i = 0; i < (uint32_t)DEPTH; ++i) dma(i);
-        clx_wait_vmcnt<4 * (DEPTH - 1)>();
-        clx_wave_sync();
-        fetch(xa, 0u);
-        // two turns per trip so that the "current" and "next" blocks alternate between xa and xb without copies
-        auto turn = [&](int32_t (&xc)[CLX_BLK], int32_t (&xn)[CLX_BLK], uint32_t i) __attribute__((always_inline)) {
-            if (i + 2u <= (uint32_t)DEPTH) clx_wait_vmcnt<4 * (DEPTH - 2)>(); else clx_wait_vmcnt<8 * (DEPTH - 2)>();
-            clx_wave_sync();
-            fetch(xn, i + 1u);
-            compute(xc, i * CLX_BLK);
-            drain(i);
-            dma(i + DEPTH);
-        };
-        for (uint32_t i = 0; i < nblk; i += 2u) { turn(xa, xb, i); turn(xb, xa, i + 1u); }
-        clx_wait_vmcnt<0>();
-    } else {
-        // rows that are not 16-byte aligned / a multiple of 4 samples long: per-lane element accesses, three row buffers
-        // rotating through a loop unrolled by three (the block computed in turn t was requested in turn t-2)
-        int32_t bufA[CLX_BLK], bufB[CLX_BLK], bufC[CLX_BLK];
-        clx_row_load<false>(row, 0u, n, bufA);
-        clx_row_load<false>(row, CLX_BLK, n, bufB);
-        for (uint32_t t0 = 0; t0 < nmax; t0 += 3u * CLX_BLK) {
-            clx_row_load<false>(row, t0 + 2u * CLX_BLK, n, bufC);
-            compute(bufA, t0); clx_row_store<false>(row, dump, t0, n, y);
-            clx_row_load<false>(row, t0 + 3u * CLX_BLK, n, bufA);
-            compute(bufB, t0 + CLX_BLK); clx_row_store<false>(row, dump, t0 + CLX_BLK, n, y);
-            clx_row_load<false>(row, t0 + 4u * CLX_BLK, n, bufB);
-            compute(bufC, t0 + 2u * CLX_BLK); clx_row_store<false>(row, dump, t0 + 2u * CLX_BLK, n, y);
-        }
+    }
+    __device__ __forceinline__ int mode() const { return all_ms ? 0 : any_decor ? 1 : 2; }
+    template <typename Hook>
+    __device__ __forceinline__ void block(int32_t (&y)[CLX_BLK], Hook&& hook) const {
+        if (all_ms) block<0>(y, hook); else if (any_decor) block<1>(y, hook); else block<2>(y, hook);
+    }
+};
+
+// Rows that are not 16-byte aligned / a multiple of 4 samples long (block sizes that are not a multiple of 4, odd
+// sample offsets): one wave, per-lane element accesses, three row buffers rotating through a loop unrolled by three
+// (the block computed in turn t was requested in turn t-2).
+template <int OMAX>
+__device__ __forceinline__ void clx_predict_unaligned(const K2Slot& S, int32_t* __restrict__ dump, uint32_t nmax, int lane) {
+    K2Predictor<OMAX> P; P.init(S);
+    K2Finisher F; F.init(S, lane);
+    int32_t y[CLX_BLK];
+    int32_t bufA[CLX_BLK], bufB[CLX_BLK], bufC[CLX_BLK];
+    clx_row_load<false>(S.row, 0u, S.n, bufA);
+    clx_row_load<false>(S.row, CLX_BLK, S.n, bufB);
+    for (uint32_t t0 = 0; t0 < nmax; t0 += 3u * CLX_BLK) {
+        clx_row_load<false>(S.row, t0 + 2u * CLX_BLK, S.n, bufC);
+        P.block(bufA, y, t0, K2NoHook()); F.block(y, K2NoHook()); clx_row_store<false>(S.row, dump, t0, S.n, y);
+        clx_row_load<false>(S.row, t0 + 3u * CLX_BLK, S.n, bufA);
+        P.block(bufB, y, t0 + CLX_BLK, K2NoHook()); F.block(y, K2NoHook()); clx_row_store<false>(S.row, dump, t0 + CLX_BLK, S.n, y);
+        clx_row_load<false>(S.row, t0 + 4u * CLX_BLK, S.n, bufB);
+        P.block(bufC, y, t0 + 2u * CLX_BLK, K2NoHook()); F.block(y, K2NoHook()); clx_row_store<false>(S.row, dump, t0 + 2u * CLX_BLK, S.n, y);
     }
 }
 
-extern "C" __global__ __launch_bounds__(64)
-void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
-    const int lane = (int)threadIdx.x;
-    const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
-    uint32_t n = 0, order = 0, shift = 0, wasted = 0, decor = 0, lim_log2 = 0;
-    uint64_t base = 0;
-    const clx_sf_desc* d = &sfd[slot < n_slots ? slot : 0];
-    if (slot < n_slots) {
-        n = d->n; order = d->order; shift = d->shift; wasted = d->wasted; decor = d->decor; base = d->out_base;
-        lim_log2 = d->lim_log2;
+// ---- aligned rows: two waves per 64 rows -----------------------------------------------------------------------------
+// A lone wave issues one instruction every ~6 shader ticks (tools/ubench/valu_lat.hip), and K2 has only n_slots/64 waves
+// for 1024 SIMDs: the kernel's duration is ONE wave's instruction count.  So the per-sample work is split over two waves
+// of a workgroup that hand blocks over through LDS:
+//   wave 0 "predictor": x from the tile -> recurrence + range check -> y back into the tile          (~12 instr/sample)
+//   wave 1 "finisher" : y from the tile -> wasted shift, decorrelation -> tile -> HBM                 (~10 instr/sample)
+// Memory side (tools/ubench/storeshape.hip, rowrmw.hip measure the shapes on MI355X): a store instruction whose 64 lanes
+// write 16 B to 64 different rows moves 0.8 TB/s, 64 B to 16 rows moves 3.9 TB/s.  So a block (16 samples = 64 B of each
+// of the 64 rows = one 4 KiB tile) crosses HBM as four instructions of "4 adjacent lanes = one row's 64 B, 16 rows":
+//   in : global_load_lds_dwordx4 (LDS-DMA: no VGPRs, asynchronous, counted by the finisher's vmcnt) into a ring of
+//        DEPTH tiles -- with ~2 us of memory latency the ring is what keeps DEPTH x 4 KiB per workgroup in flight
+//   out: four ds_read_b128 + global_store_dwordx4 in the same shape; the tile is refilled two turns later
+// Tile layout: int4 [row][pos], pos = piece ^ ((row >> 2) & 3): both the lane = row view (64-byte stride) and the
+// instruction view (contiguous) are LDS-bank-conflict free.
+// Schedule (one workgroup barrier per turn; barrier i ends turn i; a tile is touched by one wave per turn):
+//   predictor, turn i: read x(i+1) | recurrence on x(i) | write y(i)
+//   finisher,  turn i: read y(i-1) | shift, decorrelate -- and between the samples: store block i-2 (held in registers),
+//                      DMA(i-2+DEPTH) into its tile | tile | transposed read of block i-1 | wait until DMA(i+2) landed
+// The finisher's memory instructions go out one at a time between the arithmetic: a burst of scattered 64-lane VMEM
+// instructions blocks the wave's issue for hundreds of cycles.  Its vmcnt counts 4 stores + 4 DMAs per turn, the turn's
+// last one a DMA (every turn, also the first two, whose stores go to the dump area): DMA(i+2), issued in turn
+// i+4-DEPTH, is followed by 8*(DEPTH-4) younger operations when turn i ends.
+#define CLX_K2_DEPTH 8
+
+// what a lane needs to move "its" 16 bytes of every tile: instruction k moves rows 16k .. 16k+15, 4 lanes per row
+struct K2Mover {
+    const int32_t* rp[4];
+    uint32_t rn[4];
+    uint32_t pc;               // which 16-byte piece of the row's 64 bytes this lane moves
+    __device__ __forceinline__ void init(const int32_t* out, const K2Slot& S, int lane) {
+        pc = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int src = k * 16 + (lane >> 2);
+            const uint64_t ro = __shfl((unsigned long long)(S.row - out), src, 64);
+            rp[k] = out + ro; rn[k] = __shfl(S.n, src, 64);
+        }
     }
-    if (n == 0u) { order = 0; shift = 0; wasted = 0; decor = 0; lim_log2 = 0; }
+};
+
+template <int OMAX>
+__device__ __forceinline__ void clx_predict_wave(int4 (*ring)[4][64], const K2Slot& S, uint32_t nblk, int lane CLX_TL_PARAM) {
+    constexpr int DEPTH = CLX_K2_DEPTH;
+    K2Predictor<OMAX> P; P.init(S);
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // this lane's row swizzle (lane = row view)
+    auto fetch = [&](int32_t (&x)[CLX_BLK], uint32_t blk) __attribute__((always_inline)) {
+        const int4* tile = &ring[blk % DEPTH][0][0];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const int4 w = tile[(uint32_t)lane * 4u + (q ^ sw)];
+            x[4 * q] = w.x; x[4 * q + 1] = w.y; x[4 * q + 2] = w.z; x[4 * q + 3] = w.w;
+        }
+    };
+    int32_t xa[CLX_BLK], xb[CLX_BLK], y[CLX_BLK];
+    clx_wg_barrier();                          // tiles 0 and 1 have landed
+    fetch(xa, 0u);
+    // two turns per trip so that the "current" and "next" blocks alternate between xa and xb without copies
+    auto turn = [&](int32_t (&xc)[CLX_BLK], int32_t (&xn)[CLX_BLK], uint32_t i) __attribute__((always_inline)) {
+        if (i < nblk) {
+            fetch(xn, i + 1u);
+            P.block(xc, y, i * CLX_BLK, K2NoHook());
+            int4* tile = &ring[i % DEPTH][0][0];
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) tile[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        }
+        CLX_TL_WAIT(clx_wg_barrier());
+    };
+    // nblk + 2 barriers after the first one, matched by the finisher (which lags: it stores block i-2 in turn i)
+    const uint32_t nturn = nblk + 2u;
+    for (uint32_t i = 0; i < nturn; i += 2u) { turn(xa, xb, i); if (i + 1u < nturn) turn(xb, xa, i + 1u); }
+}
+
+template <int MODE>
+__device__ __forceinline__ void clx_finish_wave(int4 (*ring)[4][64], int4 (*scratch)[64], int32_t* __restrict__ out, const K2Slot& S,
+                                                const K2Finisher& F, int32_t* __restrict__ dump, uint32_t nblk, int lane CLX_TL_PARAM) {
+    constexpr int DEPTH = CLX_K2_DEPTH;
+    K2Mover M; M.init(out, S, lane);
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // lane = row view
+    auto dma1 = [&](uint32_t blk, int k) __attribute__((always_inline)) {
+        const uint32_t t = blk * CLX_BLK + 4u * M.pc;
+        const uint32_t last = M.rn[k] >= 4u ? M.rn[k] - 4u : 0u;                  // clamped: what lies past a row's end is never stored
+        clx_glds16(M.rp[k] + (t < last ? t : last), clx_lds_addr(&ring[blk % DEPTH][k][0]));
+    };
+    for (uint32_t i = 0; i + 2u < (uint32_t)DEPTH; ++i) {                          // tiles 0 .. DEPTH-3; turn i refills with block i-2+DEPTH
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma1(i, k);
+    }
+    clx_wait_vmcnt<4 * (DEPTH - 4)>();         // tiles 0 and 1
+    clx_wg_barrier();
+    // block i-2 in the instruction view, read from its tile at the end of turn i-1
+    int4 w0 = make_int4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+    const uint32_t nturn = nblk + 2u;
+    // The loop body is one straight line: turns that have nothing to finish (the first, the last) work on a scratch tile,
+    // turns that have nothing to store (the first two) store to the dump area.
+    for (uint32_t i = 0; i < nturn; ++i) {
+        const bool have_store = i >= 2u;                       // (i - 2 < nblk always holds inside the loop)
+        const bool have_block = i >= 1u && i <= nblk;
+        const uint32_t t_st = (i - 2u) * CLX_BLK + 4u * M.pc;
+        int4* const tile = have_block ? &ring[(i - 1u) % DEPTH][0][0] : &scratch[0][0];
+        int32_t y[CLX_BLK];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const int4 v = tile[(uint32_t)lane * 4u + (q ^ sw)];
+            y[4 * q] = v.x; y[4 * q + 1] = v.y; y[4 * q + 2] = v.z; y[4 * q + 3] = v.w;
+        }
+        // (w0..w3 are separate variables and the hook spells its four cases out: an array indexed by smp >> 2 is
+        //  sent to scratch memory, whose loads would both drain the ring -- vmcnt(0) -- and break the vmcnt count)
+        auto move = [&](int k, const int4& wk) __attribute__((always_inline)) {
+            int32_t* p = (have_store && t_st < M.rn[k]) ? const_cast<int32_t*>(M.rp[k]) + t_st : dump + 4 * k;
+            *reinterpret_cast<int4*>(p) = wk;
+            dma1(i - 2u + DEPTH, k);
+        };
+        F.template block<MODE>(y, [&](int smp) __attribute__((always_inline)) {
+            if (smp == 1) move(0, w0); else if (smp == 5) move(1, w1); else if (smp == 9) move(2, w2); else if (smp == 13) move(3, w3);
+        });
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) tile[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        clx_wave_sync();
+        w0 = tile[lane]; w1 = tile[64 + lane]; w2 = tile[128 + lane]; w3 = tile[192 + lane];
+        if (i + 5u <= (uint32_t)DEPTH) clx_wait_vmcnt<4 * (DEPTH - 3)>(); else clx_wait_vmcnt<8 * (DEPTH - 4)>();
+        CLX_TL_WAIT(clx_wg_barrier());                       // (also waits for the LDS reads: the next turn's DMA may refill the tile)
+    }
+    clx_wait_vmcnt<0>();
+}
+
+// Workgroup = 4 waves = two (predictor, finisher) pairs, 64 rows each.  Four waves so that a workgroup fills the four
+// SIMDs of its CU by construction: with two-wave workgroups, CUs that receive two workgroups sometimes get both
+// predictors on ONE SIMD (measured with tools/timeline.py: 245 us against 170 us for an undisturbed pair, and the
+// kernel lasts as long as its slowest wave).  The pairs share nothing but the barrier.
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    CLX_TL_BEGIN();
+    __shared__ int4 ring2[2][CLX_K2_DEPTH][4][64];    // per pair 32 KiB: 8 tiles x 64 B of each of its 64 rows
+    __shared__ int4 scratch2[2][4][64];               // per pair a tile nobody reads, for the finisher's idle turns
+    const int lane = (int)threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t pair = wave & 1u;
+    const bool finisher = wave >= 2u;              // wave-uniform
+    int4 (*ring)[4][64] = ring2[pair];
+    int4 (*scratch)[64] = scratch2[pair];
+    const uint32_t group = blockIdx.x * 2u + pair;
+    const uint32_t slot = group * 64u + (uint32_t)lane;
+    K2Slot S;
+    S.d = &sfd[slot < n_slots ? slot : 0];
+    S.n = 0; S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0;
+    uint64_t base = 0;
+    if (slot < n_slots) {
+        S.n = S.d->n; S.order = S.d->order; S.shift = S.d->shift; S.wasted = S.d->wasted; S.decor = S.d->decor; base = S.d->out_base;
+        S.lim_log2 = S.d->lim_log2;
+    }
+    if (S.n == 0u) { S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0; base = 0; }
+    S.row = out + base;
     // a decorrelated pair is only formed when both of its subframes decoded (same block size, same mode)
-    const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n, 0xB1, 0xF, 0xF, false);
-    const uint32_t pd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)decor, 0xB1, 0xF, 0xF, false);
-    const bool pair_ok = (decor != CLX_CH_INDEPENDENT) && pn == n && pd == decor && n != 0u;
-    uint32_t nmax = n, omax = order;
+    const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.n, 0xB1, 0xF, 0xF, false);
+    const uint32_t pd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.decor, 0xB1, 0xF, 0xF, false);
+    S.pair_ok = (S.decor != CLX_CH_INDEPENDENT) && pn == S.n && pd == S.decor && S.n != 0u;
+    uint32_t nmax = S.n, omax = S.order;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
         uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
     }
-    CLX_TL_BEGIN();
-    __shared__ int4 ring[8][4][64];    // 32 KiB: 8 blocks x 64 B of each of the wave's 64 rows, filled by LDS-DMA
-    int32_t* const dump = dump_all + (size_t)(blockIdx.x * 64u + (uint32_t)lane) * CLX_BLK;      // 64 bytes per lane
-    const bool work = (order != 0u) || (wasted != 0u) || pair_ok;
-    // a wave of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits is already final
+    int32_t* const dump = dump_all + (size_t)(group * 64u + (uint32_t)lane) * CLX_BLK;      // 64 bytes per lane (finisher / unaligned only)
+    const bool work = (S.order != 0u) || (S.wasted != 0u) || S.pair_ok;
+    // rows of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits are already final
+    // (both waves of a pair see the same 64 slots, so every decision below is the same in both; a wave that returns
+    //  no longer takes part in the workgroup's barriers)
     if (nmax == 0u || !__any(work)) return;
     // 16-byte row accesses need 16-byte aligned rows whose length is a multiple of 4 samples
-    const bool al = (n == 0u) || ((((uintptr_t)(out + base)) & 15u) == 0u && (n & 3u) == 0u);
+    const bool al = (S.n == 0u) || ((((uintptr_t)S.row) & 15u) == 0u && (S.n & 3u) == 0u);
     if (__all(al)) {
-        if (omax <= 4u)       clx_predict_rows<4, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, true>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-    } else {
-        if (omax <= 4u)       clx_predict_rows<4, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 8u)  clx_predict_rows<8, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else if (omax <= 12u) clx_predict_rows<12, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
-        else                  clx_predict_rows<32, false>(ring, out, dump, d, n, order, shift, wasted, decor, pair_ok, lim_log2, nmax, lane);
+        const uint32_t nblk = (nmax + CLX_BLK - 1u) / CLX_BLK;
+        if (finisher) {
+            K2Finisher F; F.init(S, lane);
+            const int mode = F.mode();
+            if (mode == 0)      clx_finish_wave<0>(ring, scratch, out, S, F, dump, nblk, lane CLX_TL_ARG);
+            else if (mode == 1) clx_finish_wave<1>(ring, scratch, out, S, F, dump, nblk, lane CLX_TL_ARG);
+            else                clx_finish_wave<2>(ring, scratch, out, S, F, dump, nblk, lane CLX_TL_ARG);
+        }
+        else if (omax <= 4u)  clx_predict_wave<4>(ring, S, nblk, lane CLX_TL_ARG);
+        else if (omax <= 8u)  clx_predict_wave<8>(ring, S, nblk, lane CLX_TL_ARG);
+        else if (omax <= 12u) clx_predict_wave<12>(ring, S, nblk, lane CLX_TL_ARG);
+        else                  clx_predict_wave<32>(ring, S, nblk, lane CLX_TL_ARG);
+    } else if (!finisher) {
+        if (omax <= 4u)       clx_predict_unaligned<4>(S, dump, nmax, lane);
+        else if (omax <= 8u)  clx_predict_unaligned<8>(S, dump, nmax, lane);
+        else if (omax <= 12u) clx_predict_unaligned<12>(S, dump, nmax, lane);
+        else                  clx_predict_unaligned<32>(S, dump, nmax, lane);
     }
-    CLX_TL_END(1, blockIdx.x);
+    CLX_TL_END(1, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -70,4 +70,7 @@ __device__ __forceinline__ void clx_wait_lds() { asm volatile("s_waitcnt lgkmcnt
 // wave-level ordering point for LDS traffic of a one-wave workgroup: no instruction, only stops the compiler from
 // moving LDS accesses across it (the LDS queue itself is in order per wave)
 __device__ __forceinline__ void clx_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// workgroup barrier for waves that hand LDS data to each other, without the fences of __syncthreads() (hipcc drains
+// vmcnt(0) there, which would stall the LDS-DMA prefetch ring): LDS writes are made visible by the lgkmcnt wait
+__device__ __forceinline__ void clx_wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif

@@ -27,5 +27,6 @@ static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {
 }
 template <int N> static inline void clx_wait_vmcnt() {}
 static inline void clx_wait_lds() {}
-#define clx_wave_sync() __syncthreads()
+#define clx_wave_sync() ((void)__ballot(1))     // a per-wave rendezvous (a block barrier would pair up with the other wave)
+#define clx_wg_barrier() __syncthreads()
 #endif

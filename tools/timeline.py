@@ -18,12 +18,12 @@ for _ in range(5):
     batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), 0)
 torch.cuda.synchronize()
 nslot_waves = (2 * n + 63) // 64
-kernels = [(0, "clx_k_residual", n), (1, "clx_k_predict", nslot_waves)] if path == "waves" else \
+kernels = [(0, "clx_k_residual", n), (1, "clx_k_predict", 4 * ((nslot_waves + 1) // 2))] if path == "waves" else \
           [(2, "clx_k_scan", (n + 63) // 64), (3, "clx_k_lanes", nslot_waves)]
 cx.lib().clx_debug_timeline.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
 for kid, name, nw in kernels:
     nw = min(nw, 65536)
-    tl = np.zeros((nw, 5), dtype=np.uint64)
+    tl = np.zeros((nw, 6), dtype=np.uint64)
     assert cx.lib().clx_debug_timeline(kid, tl.ctypes.data_as(C.c_void_p), nw) == 0
     tl = tl[tl[:, 1] != 0]
     r0, r1, c0, c1 = (tl[:, i].astype(np.int64) for i in range(4))
@@ -41,5 +41,20 @@ for kid, name, nw in kernels:
     uniq, cnt = np.unique(key, return_counts=True)
     print(f"   CUs used {uniq.size}; waves per CU min/max {cnt.min()}/{cnt.max()}; sum of wave time {dur_us.sum() / 1e3:.2f} ms"
           f" = {dur_us.sum() / end_us.max() :.0f} waves resident on average")
+    if tl[:, 5].any():
+        wt = tl[:, 5].astype(np.int64) / np.maximum(c1 - c0, 1)
+        print(f"   fraction of wave time inside instrumented waits: all {q(wt * 100)} %")
     for i in np.argsort(end_us)[-3:]:
         print(f"     wave {i}: start {start_us[i]:.1f} end {end_us[i]:.1f} us")
+    simd = (hwid >> 4) & 3
+    # how the waves of shared CUs sit on the SIMDs (a CU with k waves on fewer than min(k, 4) SIMDs makes them share issue slots)
+    from collections import Counter
+    shape = Counter()
+    for u in uniq[cnt > 1]:
+        sel = key == u
+        shape[tuple(sorted(np.bincount(simd[sel], minlength=4).tolist(), reverse=True))] += 1
+    print(f"   SIMD occupancy shapes of CUs with more than one wave: {dict(shape)}")
+    if name == "clx_k_predict":
+        for u in uniq[cnt > 2][:3]:
+            sel = np.nonzero(key == u)[0]
+            print("     CU", u, [(int(j), int(simd[j]), round(float(dur_us[j]), 1)) for j in sel])
