@@ -120,6 +120,20 @@ def main():
                 "step_achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / peak, 4)}
 
+    # achievable-copy ceiling of this box: device-to-device copy of 1 GiB, read + write bytes
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.int32, device=dev); dst = torch.empty_like(src)
+        dst.copy_(src); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        roofline["copy_ceiling"] = round(copy_gbs, 1)
+        roofline["frac_of_copy_ceiling"] = round(achieved / copy_gbs, 4)
+        del src, dst
+
     out = {
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

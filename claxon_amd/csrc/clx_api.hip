@@ -315,10 +315,11 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     }
     for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
     // path: explicit flag, else by batch shape -- the lane-serial kernels need many independent subframes to fill
-    // the machine (one lane each, ~1 wave-instruction per 4 cycles per wave); below that the wave-per-frame kernels
-    // are faster.  Measured crossover on MI355X: 20k subframes 1.80 ms (waves) vs 2.34 ms (lanes); 80k subframes
-    // 4.71 ms vs 3.47 ms.
-    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 40000);
+    // the machine (their duration is one lane's serial chain: ~1.9 ms for 4096-sample subframes however few there
+    // are, until every SIMD has a wave), the wave-per-frame kernels scale with the batch (0.73 ms per 10k stereo
+    // frames).  Measured crossover on MI355X: 50k subframes 1.61 ms (waves) vs 1.91 ms
+    // (lanes); 64k subframes 1.94 vs 1.88 ms; 80k subframes 2.51 vs 2.08 ms.
+    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 62000);
     if (!b->lanes) {
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
@@ -828,7 +829,7 @@ extern "C" void clx_reader_close(clx_reader* r) { delete r; }
 #ifdef CLX_TIMELINE
 // debug aid, see clx_device.h / tools/timeline.py: kernel 0 = residual, 1 = predict, 2 = scan, 3 = lanes
 extern "C" int clx_debug_timeline(int kernel, void* host, size_t n_waves) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clx_timeline_buf), n_waves * 6 * sizeof(uint64_t),
-                                    (size_t)kernel * CLX_TL_WAVES * 6 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clx_timeline_buf), n_waves * 14 * sizeof(uint64_t),
+                                    (size_t)kernel * CLX_TL_WAVES * 14 * sizeof(uint64_t), hipMemcpyDeviceToHost);
 }
 #endif

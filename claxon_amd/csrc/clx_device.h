@@ -45,8 +45,8 @@ static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
 // ended (s_memrealtime, 100 MHz), its shader clock ticks and where it ran.  Not part of the product build.
 #if defined(CLX_TIMELINE) && defined(__HIPCC__)
 #define CLX_TL_WAVES 65536
-__device__ uint64_t clx_timeline_buf[4][CLX_TL_WAVES][6];
-#define CLX_TL_BEGIN() const uint64_t tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime(); uint64_t tl_wait = 0; (void)tl_wait
+__device__ uint64_t clx_timeline_buf[4][CLX_TL_WAVES][14];
+#define CLX_TL_BEGIN() const uint64_t tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime(); uint64_t tl_wait = 0; (void)tl_wait; uint64_t tl_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t tl_mark = tl_c0; (void)tl_ph; (void)tl_mark
 #define CLX_TL_END(kid, wave) do { \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         if ((threadIdx.x & 63u) == 0 && (wave) < CLX_TL_WAVES) { \
@@ -55,14 +55,21 @@ __device__ uint64_t clx_timeline_buf[4][CLX_TL_WAVES][6];
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
             uint64_t* tl = clx_timeline_buf[kid][wave]; \
             tl[0] = tl_r0; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[2] = tl_c0; tl[3] = __builtin_amdgcn_s_memtime(); \
-            tl[4] = ((uint64_t)xcc << 32) | hwid; tl[5] = tl_wait; \
+            tl[4] = ((uint64_t)xcc << 32) | hwid; tl[5] = tl_wait; for (int tl_i = 0; tl_i < 8; ++tl_i) tl[6 + tl_i] = tl_ph[tl_i]; \
         } } while (0)
 #define CLX_TL_PARAM , uint64_t& tl_wait
 #define CLX_TL_ARG , tl_wait
+#define CLX_TL_PH_PARAM , uint64_t (&tl_ph)[8], uint64_t& tl_mark
+#define CLX_TL_PH_ARG , tl_ph, tl_mark
+/* ticks since the previous mark go to phase `i` */
+#define CLX_TL_PHASE(i) do { const uint64_t tl_n = __builtin_amdgcn_s_memtime(); tl_ph[i] += tl_n - tl_mark; tl_mark = tl_n; } while (0)
 #define CLX_TL_WAIT(stmt) do { const uint64_t tl_a = __builtin_amdgcn_s_memtime(); stmt; tl_wait += __builtin_amdgcn_s_memtime() - tl_a; } while (0)
 #else
 #define CLX_TL_PARAM
 #define CLX_TL_ARG
+#define CLX_TL_PH_PARAM
+#define CLX_TL_PH_ARG
+#define CLX_TL_PHASE(i) do {} while (0)
 #define CLX_TL_WAIT(stmt) do { stmt; } while (0)
 #define CLX_TL_BEGIN() do {} while (0)
 #define CLX_TL_END(kid, wave) do {} while (0)

@@ -147,8 +147,9 @@ __device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint3
 // output indices; (4) each lane extracts its codes (clz for the unary part, shift for the remainder)
 // into LDS, from where they are written to HBM coalesced.
 __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32_t k, uint32_t count,
-                                       int32_t* dst, uint32_t limit, uint32_t* err, int lane) {
+                                       int32_t* dst, uint32_t limit, uint32_t* err, int lane CLX_TL_PH_PARAM) {
     const uint32_t SC = k + 1u, ns = k + 2u;
+    CLX_TL_PHASE(5);                       // everything outside the residual decode: headers, warm-up, descriptors
     uint32_t done = 0;
     while (done < count) {
         const uint32_t remaining = count - done;
@@ -165,6 +166,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         uint32_t c = c_raw;
         if (B < 32u) c &= ~(0xffffffffu >> B);
 
+        CLX_TL_PHASE(0);                   // span set-up, window
         // (1) exit-state tables
         const uint32_t ex0 = clx_chunk_exit(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
@@ -179,6 +181,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             L.u.t.tab[g][lane] = packed;
         }
         __syncthreads();
+        CLX_TL_PHASE(1);                   // exit tables
         // (2a) group tables: lane (g8, e) walks group g8's 8 chunks for entry states e, e+8, ...
         {
             const uint32_t g8 = (uint32_t)lane >> 3;
@@ -208,6 +211,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                 m = (L.u.t.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
             }
         }
+        CLX_TL_PHASE(2);                   // three-level walk
         // (3) starts in my chunk
         uint32_t S = 0;
         {
@@ -226,6 +230,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         const uint32_t prefix = clx_wave_excl_scan(cnt, lane, &total);
         const uint32_t ntake = total < remaining ? total : remaining;
 
+        CLX_TL_PHASE(3);                   // starts + prefix sum
         // (4a) list the span-relative start position of every code (ascending inside a lane, lanes in order)
         {
             uint32_t Sit = S, idx = prefix;
@@ -256,6 +261,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             }
             newpos = clx_pick(e, owner, limit + 1u);
         } else newpos = pos + L.u.P[remaining];              // start of the first code that is not taken
+        CLX_TL_PHASE(4);                   // position list + the span's last code
         // (4c) extraction, balanced over the lanes and written straight to HBM (coalesced): code i has
         // q = start(i+1) - start(i) - 1 - k zeros and its k remainder bits end where code i+1 starts
         const uint32_t end_rel = newpos - pos;
@@ -272,6 +278,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         done += ntake;
         pos = newpos;
         __syncthreads();
+        CLX_TL_PHASE(6);                   // extraction + stores
     }
     return pos;
 }
@@ -425,7 +432,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                 if (!clx_hdr_bits(L, b, h, rice2 ? 5u : 4u, &v)) break;
                 if (v == (rice2 ? 31u : 15u)) { h.err = CLX_MKERR(CLX_UNSUPPORTED, CLX_MSG_UNENCODED_BINARY); break; }
                 uint32_t perr = CLX_ERR_NONE;
-                h.pos = clx_rice_partition(L, b, h.pos, v, len, chan + start, h.limit, &perr, lane);
+                h.pos = clx_rice_partition(L, b, h.pos, v, len, chan + start, h.limit, &perr, lane CLX_TL_PH_ARG);
                 if (perr != CLX_ERR_NONE) { h.err = perr; break; }
                 start += len;
                 len = per;
@@ -462,6 +469,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         r.end_bit = (uint64_t)(h.pos - o);
         results[f] = r;
     }
+    CLX_TL_PHASE(5);
     CLX_TL_END(0, blockIdx.x);
 }
 

@@ -23,7 +23,7 @@ kernels = [(0, "clx_k_residual", n), (1, "clx_k_predict", 4 * ((nslot_waves + 1)
 cx.lib().clx_debug_timeline.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
 for kid, name, nw in kernels:
     nw = min(nw, 65536)
-    tl = np.zeros((nw, 6), dtype=np.uint64)
+    tl = np.zeros((nw, 14), dtype=np.uint64)
     assert cx.lib().clx_debug_timeline(kid, tl.ctypes.data_as(C.c_void_p), nw) == 0
     tl = tl[tl[:, 1] != 0]
     r0, r1, c0, c1 = (tl[:, i].astype(np.int64) for i in range(4))
@@ -44,6 +44,9 @@ for kid, name, nw in kernels:
     if tl[:, 5].any():
         wt = tl[:, 5].astype(np.int64) / np.maximum(c1 - c0, 1)
         print(f"   fraction of wave time inside instrumented waits: all {q(wt * 100)} %")
+    if tl[:, 6:14].any():
+        ph = tl[:, 6:14].astype(np.float64).sum(axis=0)
+        print('   phase shares of wave time %:', ' '.join(f'{v:.1f}' for v in ph / (c1 - c0).sum() * 100))
     for i in np.argsort(end_us)[-3:]:
         print(f"     wave {i}: start {start_us[i]:.1f} end {end_us[i]:.1f} us")
     simd = (hwid >> 4) & 3
