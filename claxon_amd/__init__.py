@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libclaxon_hip.so")
 
 OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
 CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)
-ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16, PATH_WAVES, PATH_LANES = 1, 2, 4, 8, 16
+ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16, PATH_WAVES, PATH_LANES, PCM_ON_DEVICE = 1, 2, 4, 8, 16, 32
 
 
 class ClaxonError(RuntimeError):
@@ -72,8 +72,8 @@ assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
 
 EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
-    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes",
-    "clx_batch_create", "clx_batch_run", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
+    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes", "clx_interleave",
+    "clx_batch_create", "clx_batch_run", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_reader_open", "clx_reader_new",
     "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames",
 ]
@@ -136,6 +136,8 @@ def lib():
     L.clx_batch_create.argtypes = [vp, vp, sz, vp, C.c_uint32, C.POINTER(vp)]
     L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_results.argtypes = [vp, vp]
+    L.clx_batch_interleave.argtypes = [vp, vp, vp, C.c_uint32, vp]
+    L.clx_interleave.argtypes = [vp, vp, vp, sz, vp, vp, vp, C.c_uint32, C.c_uint32]
     L.clx_batch_slots.restype = C.c_uint64
     L.clx_batch_slots.argtypes = [vp]
     L.clx_batch_set_profiling.argtypes = [vp, C.c_int]
@@ -323,6 +325,26 @@ class Context:
         self._check(st)
         return out, res
 
+    def interleave(self, planar, descs, out_offs, sample_bytes, results=None, pcm=None):
+        """One-shot interleave / narrow stage on host arrays: planar i32 -> channel-interleaved little-endian PCM of
+        `sample_bytes` bytes per sample (uint8 array, frame i at byte out_offs[i] * sample_bytes).  Frames whose
+        `results` status is not OK keep whatever `pcm` held."""
+        planar = np.ascontiguousarray(planar, dtype=np.int32)
+        descs = np.ascontiguousarray(descs, dtype=FRAME_DESC_DTYPE)
+        out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+        n = descs.size
+        total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+        assert planar.size >= total
+        if pcm is None:
+            pcm = np.zeros(total * sample_bytes, dtype=np.uint8)
+        assert pcm.dtype == np.uint8 and pcm.size >= total * sample_bytes
+        if results is not None:
+            results = np.ascontiguousarray(results, dtype=FRAME_RESULT_DTYPE)
+        st = lib().clx_interleave(self._h, _np_ptr(planar), _np_ptr(descs), n, _np_ptr(out_offs),
+                                  _np_ptr(results) if results is not None else None, _np_ptr(pcm), sample_bytes, 0)
+        self._check(st)
+        return pcm
+
     def decode_subframes(self, arena, offs, block_sizes, bps, out_offs, out=None):
         a = _u8(arena)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
@@ -365,6 +387,12 @@ class Batch:
         """d_arena_ptr / d_out_ptr: integer device addresses (e.g. torch tensor .data_ptr())."""
         st = lib().clx_batch_run(self._h, C.c_void_p(d_arena_ptr), arena_len, C.c_void_p(d_out_ptr),
                                  C.c_void_p(stream) if stream else None)
+        self.ctx._check(st)
+
+    def interleave(self, d_planar_ptr, d_pcm_ptr, sample_bytes, stream=0):
+        """Device-resident interleave / narrow stage after run(): integer device addresses, async on `stream`."""
+        st = lib().clx_batch_interleave(self._h, C.c_void_p(d_planar_ptr), C.c_void_p(d_pcm_ptr), sample_bytes,
+                                        C.c_void_p(stream) if stream else None)
         self.ctx._check(st)
 
     def results(self):

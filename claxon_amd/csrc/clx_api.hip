@@ -413,6 +413,20 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     return CLX_OK;
 }
 
+extern "C" int clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void* d_pcm, uint32_t sample_bytes, void* stream_) {
+    if (!b || !b->ctx) return CLX_API_ERROR;
+    clx_ctx* ctx = b->ctx;
+    if (b->n == 0) return CLX_OK;
+    if (!d_planar || !d_pcm || sample_bytes < 1u || sample_bytes > 4u) { ctx->last_error = "clx_batch_interleave: bad argument"; return CLX_API_ERROR; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : (b->last_stream ? b->last_stream : ctx->stream);
+    hipLaunchKernelGGL(clx_k_interleave, dim3((unsigned)b->n), dim3(256), 0, stream, d_planar,
+                       (const clx_dev_frame*)b->d_frames, (const clx_frame_result*)b->d_results, (uint32_t)b->n,
+                       (uint8_t*)d_pcm, sample_bytes);
+    HIP_TRY(ctx, hipGetLastError());
+    return CLX_OK;
+}
+
 extern "C" int clx_batch_results(clx_batch* b, clx_frame_result* results) {
     if (!b || !b->ctx || (b->n && !results)) return CLX_API_ERROR;
     clx_ctx* ctx = b->ctx;
@@ -475,6 +489,53 @@ extern "C" int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t aren
     }
     cleanup();
     return st;
+}
+
+extern "C" int clx_interleave(clx_ctx* ctx, const int32_t* planar, const clx_frame_desc* frames, size_t n,
+                              const uint64_t* out_sample_offsets, const clx_frame_result* results,
+                              void* pcm, uint32_t sample_bytes, uint32_t flags) {
+    if (!ctx) return CLX_API_ERROR;
+    if (n == 0) return CLX_OK;
+    if (!planar || !frames || !out_sample_offsets || !pcm || sample_bytes < 1u || sample_bytes > 4u) { ctx->last_error = "clx_interleave: bad argument"; return CLX_API_ERROR; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<clx_dev_frame> dev(n);
+    uint64_t n_slots = 0;
+    const long bad = clx_plan_frames(frames, n, out_sample_offsets, dev.data(), &n_slots);
+    if (bad >= 0) { ctx->last_error = "clx_interleave: invalid frame descriptor"; return CLX_API_ERROR; }
+    uint64_t len = 0;
+    for (size_t i = 0; i < n; ++i)
+        len = std::max<uint64_t>(len, out_sample_offsets[i] + (uint64_t)frames[i].n_channels * frames[i].block_size);
+    clx_dev_frame* d_frames = nullptr; clx_frame_result* d_res = nullptr; int32_t* d_planar = nullptr; uint8_t* d_pcm = nullptr;
+    auto cleanup = [&]() {
+        if (d_frames) (void)hipFree(d_frames);
+        if (d_res) (void)hipFree(d_res);
+        if (!(flags & CLX_OUT_ON_DEVICE) && d_planar) (void)hipFree(d_planar);
+        if (!(flags & CLX_PCM_ON_DEVICE) && d_pcm) (void)hipFree(d_pcm);
+    };
+    bool ok = hip_ok(ctx, hipMalloc((void**)&d_frames, n * sizeof(clx_dev_frame)), "hipMalloc frames") &&
+              hip_ok(ctx, hipMemcpyAsync(d_frames, dev.data(), n * sizeof(clx_dev_frame), hipMemcpyHostToDevice, ctx->stream), "H2D frames");
+    if (ok && results) ok = hip_ok(ctx, hipMalloc((void**)&d_res, n * sizeof(clx_frame_result)), "hipMalloc results") &&
+                            hip_ok(ctx, hipMemcpyAsync(d_res, results, n * sizeof(clx_frame_result), hipMemcpyHostToDevice, ctx->stream), "H2D results");
+    if (ok) {
+        if (flags & CLX_OUT_ON_DEVICE) d_planar = const_cast<int32_t*>(planar);
+        else ok = hip_ok(ctx, hipMalloc((void**)&d_planar, std::max<uint64_t>(len, 1) * 4), "hipMalloc planar") &&
+                  hip_ok(ctx, hipMemcpyAsync(d_planar, planar, len * 4, hipMemcpyHostToDevice, ctx->stream), "H2D planar");
+    }
+    if (ok) {
+        if (flags & CLX_PCM_ON_DEVICE) d_pcm = (uint8_t*)pcm;
+        else ok = hip_ok(ctx, hipMalloc((void**)&d_pcm, std::max<uint64_t>(len, 1) * sample_bytes), "hipMalloc pcm") &&
+                  // bytes of skipped frames come back as the caller left them
+                  hip_ok(ctx, hipMemcpyAsync(d_pcm, pcm, len * sample_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D pcm");
+    }
+    if (ok) {
+        hipLaunchKernelGGL(clx_k_interleave, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_planar, d_frames, d_res, (uint32_t)n, d_pcm, sample_bytes);
+        ok = hip_ok(ctx, hipGetLastError(), "clx_k_interleave");
+    }
+    if (ok && !(flags & CLX_PCM_ON_DEVICE))
+        ok = hip_ok(ctx, hipMemcpyAsync(pcm, d_pcm, len * sample_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H pcm");
+    if (ok) ok = hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync");
+    cleanup();
+    return ok ? CLX_OK : CLX_API_ERROR;
 }
 
 extern "C" int clx_decode_subframes(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,

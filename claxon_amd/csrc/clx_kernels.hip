@@ -959,3 +959,48 @@ void clx_k_crc16(const uint8_t* __restrict__ arena, const clx_dev_frame* __restr
         if (contrib != presumed) { results[f].status = CLX_FORMAT_ERROR; results[f].msg = CLX_MSG_FRAME_CRC_MISMATCH; }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// K4: interleave / narrow output stage.  What every caller of the reference does right after the
+// hot path: walk the block channel-interleaved (FlacSamples, lib.rs:473-520; Block::stereo_samples -> i16 WAV,
+// examples/decode.rs:48-62).  Frame f's planar samples planar[out_off + c*bs + i] become little-endian two's
+// complement PCM of `sb` bytes per sample at byte (out_off + i*C + c) * sb of `dst` -- the byte order the STREAMINFO
+// MD5 is defined over (metadata.rs:52-53).  Frames that failed to decode are skipped (they expose nothing).
+// One workgroup per frame; HBM-bound: reads 4 B, writes sb B per sample, both coalesced on the common shapes.
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_interleave(const int32_t* __restrict__ planar, const clx_dev_frame* __restrict__ frames,
+                      const clx_frame_result* __restrict__ results, uint32_t n_frames,
+                      uint8_t* __restrict__ dst, uint32_t sb) {
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames) return;
+    if (results && results[f].status != CLX_OK) return;
+    const clx_dev_frame fr = frames[f];
+    const uint32_t C = fr.n_channels, bs = fr.block_size;
+    const int32_t* __restrict__ src = planar + fr.out_off;
+    uint8_t* __restrict__ d = dst + fr.out_off * (uint64_t)sb;
+    const bool even = (fr.out_off & 1ull) == 0ull && ((uintptr_t)dst & 7u) == 0u;
+    if (C == 2u && sb == 2u && even) {                 // 16-bit stereo: one dword per sample pair
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(d);
+        for (uint32_t i = threadIdx.x; i < bs; i += 256u)
+            d32[i] = ((uint32_t)src[i] & 0xffffu) | ((uint32_t)src[bs + i] << 16);
+    } else if (C == 2u && sb == 4u && even) {
+        int2* d64 = reinterpret_cast<int2*>(d);
+        for (uint32_t i = threadIdx.x; i < bs; i += 256u) d64[i] = make_int2(src[i], src[bs + i]);
+    } else if (sb == 4u && ((uintptr_t)dst & 3u) == 0u) {
+        int32_t* d32 = reinterpret_cast<int32_t*>(d);
+        for (uint32_t i = threadIdx.x; i < bs; i += 256u)
+            for (uint32_t c = 0; c < C; ++c) d32[i * C + c] = src[c * bs + i];
+    } else if (sb == 2u && ((uintptr_t)dst & 1u) == 0u) {
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(d);
+        for (uint32_t i = threadIdx.x; i < bs; i += 256u)
+            for (uint32_t c = 0; c < C; ++c) d16[i * C + c] = (uint16_t)src[c * bs + i];
+    } else {                                           // 8 / 24-bit packing, odd alignments: byte stores
+        for (uint32_t i = threadIdx.x; i < bs; i += 256u)
+            for (uint32_t c = 0; c < C; ++c) {
+                const uint32_t v = (uint32_t)src[c * bs + i];
+                uint8_t* q = d + (size_t)(i * C + c) * sb;
+                for (uint32_t k = 0; k < sb; ++k) q[k] = (uint8_t)(v >> (8u * k));
+            }
+    }
+}

@@ -172,7 +172,8 @@ enum {
      * LANES: one lane per subframe, lane-serial fused decode (highest throughput for many frames;
      *        needs arena_len < 4 GiB). */
     CLX_PATH_WAVES      = 1u << 3,
-    CLX_PATH_LANES      = 1u << 4
+    CLX_PATH_LANES      = 1u << 4,
+    CLX_PCM_ON_DEVICE   = 1u << 5    /* clx_interleave: `pcm` is a device pointer (else host; copied D2H) */
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32
@@ -182,6 +183,12 @@ int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,
                       const clx_frame_desc* frames, size_t n,
                       int32_t* out, const uint64_t* out_sample_offsets,
                       clx_frame_result* results, uint32_t flags);
+
+/* One-shot interleave / narrow stage (see clx_batch_interleave).  `planar` follows CLX_OUT_ON_DEVICE, `pcm`
+ * CLX_PCM_ON_DEVICE; `results` (may be NULL) marks frames to skip (status != CLX_OK). */
+int clx_interleave(clx_ctx* ctx, const int32_t* planar, const clx_frame_desc* frames, size_t n,
+                   const uint64_t* out_sample_offsets, const clx_frame_result* results,
+                   void* pcm, uint32_t sample_bytes, uint32_t flags);
 
 /* Config-2 entry: n independent byte-aligned SUBFRAMES (no frame header):
  * subframe i starts at arena[byte_offs[i]], decoded at bps[i] into
@@ -201,6 +208,12 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                    int32_t* d_out, void* stream);
 /* Blocks until the last run finished, then copies the per-frame results to host. */
 int  clx_batch_results(clx_batch* b, clx_frame_result* results);
+/* Interleave / narrow output stage on the planned frames (what callers of the reference do next: FlacSamples,
+ * lib.rs:473-520; Block::stereo_samples -> i16 WAV, examples/decode.rs:48-62).  Frame i's planar samples
+ * d_planar[off_i + c*bs + s] become little-endian two's-complement PCM of `sample_bytes` (1..4) bytes at byte
+ * (off_i + s*channels + c) * sample_bytes of d_pcm -- channel-interleaved, the order the STREAMINFO MD5 is defined
+ * over (metadata.rs:52-53).  Frames whose last run failed are skipped.  Async on `stream`, after clx_batch_run. */
+int  clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void* d_pcm, uint32_t sample_bytes, void* stream);
 /* Number of predictor slots (subframes incl. alignment padding) in the plan. */
 uint64_t clx_batch_slots(const clx_batch* b);
 /* Per-kernel HIP-event timing of the LAST run made with profiling enabled: kernels are numbered in

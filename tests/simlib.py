@@ -37,7 +37,25 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.sim_decode_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        _lib.sim_interleave.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     return _lib
+
+
+def interleave(planar, descs, out_offs, sample_bytes, results=None, pcm=None):
+    """K4 under simulation (same contract as claxon_amd.Context.interleave)."""
+    planar = np.ascontiguousarray(planar, dtype=np.int32)
+    descs = np.ascontiguousarray(descs, dtype=cx.FRAME_DESC_DTYPE)
+    out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+    n = descs.size
+    total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+    if pcm is None:
+        pcm = np.zeros(total * sample_bytes + 8, dtype=np.uint8)
+    if results is not None:
+        results = np.ascontiguousarray(results, dtype=cx.FRAME_RESULT_DTYPE)
+    st = lib().sim_interleave(planar.ctypes.data, descs.ctypes.data, n, out_offs.ctypes.data,
+                              results.ctypes.data if results is not None else None, pcm.ctypes.data, sample_bytes)
+    assert st == 0
+    return pcm[:total * sample_bytes]
 
 
 def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_only=False, fill=0, path=0):

@@ -37,3 +37,12 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
     return CLX_OK;
 }
+
+extern "C" int sim_interleave(const int32_t* planar, const clx_frame_desc* frames, size_t n, const uint64_t* out_offs,
+                              const clx_frame_result* results, uint8_t* pcm, uint32_t sample_bytes) {
+    std::vector<clx_dev_frame> dev(n ? n : 1);
+    uint64_t n_slots = 0;
+    if (clx_plan_frames(frames, n, out_offs, dev.data(), &n_slots) >= 0) return CLX_API_ERROR;
+    if (n) SIM_LAUNCH(clx_k_interleave, n, 256, planar, dev.data(), results, (uint32_t)n, pcm, sample_bytes);
+    return CLX_OK;
+}

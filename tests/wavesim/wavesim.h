@@ -218,6 +218,8 @@ static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned old = *p; i
 static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
 struct int4 { int x, y, z, w; } __attribute__((aligned(16)));
 static inline int4 make_int4(int a, int b, int c, int d) { int4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }
+struct int2 { int x, y; } __attribute__((aligned(8)));
+static inline int2 make_int2(int a, int b) { int2 v; v.x = a; v.y = b; return v; }
 
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
