@@ -75,7 +75,7 @@ EXPORTS = [
     "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes", "clx_interleave",
     "clx_batch_create", "clx_batch_run", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_reader_open", "clx_reader_new",
-    "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames",
+    "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames", "clx_index_frames_device",
 ]
 
 
@@ -137,6 +137,7 @@ def lib():
     L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_results.argtypes = [vp, vp]
     L.clx_batch_interleave.argtypes = [vp, vp, vp, C.c_uint32, vp]
+    L.clx_index_frames_device.argtypes = [vp, vp, sz, sz, vp, vp, sz, C.POINTER(sz), C.POINTER(sz), C.c_uint32]
     L.clx_interleave.argtypes = [vp, vp, vp, sz, vp, vp, vp, C.c_uint32, C.c_uint32]
     L.clx_batch_slots.restype = C.c_uint64
     L.clx_batch_slots.argtypes = [vp]
@@ -308,6 +309,19 @@ class Context:
     def _check(self, st):
         if st != OK:
             raise ClaxonError(st, 0, self.last_error())
+
+    def index_frames(self, data, start=0, cap=1 << 20):
+        """Device frame indexer: same contract as claxon_amd.index_frames (host), byte work on the GPU."""
+        a = _u8(data)
+        cap = max(1, min(cap, a.size // 8 + 2))
+        descs = np.zeros(cap, dtype=FRAME_DESC_DTYPE)
+        hdrs = np.zeros(cap, dtype=FRAME_HEADER_DTYPE)
+        n = C.c_size_t(0)
+        stop = C.c_size_t(0)
+        st = lib().clx_index_frames_device(self._h, _np_ptr(a), a.size, start, _np_ptr(descs), _np_ptr(hdrs), cap,
+                                           C.byref(n), C.byref(stop), 0)
+        self._check(st)
+        return descs[:n.value].copy(), hdrs[:n.value].copy(), int(stop.value)
 
     def decode_frames(self, arena, descs, out_offs, out=None, verify_crc=False, path=0):
         """One-shot host->device->host decode.  Returns (out int32, results np FRAME_RESULT_DTYPE)."""

@@ -678,6 +678,106 @@ extern "C" int clx_index_frames(const uint8_t* data, size_t len, size_t start_of
     return CLX_OK;
 }
 
+// Device frame indexer: same contract and same answer as clx_index_frames; the byte scan and the
+// CRC-16 of every byte run on the GPU (K5-K7 in clx_kernels.hip), the chain walk over the few candidates here.
+extern "C" int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t len, size_t start_off,
+                                       clx_frame_desc* descs, clx_frame_header* headers, size_t cap,
+                                       size_t* n_found, size_t* stop_off, uint32_t flags) {
+    if (!ctx) return CLX_API_ERROR;
+    if (!n_found || !stop_off || (!data && len) || (cap && !descs)) { ctx->last_error = "clx_index_frames_device: bad argument"; return CLX_API_ERROR; }
+    *n_found = 0; *stop_off = start_off;
+    if (start_off + 2 > len || cap == 0) return CLX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint8_t* d_data = nullptr; uint64_t* d_cand = nullptr; uint32_t* d_count = nullptr; uint8_t* d_hdr = nullptr;
+    uint64_t* d_pos = nullptr; uint16_t* d_crc = nullptr;
+    auto cleanup = [&]() {
+        if (!(flags & CLX_ARENA_ON_DEVICE) && d_data) (void)hipFree(d_data);
+        if (d_cand) (void)hipFree(d_cand);
+        if (d_count) (void)hipFree(d_count);
+        if (d_hdr) (void)hipFree(d_hdr);
+        if (d_pos) (void)hipFree(d_pos);
+        if (d_crc) (void)hipFree(d_crc);
+    };
+    auto fail_api = [&](const char* what) { if (what) ctx->last_error = what; cleanup(); return (int)CLX_API_ERROR; };
+    if (flags & CLX_ARENA_ON_DEVICE) d_data = const_cast<uint8_t*>(data);      // (16-byte aligned, padded like a decode arena)
+    else {
+        const size_t alloc = ((len + 15) & ~(size_t)15) + 32;
+        if (!hip_ok(ctx, hipMalloc((void**)&d_data, alloc), "hipMalloc stream") ||
+            !hip_ok(ctx, hipMemsetAsync(d_data + (alloc - 48), 0, 48, st), "memset") ||
+            !hip_ok(ctx, hipMemcpyAsync(d_data, data, len, hipMemcpyHostToDevice, st), "H2D stream")) return fail_api(nullptr);
+    }
+    // ---- K5: candidates
+    const uint64_t scan0 = (uint64_t)start_off & ~15ull;
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((len - scan0) / 16 + 4096, 1u << 26);
+    if (!hip_ok(ctx, hipMalloc((void**)&d_cand, (size_t)cand_cap * 8), "hipMalloc candidates") ||
+        !hip_ok(ctx, hipMalloc((void**)&d_count, 4), "hipMalloc count") ||
+        !hip_ok(ctx, hipMemsetAsync(d_count, 0, 4, st), "memset")) return fail_api(nullptr);
+    const uint64_t n_threads = (len - scan0 + 15) / 16;
+    hipLaunchKernelGGL(clx_k_find_headers, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, st, d_data, (uint64_t)len,
+                       (uint64_t)start_off, d_cand, cand_cap, d_count);
+    uint32_t count = 0;
+    if (!hip_ok(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, st), "D2H count") ||
+        !hip_ok(ctx, hipStreamSynchronize(st), "sync")) return fail_api(nullptr);
+    if (count > cand_cap) return fail_api("clx_index_frames_device: candidate list overflow");
+    std::vector<uint64_t> cand(count);
+    if (count && (!hip_ok(ctx, hipMemcpyAsync(cand.data(), d_cand, (size_t)count * 8, hipMemcpyDeviceToHost, st), "D2H candidates") ||
+                  !hip_ok(ctx, hipStreamSynchronize(st), "sync"))) return fail_api(nullptr);
+    std::sort(cand.begin(), cand.end());
+    // ---- K7 + the authoritative host parse of every candidate
+    std::vector<uint64_t> pos; std::vector<clx_frame_header> hdr;
+    if (count) {
+        std::vector<uint8_t> bytes((size_t)count * 20);
+        if (!hip_ok(ctx, hipMalloc((void**)&d_hdr, bytes.size()), "hipMalloc headers") ||
+            !hip_ok(ctx, hipMemcpyAsync(d_cand, cand.data(), (size_t)count * 8, hipMemcpyHostToDevice, st), "H2D candidates")) return fail_api(nullptr);
+        hipLaunchKernelGGL(clx_k_gather_headers, dim3((count + 255) / 256), dim3(256), 0, st, d_data, (uint64_t)len, d_cand, count, d_hdr);
+        if (!hip_ok(ctx, hipMemcpyAsync(bytes.data(), d_hdr, bytes.size(), hipMemcpyDeviceToHost, st), "D2H headers") ||
+            !hip_ok(ctx, hipStreamSynchronize(st), "sync")) return fail_api(nullptr);
+        for (uint32_t i = 0; i < count; ++i) {
+            clx_frame_header h; uint32_t m;
+            const size_t avail = std::min<size_t>(20, len - (size_t)cand[i]);
+            if (clx_parse_frame_header(bytes.data() + (size_t)i * 20, avail, 1, &h, &m) == CLX_OK) { pos.push_back(cand[i]); hdr.push_back(h); }
+        }
+    }
+    if (pos.empty() || pos[0] != start_off) { cleanup(); return CLX_OK; }          // no frame starts at start_off
+    // ---- K6: CRC-16 of the span between consecutive candidates (the last one runs to the end of the stream)
+    const uint32_t m = (uint32_t)pos.size();
+    pos.push_back(len);
+    std::vector<uint16_t> crc(m);
+    if (!hip_ok(ctx, hipMalloc((void**)&d_pos, (size_t)(m + 1) * 8), "hipMalloc pos") ||
+        !hip_ok(ctx, hipMalloc((void**)&d_crc, (size_t)m * 2), "hipMalloc crc") ||
+        !hip_ok(ctx, hipMemcpyAsync(d_pos, pos.data(), (size_t)(m + 1) * 8, hipMemcpyHostToDevice, st), "H2D pos")) return fail_api(nullptr);
+    hipLaunchKernelGGL(clx_k_span_crc16, dim3(m), dim3(64), 0, st, d_data, d_pos, m, d_crc);
+    if (!hip_ok(ctx, hipMemcpyAsync(crc.data(), d_crc, (size_t)m * 2, hipMemcpyDeviceToHost, st), "D2H crc") ||
+        !hip_ok(ctx, hipStreamSynchronize(st), "sync")) return fail_api(nullptr);
+    cleanup();
+    // ---- chain: frame i ends at the first later candidate (or the end of the stream) e >= its header + 2 with
+    //      crc16([pos_i, e)) == 0, i.e. whose two preceding bytes are the frame's CRC-16
+    uint32_t cur = 0;
+    while (*n_found < cap && cur < m) {
+        uint32_t acc = 0, end = 0;
+        for (uint32_t j = cur + 1; j <= m; ++j) {
+            acc = clx_gf_mulmod(acc, clx_xpow8_64(pos[j] - pos[j - 1])) ^ crc[j - 1];
+            if (acc == 0u && pos[j] >= pos[cur] + hdr[cur].header_bytes + 2u) { end = j; break; }
+        }
+        if (!end) break;
+        clx_frame_desc& d = descs[*n_found];
+        std::memset(&d, 0, sizeof d);
+        d.byte_off = pos[cur];
+        d.max_bytes = (uint32_t)std::min<uint64_t>(len - pos[cur], 0xffffffffu);
+        d.header_bytes = hdr[cur].header_bytes;
+        d.block_size = hdr[cur].block_size;
+        d.n_channels = hdr[cur].n_channels;
+        d.channel_assignment = hdr[cur].channel_assignment;
+        d.bps = hdr[cur].bps;
+        if (headers) headers[*n_found] = hdr[cur];
+        ++*n_found;
+        cur = end;
+    }
+    *stop_off = (size_t)pos[cur];
+    return CLX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // claxon::FrameReader / FlacReader / Block (host/claxon.hpp) -- the reference's API surface
 // ------------------------------------------------------------------------------------------------
@@ -697,6 +797,8 @@ struct FrameReader::Impl {
     uint8_t* d_arena = nullptr;       // same bytes on the device, uploaded once
     size_t pos = 0;                   // next undecoded byte
     size_t batch_frames = 4096;
+    // frame index of the rest of the stream (speculative: confirmed frame by frame against the decode), and how far it is used
+    std::vector<clx_frame_desc> idx_descs; std::vector<clx_frame_header> idx_hdrs; size_t idx_next = 0;
     struct Pending { clx_frame_header hdr; int status; uint32_t msg; std::vector<int32_t> samples; };
     std::vector<Pending> queue;
     size_t qhead = 0;
@@ -726,10 +828,35 @@ static int fill_queue(FrameReader::Impl& I) {
         I.queue.push_back(std::move(p));
         return CLX_OK;
     }
-    std::vector<clx_frame_desc> descs(I.batch_frames);
-    std::vector<clx_frame_header> hdrs(I.batch_frames);
-    size_t n = 0, stop = 0;
-    clx_index_frames(data, len, I.pos, descs.data(), hdrs.data(), I.batch_frames, &n, &stop);
+    auto upload = [&]() -> bool {
+        if (I.d_arena) return true;
+        if (hipSetDevice(I.ctx->device) != hipSuccess) return false;
+        const size_t alloc = ((len + 15) & ~(size_t)15) + 32;
+        if (hipMalloc((void**)&I.d_arena, alloc) != hipSuccess) return false;
+        return hipMemset(I.d_arena, 0, alloc) == hipSuccess && hipMemcpy(I.d_arena, data, len, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (I.idx_next >= I.idx_descs.size() || I.idx_descs[I.idx_next].byte_off != I.pos) {
+        // (re)index from here: long remainders on the device in one go, short ones on the host a batch at a time
+        I.idx_next = 0;
+        size_t nf = 0, stop = 0;
+        if (len - I.pos >= (256u << 10)) {
+            if (!upload()) return CLX_API_ERROR;
+            const size_t cap = (len - I.pos) / 8 + 2;
+            I.idx_descs.resize(cap); I.idx_hdrs.resize(cap);
+            const int st = clx_index_frames_device(I.ctx, I.d_arena, len, I.pos, I.idx_descs.data(), I.idx_hdrs.data(), cap, &nf, &stop,
+                                                   CLX_ARENA_ON_DEVICE);
+            if (st != CLX_OK) return st;
+        } else {
+            I.idx_descs.resize(I.batch_frames); I.idx_hdrs.resize(I.batch_frames);
+            clx_index_frames(data, len, I.pos, I.idx_descs.data(), I.idx_hdrs.data(), I.batch_frames, &nf, &stop);
+        }
+        I.idx_descs.resize(nf); I.idx_hdrs.resize(nf);
+    }
+    size_t n = std::min(I.batch_frames, I.idx_descs.size() - I.idx_next);
+    std::vector<clx_frame_desc> descs(I.idx_descs.begin() + (ptrdiff_t)I.idx_next, I.idx_descs.begin() + (ptrdiff_t)(I.idx_next + n));
+    std::vector<clx_frame_header> hdrs(I.idx_hdrs.begin() + (ptrdiff_t)I.idx_next, I.idx_hdrs.begin() + (ptrdiff_t)(I.idx_next + n));
+    I.idx_next += n;
+    if (n == 0) { descs.resize(1); hdrs.resize(1); }
     if (n == 0) {
         // the chain could not be confirmed from here: decode this one frame against the rest of the stream
         n = 1; hdrs[0] = h0;
@@ -750,11 +877,7 @@ static int fill_queue(FrameReader::Impl& I) {
     std::vector<int32_t> host_out(total);
     if (usable) {
         if (hipSetDevice(I.ctx->device) != hipSuccess) return CLX_API_ERROR;
-        if (!I.d_arena) {
-            const size_t alloc = ((len + 15) & ~(size_t)15) + 16;
-            if (hipMalloc((void**)&I.d_arena, alloc) != hipSuccess) return CLX_API_ERROR;
-            if (hipMemset(I.d_arena, 0, alloc) != hipSuccess || hipMemcpy(I.d_arena, data, len, hipMemcpyHostToDevice) != hipSuccess) return CLX_API_ERROR;
-        }
+        if (!upload()) return CLX_API_ERROR;
         if (hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * sizeof(int32_t)) != hipSuccess) return CLX_API_ERROR;
         int st = clx_decode_frames(I.ctx, I.d_arena, len, descs.data(), usable, d_out, offs.data(), results.data(),
                                    CLX_ARENA_ON_DEVICE | CLX_OUT_ON_DEVICE | CLX_VERIFY_CRC16);

@@ -908,7 +908,7 @@ __device__ __forceinline__ uint32_t clx_crc16_byte(uint32_t crc, uint32_t byte) 
     return crc;
 }
 // (a * b) mod P over GF(2), 16-bit polynomials
-__device__ __forceinline__ uint32_t clx_gf_mulmod(uint32_t a, uint32_t b) {
+__host__ __device__ __forceinline__ uint32_t clx_gf_mulmod(uint32_t a, uint32_t b) {
     uint32_t r = 0;
 #pragma unroll
     for (int i = 15; i >= 0; --i) {
@@ -923,6 +923,15 @@ __device__ __forceinline__ uint32_t clx_xpow8(uint32_t nbytes) {
     uint32_t base = 0x0100u;         // x^8
     while (nbytes) {
         if (nbytes & 1u) result = clx_gf_mulmod(result, base);
+        base = clx_gf_mulmod(base, base);
+        nbytes >>= 1;
+    }
+    return result;
+}
+__host__ __device__ __forceinline__ uint32_t clx_xpow8_64(uint64_t nbytes) {
+    uint32_t result = 1u, base = 0x0100u;
+    while (nbytes) {
+        if (nbytes & 1ull) result = clx_gf_mulmod(result, base);
         base = clx_gf_mulmod(base, base);
         nbytes >>= 1;
     }
@@ -1003,4 +1012,91 @@ void clx_k_interleave(const int32_t* __restrict__ planar, const clx_dev_frame* _
                 for (uint32_t k = 0; k < sb; ++k) q[k] = (uint8_t)(v >> (8u * k));
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 / K6: frame indexer for raw streams (header grammar frame.rs:131-316; the reference has no resync,
+// frame.rs:601-602).  The byte work is data-parallel and lives here; the (tiny) chain logic lives in the host
+// (clx_index_frames_device, clx_api.hip), which also re-parses every candidate with the authoritative host parser.
+//   K5 clx_k_find_headers: every byte position is tested for "sync code + a header that obeys the grammar's length
+//      rules + matching CRC-8" (a superset of the valid headers); hits are appended to a list (unordered).
+//   K6 clx_k_span_crc16: CRC-16 (as K3) of the bytes between consecutive sorted candidates.  CRC-16 with init 0 and
+//      no final xor is linear and a frame followed by its own footer has CRC 0, so the host confirms a frame
+//      [p_i, p_j) by folding the spans in between: crc(A||B) = crc(A) * x^(8|B|) xor crc(B).
+// ------------------------------------------------------------------------------------------------
+// length of a CRC-8-valid frame header at d (including the CRC byte), 0 if there is none; reads < 17 bytes
+__device__ __forceinline__ uint32_t clx_header_probe(const uint8_t* __restrict__ d, uint64_t avail) {
+    if (avail < 6u) return 0u;
+    const uint32_t b2 = d[2], b3 = d[3], b4 = d[4];
+    const uint32_t bn = b2 >> 4, sn = b2 & 15u;
+    if (bn == 0u || sn == 15u) return 0u;
+    if ((b3 >> 4) > 10u || (b3 & 1u)) return 0u;
+    const uint32_t bc = (b3 >> 1) & 7u;
+    if (bc == 3u || bc == 7u) return 0u;
+    uint32_t ones = (uint32_t)__clz((int)(~(b4 << 24)));          // leading one bits of the first varint byte (read_var_length_int, frame.rs:64-105)
+    if (ones > 8u) ones = 8u;
+    if (ones == 1u) return 0u;
+    const uint32_t extra = ones ? ones - 1u : 0u;
+    const uint32_t len = 5u + extra + (bn == 6u ? 1u : bn == 7u ? 2u : 0u) + (sn == 12u ? 1u : (sn == 13u || sn == 14u) ? 2u : 0u);
+    if ((uint64_t)len + 1u > avail) return 0u;
+    for (uint32_t i = 0; i < extra; ++i) if ((d[5u + i] & 0xc0u) != 0x80u) return 0u;
+    uint32_t crc = 0;                                              // CRC-8, poly 0x07, init 0 (crc.rs:13-31)
+    for (uint32_t i = 0; i < len; ++i) {
+        crc ^= d[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xffu : (crc << 1) & 0xffu;
+    }
+    return crc == d[len] ? len + 1u : 0u;
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_find_headers(const uint8_t* __restrict__ data, uint64_t len, uint64_t start, uint64_t* __restrict__ cand,
+                        uint32_t cap, uint32_t* __restrict__ count) {
+    // 16 positions per thread: one aligned 16-byte load + the byte after it
+    const uint64_t base = (start & ~15ull) + ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (base >= len) return;
+    const uint4 v = *reinterpret_cast<const uint4*>(data + base);          // (allocation is padded to 16 bytes + 16)
+    const uint32_t nxt = data[base + 16u];
+    const uint32_t w[5] = { v.x, v.y, v.z, v.w, nxt };
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; ++i) {
+        const uint32_t b0 = (w[i >> 2] >> (8u * (i & 3u))) & 0xffu;
+        const uint32_t b1 = (w[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 0xffu;
+        if (b0 == 0xffu && (b1 & 0xfeu) == 0xf8u) {
+            const uint64_t p = base + i;
+            if (p >= start && p + 2u <= len && clx_header_probe(data + p, len - p) != 0u) {
+                const uint32_t k = atomicAdd(count, 1u);
+                if (k < cap) cand[k] = p;
+            }
+        }
+    }
+}
+
+// span j = [pos[j], pos[j+1]) for j < n_spans (pos has n_spans + 1 entries, ascending); one wave per span
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_span_crc16(const uint8_t* __restrict__ data, const uint64_t* __restrict__ pos, uint32_t n_spans, uint16_t* __restrict__ crc_out) {
+    const int lane = (int)threadIdx.x;
+    const uint32_t j = blockIdx.x;
+    if (j >= n_spans) return;
+    const uint8_t* p = data + pos[j];
+    const uint64_t nbytes = pos[j + 1] - pos[j];
+    const uint64_t per = (nbytes + 63u) / 64u;
+    const uint64_t lo = (uint64_t)lane * per < nbytes ? (uint64_t)lane * per : nbytes;
+    const uint64_t hi = lo + per < nbytes ? lo + per : nbytes;
+    uint32_t crc = 0;
+    for (uint64_t i = lo; i < hi; ++i) crc = clx_crc16_byte(crc, p[i]);
+    const uint64_t tail = nbytes - hi;
+    uint32_t contrib = (hi > lo) ? clx_gf_mulmod(crc, clx_xpow8_64(tail)) : 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) contrib ^= __shfl_xor(contrib, s, 64);
+    if (lane == 0) crc_out[j] = (uint16_t)contrib;
+}
+
+// K7: the first 20 bytes of every candidate, gathered for the host's authoritative header parse (zero padded at the end)
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_gather_headers(const uint8_t* __restrict__ data, uint64_t len, const uint64_t* __restrict__ pos, uint32_t n, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t p = pos[i];
+    for (uint32_t k = 0; k < 20u; ++k) out[(size_t)i * 20u + k] = p + k < len ? data[p + k] : 0u;
 }

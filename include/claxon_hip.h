@@ -272,6 +272,13 @@ int clx_index_frames(const uint8_t* data, size_t len, size_t start_off,
                      clx_frame_desc* descs, clx_frame_header* headers, size_t cap,
                      size_t* n_found, size_t* stop_off);
 
+/* The same indexer with the byte work on the GPU (sync-code scan + CRC-8 of every candidate header, CRC-16 of every
+ * byte between candidates); identical outputs.  `data` is a host pointer, or with CLX_ARENA_ON_DEVICE a 16-byte
+ * aligned device pointer whose allocation is padded like a decode arena (>= round16(len) + 32 bytes). */
+int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t len, size_t start_off,
+                            clx_frame_desc* descs, clx_frame_header* headers, size_t cap,
+                            size_t* n_found, size_t* stop_off, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

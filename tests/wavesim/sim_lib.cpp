@@ -46,3 +46,17 @@ extern "C" int sim_interleave(const int32_t* planar, const clx_frame_desc* frame
     if (n) SIM_LAUNCH(clx_k_interleave, n, 256, planar, dev.data(), results, (uint32_t)n, pcm, sample_bytes);
     return CLX_OK;
 }
+
+// frame indexer kernels (K5, K6) under simulation; `data` must be 16-byte aligned and padded by >= 32 bytes
+extern "C" int sim_find_headers(const uint8_t* data, uint64_t len, uint64_t start, uint64_t* cand, uint32_t cap, uint32_t* count) {
+    *count = 0;
+    if (start >= len) return CLX_OK;
+    const uint64_t scan0 = start & ~15ull;
+    const uint64_t n_threads = (len - scan0 + 15) / 16;
+    SIM_LAUNCH(clx_k_find_headers, (n_threads + 255) / 256, 256, data, len, start, cand, cap, count);
+    return CLX_OK;
+}
+extern "C" int sim_span_crc16(const uint8_t* data, const uint64_t* pos, uint32_t n_spans, uint16_t* crc) {
+    if (n_spans) SIM_LAUNCH(clx_k_span_crc16, n_spans, 64, data, pos, n_spans, crc);
+    return CLX_OK;
+}
