@@ -103,14 +103,18 @@ __device__ __forceinline__ int32_t clx_peek_signed(const K1Lds& L, const BitSrc&
 }
 
 __device__ __forceinline__ uint32_t clx_wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += up;
-    }
-    *total = __shfl(incl, 63, 64);
-    return incl - v;
+    // DPP scan: four shifted adds inside each row of 16 lanes, then the row totals are broadcast down (row_bcast:15 into
+    // rows 1 and 3, row_bcast:31 into rows 2 and 3): six instructions, no LDS traffic
+    (void)lane;
+    int incl = (int)v;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
+    *total = __shfl((uint32_t)incl, 63, 64);
+    return (uint32_t)incl - v;
 }
 
 // value of `v` in the (unique) lane where `pred` holds; `dflt` when there is none.  Wave-uniform result.
@@ -124,9 +128,19 @@ __device__ __forceinline__ uint32_t clx_pick(uint32_t v, bool pred, uint32_t dfl
 // (low 32-B bits zero).  States: m in [0,k] = "m remainder bits still to skip, then a code starts";
 // SC = k+1 = "inside a unary run that started earlier".  subframe.rs:337-341 per code:
 // q zeros, a one, k remainder bits.
+// SENT (B < 32): `c` carries a sentinel one right behind the chunk, so a walk never runs off it and the step is three
+// instructions -- shift, count leading zeros, add; a code whose terminator turns out to be the sentinel is a run that
+// continues into the next chunk.
+template <bool SENT>
 __device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint32_t k, uint32_t m) {
     const uint32_t SC = k + 1u;
     uint32_t p = (m == SC) ? 0u : m;
+    if (SENT) {
+        const uint32_t k1 = k + 1u;
+        uint32_t end = 0xffffffffu;                      // position behind the last code walked (terminator + 1 + k)
+        while (p < B) { p += (uint32_t)__clz((int)(c << p)) + k1; end = p; }
+        return (end == B + k1) ? SC : p - B;             // terminator == B: the sentinel
+    }
     for (;;) {
         if (p >= B) return p - B;
         uint32_t rest = c << p;
@@ -168,14 +182,17 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
 
         CLX_TL_PHASE(0);                   // span set-up, window
         // (1) exit-state tables
-        const uint32_t ex0 = clx_chunk_exit(c, B, k, 0u);
+        const bool sent = B < 32u;                           // wave-uniform
+        const uint32_t cs = sent ? (c | (0x80000000u >> B)) : c;
+        const uint32_t ex0 = sent ? clx_chunk_exit<true>(cs, B, k, 0u) : clx_chunk_exit<false>(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
             uint32_t packed = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t m = 4u * g + j;
                 // entering inside a run (SC) walks exactly like entering at a code start (state 0)
-                const uint32_t ex = (m == 0u || m == SC) ? ex0 : (m < ns) ? clx_chunk_exit(c, B, k, m) : 0u;
+                const uint32_t ex = (m == 0u || m == SC) ? ex0 : (m >= ns) ? 0u
+                                  : sent ? clx_chunk_exit<true>(cs, B, k, m) : clx_chunk_exit<false>(c, B, k, m);
                 packed |= ex << (8u * j);
             }
             L.u.t.tab[g][lane] = packed;
@@ -216,13 +233,19 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         uint32_t S = 0;
         {
             uint32_t p = (my_entry == SC) ? 0u : my_entry;
-            bool fresh = (my_entry != SC);
-            while (p < B) {
-                if (fresh) S |= 1u << p;
-                fresh = true;
-                uint32_t rest = c << p;
-                if (rest == 0u) break;
-                p += (uint32_t)__clz((int)rest) + 1u + k;
+            if (sent) {
+                const uint32_t k1 = k + 1u;
+                while (p < B) { S |= 0x1u << p; p += (uint32_t)__clz((int)(cs << p)) + k1; }
+                if (my_entry == SC) S &= ~1u;                // position 0 continued a run: it is not a start
+            } else {
+                bool fresh = (my_entry != SC);
+                while (p < B) {
+                    if (fresh) S |= 1u << p;
+                    fresh = true;
+                    uint32_t rest = c << p;
+                    if (rest == 0u) break;
+                    p += (uint32_t)__clz((int)rest) + 1u + k;
+                }
             }
         }
         const uint32_t cnt = (uint32_t)__popc(S);

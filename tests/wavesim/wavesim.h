@@ -196,13 +196,23 @@ static int all_(int line, int pred) {
     for (int l = 0; l < 64; ++l) if (!all[l]) return 0;
     return 1;
 }
-// DPP quad_perm (dpp_ctrl 0x00-0xFF), full row/bank masks: lane l reads lane (l & ~3) | perm[l & 3]
+// DPP controls the kernels use, with gfx9 semantics: quad_perm (0x00-0xFF): lane l reads lane (l & ~3) | perm[l & 3];
+// row_shr:n (0x111-0x11F): lane l reads lane l-n of its row of 16, lanes without a source get 0 (bound_ctrl) or `old`;
+// row_bcast:15 (0x142) / row_bcast:31 (0x143): lane 15 of the previous row / lane 31 of the previous half goes to a whole
+// row.  Rows not selected by row_mask keep `old`.  (bank_mask must be 0xF.)
 static int update_dpp_(int line, int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
-    if (dpp_ctrl < 0 || dpp_ctrl > 0xff) die("only quad_perm DPP controls are simulated");
+    if (bank_mask != 0xf) die("only bank_mask 0xF is simulated");
     const int lane = S().cur & 63;
     const uint64_t* all = exchange(src, WAVESIM_SITE(line));
-    return from_bits<int>(all[(lane & ~3) | ((dpp_ctrl >> (2 * (lane & 3))) & 3)]);
+    int from = -1;                                       // source lane, -1: none
+    if (dpp_ctrl >= 0 && dpp_ctrl <= 0xff) from = (lane & ~3) | ((dpp_ctrl >> (2 * (lane & 3))) & 3);
+    else if (dpp_ctrl >= 0x111 && dpp_ctrl <= 0x11f) { const int n = dpp_ctrl - 0x110; from = (lane & 15) >= n ? lane - n : -1; }
+    else if (dpp_ctrl == 0x142) from = (lane >= 16) ? ((lane & ~15) - 1) : -1;
+    else if (dpp_ctrl == 0x143) from = (lane >= 32) ? 31 : -1;
+    else die("this DPP control is not simulated");
+    if (!((row_mask >> (lane >> 4)) & 1)) return old;
+    if (from < 0) return bound_ctrl ? 0 : old;
+    return from_bits<int>(all[from]);
 }
 }  // namespace wavesim
 
