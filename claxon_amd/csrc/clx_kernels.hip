@@ -93,6 +93,13 @@ __device__ __forceinline__ uint32_t clx_peek32(const K1Lds& L, const BitSrc& b, 
     return (uint32_t)((v << off) >> 32);
 }
 
+// The same for a position the caller knows to be inside the window (clx_window_ensure): no bounds test, no fallback.
+__device__ __forceinline__ uint32_t clx_peek32_win(const K1Lds& L, const BitSrc& b, uint32_t pos) {
+    const uint32_t i = (pos >> 5) - b.win_dw;
+    const uint64_t v = ((uint64_t)L.W[i] << 32) | L.W[i + 1];
+    return (uint32_t)((v << (pos & 31u)) >> 32);
+}
+
 // `bits` (1..32) bits at `pos`, right aligned; 0 bits -> 0 (read_leq_u8(0) == 0, input.rs:706).
 __device__ __forceinline__ uint32_t clx_peek_bits(const K1Lds& L, const BitSrc& b, uint32_t pos, uint32_t bits) {
     return bits ? (clx_peek32(L, b, pos) >> (32u - bits)) : 0u;
@@ -113,7 +120,7 @@ __device__ __forceinline__ uint32_t clx_wave_excl_scan(uint32_t v, int lane, uin
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
-    *total = __shfl((uint32_t)incl, 63, 64);
+    *total = clx_readlane((uint32_t)incl, 63u);
     return (uint32_t)incl - v;
 }
 
@@ -121,7 +128,7 @@ __device__ __forceinline__ uint32_t clx_wave_excl_scan(uint32_t v, int lane, uin
 __device__ __forceinline__ uint32_t clx_pick(uint32_t v, bool pred, uint32_t dflt) {
     unsigned long long m = __ballot(pred);
     if (m == 0ull) return dflt;
-    return __shfl(v, __ffsll((long long)m) - 1, 64);
+    return clx_readlane(v, (uint32_t)__ffsll((long long)m) - 1u);
 }
 
 // Exit state of one chunk for one entry state.  A chunk is `B` stream bits held left-aligned in `c`
@@ -162,6 +169,9 @@ __device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint3
 // into LDS, from where they are written to HBM coalesced.
 __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32_t k, uint32_t count,
                                        int32_t* dst, uint32_t limit, uint32_t* err, int lane CLX_TL_PH_PARAM) {
+    // the cursor and the partition's shape are the same in every lane: keep them (and all that follows from them: chunk
+    // width, window tests, loop control) on the scalar unit -- this kernel is bound by VALU issue slots
+    pos = clx_uniform(pos); k = clx_uniform(k); count = clx_uniform(count); limit = clx_uniform(limit);
     const uint32_t SC = k + 1u, ns = k + 2u;
     CLX_TL_PHASE(5);                       // everything outside the residual decode: headers, warm-up, descriptors
     uint32_t done = 0;
@@ -175,8 +185,15 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         clx_window_ensure(L, b, pos, 64u * B + 64u, lane);
 
         const uint32_t cpos = pos + B * (uint32_t)lane;
-        const uint32_t c_raw = clx_peek32(L, b, cpos);       // my chunk and the 32 bits after it: codes that start in
-        const uint32_t c_next = clx_peek32(L, b, cpos + 32u);  // my chunk are extracted from this 64-bit register window
+        // my chunk and the 32 bits after it (codes that start in my chunk are extracted from this 64-bit register window):
+        // three dwords of the LDS window, which clx_window_ensure has just made sure of
+        uint32_t c_raw, c_next;
+        {
+            const uint32_t wi = (cpos >> 5) - b.win_dw, off = cpos & 31u;
+            const uint32_t w0 = L.W[wi], w1 = L.W[wi + 1u], w2 = L.W[wi + 2u];
+            c_raw = (uint32_t)(((((uint64_t)w0 << 32) | w1) << off) >> 32);
+            c_next = (uint32_t)(((((uint64_t)w1 << 32) | w2) << off) >> 32);
+        }
         uint32_t c = c_raw;
         if (B < 32u) c &= ~(0xffffffffu >> B);
 
@@ -283,16 +300,22 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                 e = (v == 0u) ? limit + 1u : t + (uint32_t)__clz((int)v) + 1u + k;
             }
             newpos = clx_pick(e, owner, limit + 1u);
-        } else newpos = pos + L.u.P[remaining];              // start of the first code that is not taken
+        } else newpos = pos + clx_uniform((uint32_t)L.u.P[remaining]);      // start of the first code that is not taken
         CLX_TL_PHASE(4);                   // position list + the span's last code
         // (4c) extraction, balanced over the lanes and written straight to HBM (coalesced): code i has
         // q = start(i+1) - start(i) - 1 - k zeros and its k remainder bits end where code i+1 starts
         const uint32_t end_rel = newpos - pos;
+        const bool far = end_rel > 64u * B + 32u;            // the span's last code runs past what the window is known to hold
         for (uint32_t i = (uint32_t)lane; i < ntake; i += 64u) {
             const uint32_t s = L.u.P[i];
             const uint32_t e = (i + 1u < ntake) ? (uint32_t)L.u.P[i + 1u] : end_rel;
             const uint32_t q = e - s - 1u - k;
-            const uint32_t r = clx_peek_bits(L, b, pos + e - k, k);
+            uint32_t r = 0;
+            if (k != 0u) {
+                const uint32_t at = pos + e - k;
+                const uint32_t v = (far && i + 1u == ntake) ? clx_peek32(L, b, at) : clx_peek32_win(L, b, at);
+                r = v >> (32u - k);
+            }
             const uint32_t u = (q << k) | r;                 // u32 wrapping shift, subframe.rs:340
             dst[done + i] = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                           // rice_to_signed, subframe.rs:157-170
         }

@@ -73,4 +73,9 @@ __device__ __forceinline__ void clx_wave_sync() { __builtin_amdgcn_wave_barrier(
 // workgroup barrier for waves that hand LDS data to each other, without the fences of __syncthreads() (hipcc drains
 // vmcnt(0) there, which would stall the LDS-DMA prefetch ring): LDS writes are made visible by the lgkmcnt wait
 __device__ __forceinline__ void clx_wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// A value the code knows to be wave-uniform, moved to a scalar register: everything computed from it afterwards runs on
+// the scalar unit instead of taking VALU issue slots (K1 is VALU-issue bound).  The simulator checks the claim.
+__device__ __forceinline__ uint32_t clx_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// lane `idx` (wave-uniform) of v, as a scalar
+__device__ __forceinline__ uint32_t clx_readlane(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); }
 #endif

@@ -29,4 +29,13 @@ template <int N> static inline void clx_wait_vmcnt() {}
 static inline void clx_wait_lds() {}
 #define clx_wave_sync() ((void)__ballot(1))     // a per-wave rendezvous (a block barrier would pair up with the other wave)
 #define clx_wg_barrier() __syncthreads()
+// clx_uniform: the kernels claim the value is the same in every live lane -- checked here
+static inline uint32_t clx_uniform_(int line, uint32_t v) {
+    const unsigned long long live = wavesim::ballot_(line, 1);
+    const uint32_t first = wavesim::shfl_(line, v, __builtin_ctzll(live), 64);
+    if (wavesim::any_(line, v != first)) { fprintf(stderr, "wavesim: clx_uniform() of a value that differs between lanes (line %d)\n", line); abort(); }
+    return first;
+}
+#define clx_uniform(v) clx_uniform_(__LINE__, (v))
+#define clx_readlane(v, idx) ((uint32_t)__shfl((uint32_t)(v), (int)(idx), 64))
 #endif
