@@ -37,7 +37,10 @@ struct K1Lds {
     // then the positions of the codes are listed.  4.4 KiB per wave in all = 8 waves per SIMD.
     union {
         struct {
-            uint32_t tab[8][64];   // tab[g][lane]: exit states of that lane's chunk for entry states 4g..4g+3
+            // tab[lane][s]: exit state of that lane's chunk for entry state s, one byte each, so that a step of the walk
+            // is "add the state to the row's address, read a byte"; rows are padded to 36 bytes (9 dwords): the eight
+            // groups of lanes that read their rows at the same time then hit different LDS banks
+            uint8_t  tab[64][36];
             uint8_t  gtab[8][32];  // gtab[g][s]: exit state of lane group g (8 lanes) for entry state s
         } t;
         uint16_t P[CLX_NPOS];      // P[i]: bit position (relative to the span) where code i of the span starts
@@ -212,7 +215,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                                   : sent ? clx_chunk_exit<true>(cs, B, k, m) : clx_chunk_exit<false>(c, B, k, m);
                 packed |= ex << (8u * j);
             }
-            L.u.t.tab[g][lane] = packed;
+            *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4u * g]) = packed;     // states 4g .. 4g+3 (little endian)
         }
         __syncthreads();
         CLX_TL_PHASE(1);                   // exit tables
@@ -222,27 +225,27 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             for (uint32_t st = (uint32_t)lane & 7u; st < ns; st += 8u) {
                 uint32_t m = st;
 #pragma unroll
-                for (uint32_t i = 0; i < 8; ++i)
-                    m = (L.u.t.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
+                for (uint32_t i = 0; i < 8; ++i) m = L.u.t.tab[g8 * 8u + i][m];
                 L.u.t.gtab[g8][st] = (uint8_t)m;
             }
         }
         __syncthreads();
-        // (2b) across groups (uniform), (2c) inside each group
+        // (2b) across groups (on the scalar unit: the eight group entry states are packed into two registers, every
+        // lane picks its group's byte), (2c) inside each group
         uint32_t my_entry = 0;
         {
-            uint32_t m = 0, mine = 0;                       // a span always begins at a code start
+            uint32_t m = 0, lo = 0, hi = 0;                  // a span always begins at a code start
 #pragma unroll
             for (uint32_t g = 0; g < 8; ++g) {
-                if (((uint32_t)lane >> 3) == g) mine = m;
-                m = L.u.t.gtab[g][m];
+                if (g < 4u) lo |= m << (8u * g); else hi |= m << (8u * (g - 4u));
+                m = clx_uniform((uint32_t)L.u.t.gtab[g][m]);
             }
-            m = mine;
             const uint32_t g8 = (uint32_t)lane >> 3;
+            m = (((g8 & 4u) ? hi : lo) >> (8u * (g8 & 3u))) & 0xffu;
 #pragma unroll
             for (uint32_t i = 0; i < 8; ++i) {
                 if (((uint32_t)lane & 7u) == i) my_entry = m;
-                m = (L.u.t.tab[m >> 2][g8 * 8u + i] >> (8u * (m & 3u))) & 0xffu;
+                m = L.u.t.tab[g8 * 8u + i][m];
             }
         }
         CLX_TL_PHASE(2);                   // three-level walk
