@@ -74,7 +74,8 @@ EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
     "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes", "clx_interleave",
     "clx_batch_create", "clx_batch_run", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
-    "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_reader_open", "clx_reader_new",
+    "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
+    "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
     "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames", "clx_index_frames_device",
 ]
 
@@ -148,6 +149,18 @@ def lib():
     L.clx_batch_destroy.argtypes = [vp]
     L.clx_batch_destroy.restype = None
     L.clx_read_stream_header.argtypes = [vp, sz, C.POINTER(StreamInfo), C.POINTER(sz), u32p]
+    L.clx_read_stream_header_ext.argtypes = [vp, sz, C.c_uint32, C.POINTER(StreamInfo), C.POINTER(sz), C.POINTER(vp), u32p]
+    L.clx_tags_vendor.restype = vp
+    L.clx_tags_vendor.argtypes = [vp, C.POINTER(sz)]
+    L.clx_tags_count.restype = sz
+    L.clx_tags_count.argtypes = [vp]
+    L.clx_tags_get.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
+    L.clx_tags_lookup.restype = vp
+    L.clx_tags_lookup.argtypes = [vp, C.c_char_p, sz, C.POINTER(sz)]
+    L.clx_tags_free.argtypes = [vp]
+    L.clx_tags_free.restype = None
+    L.clx_reader_tags.restype = vp
+    L.clx_reader_tags.argtypes = [vp]
     L.clx_reader_open.argtypes = [vp, C.c_char_p, C.POINTER(vp), u32p]
     L.clx_reader_new.argtypes = [vp, vp, sz, C.POINTER(vp), u32p]
     L.clx_reader_streaminfo.argtypes = [vp, C.POINTER(StreamInfo)]
@@ -201,6 +214,48 @@ def read_stream_header(data):
     m = C.c_uint32(0)
     st = lib().clx_read_stream_header(_np_ptr(a), a.size, C.byref(si), C.byref(off), C.byref(m))
     return st, int(m.value), si, int(off.value)
+
+
+def _tags_to_py(t):
+    """(vendor bytes | None, [(name bytes, value bytes)]) from a clx_tags handle (not freed here)."""
+    if not t:
+        return None, []
+    n = C.c_size_t(0)
+    v = lib().clx_tags_vendor(t, C.byref(n))
+    vendor = C.string_at(v, n.value)
+    out = []
+    for i in range(lib().clx_tags_count(t)):
+        pn, pv, ln, lv = C.c_void_p(), C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+        assert lib().clx_tags_get(t, i, C.byref(pn), C.byref(ln), C.byref(pv), C.byref(lv)) == OK
+        out.append((C.string_at(pn, ln.value), C.string_at(pv, lv.value)))
+    return vendor, out
+
+
+def _tags_lookup(t, name):
+    """metadata::GetTag (metadata.rs:197-211): every value whose name matches ASCII-case-insensitively, in order."""
+    out, k = [], 0
+    while True:
+        n = C.c_size_t(0)
+        v = lib().clx_tags_lookup(t, name.encode() if isinstance(name, str) else name, k, C.byref(n))
+        if not v:
+            return out
+        out.append(C.string_at(v, n.value))
+        k += 1
+
+
+def read_stream_header_ext(data, metadata_only=False, read_vorbis_comment=True):
+    """FlacReader::new_ext (lib.rs:230-307) on bytes: (status, msg, StreamInfo, audio offset, vendor | None, [(name, value)])."""
+    a = _u8(data)
+    si = StreamInfo()
+    off = C.c_size_t(0)
+    m = C.c_uint32(0)
+    t = C.c_void_p()
+    opts = (1 if metadata_only else 0) | (0 if read_vorbis_comment else 2)
+    st = lib().clx_read_stream_header_ext(_np_ptr(a), a.size, opts, C.byref(si), C.byref(off), C.byref(t), C.byref(m))
+    vendor, tags = _tags_to_py(t.value)
+    if t.value:
+        lib().clx_tags_free(t)
+    return st, int(m.value), si, int(off.value), vendor, tags
 
 
 def index_frames(data, start=0, cap=1 << 20):
@@ -503,6 +558,21 @@ class FlacReader:
 
     def streaminfo(self):
         return self._si
+
+    def vendor(self):
+        """lib.rs:321: the encoder's vendor string (str), or None when the stream has no Vorbis comment block."""
+        v, _ = _tags_to_py(lib().clx_reader_tags(self._h))
+        return None if v is None else v.decode("utf-8")
+
+    def tags(self):
+        """lib.rs:335: (name, value) pairs in stream order."""
+        _, t = _tags_to_py(lib().clx_reader_tags(self._h))
+        return [(n.decode("utf-8"), v.decode("utf-8")) for n, v in t]
+
+    def get_tag(self, name):
+        """lib.rs:356: every value of the tag `name` (ASCII-case-insensitive), in stream order."""
+        t = lib().clx_reader_tags(self._h)
+        return [v.decode("utf-8") for v in _tags_lookup(t, name)] if t else []
 
     def read_next_or_eof(self):
         """Returns a Block, or None at the end of the stream; raises ClaxonError like the reference returns Err."""

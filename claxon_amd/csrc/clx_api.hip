@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "clx_plan.h"
@@ -60,6 +61,17 @@ const MsgInfo kMsgs[CLX_MSG_COUNT] = {
     { CLX_FORMAT_ERROR, "invalid sample rate" },
     { CLX_FORMAT_ERROR, "application block length must be at least 4 bytes" },
     { CLX_UNSUPPORTED, "application blocks larger than 10 MiB are not supported" },
+    { CLX_FORMAT_ERROR, "Vorbis comment block is too short" },
+    { CLX_UNSUPPORTED, "Vorbis comment blocks larger than 10 MiB are not supported" },
+    { CLX_FORMAT_ERROR, "vendor string too long" },
+    { CLX_FORMAT_ERROR, "too many entries for Vorbis comment block" },
+    { CLX_FORMAT_ERROR, "Vorbis comment too long for Vorbis comment block" },
+    { CLX_FORMAT_ERROR, "Vorbis comment field name contains invalid byte" },
+    { CLX_FORMAT_ERROR, "Vorbis comment does not contain '='" },
+    { CLX_FORMAT_ERROR, "Vorbis comment block has excess data" },
+    { CLX_FORMAT_ERROR, "Vorbis comment block contains wrong number of entries" },
+    { CLX_FORMAT_ERROR, "Vorbis comment or vendor string is not valid UTF-8" },
+    { CLX_FORMAT_ERROR, "encountered second Vorbis comment block" },
 };
 
 // CRC tables generated from the polynomials (crc.rs:61,69): x^8+x^2+x+1 and x^16+x^15+x^2+1.
@@ -567,8 +579,76 @@ extern "C" int clx_decode_subframes(clx_ctx* ctx, const uint8_t* arena, size_t a
 // stream header + STREAMINFO (lib.rs:186-205, 230-307; metadata.rs:214-400).  Other metadata blocks
 // are skipped by length (VORBIS_COMMENT parsing is outside the hot-path scope).
 // ------------------------------------------------------------------------------------------------
-extern "C" int clx_read_stream_header(const uint8_t* d, size_t len, clx_streaminfo* info, size_t* audio_offset, uint32_t* msg) {
+struct clx_tags {
+    std::string vendor;
+    std::vector<std::pair<std::string, size_t>> comments;     // "NAME=value" and the index of '=' (metadata.rs:97)
+};
+
+namespace {
+// String::from_utf8 (metadata.rs:441, 495): well-formed UTF-8 only -- no overlong forms, no surrogates, nothing past U+10FFFF
+bool valid_utf8(const uint8_t* p, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t b = p[i];
+        if (b < 0x80) { ++i; continue; }
+        size_t need; uint32_t cp, min;
+        if ((b & 0xe0) == 0xc0) { need = 1; cp = b & 0x1f; min = 0x80; }
+        else if ((b & 0xf0) == 0xe0) { need = 2; cp = b & 0x0f; min = 0x800; }
+        else if ((b & 0xf8) == 0xf0) { need = 3; cp = b & 0x07; min = 0x10000; }
+        else return false;
+        if (i + need >= n) return false;                     // truncated sequence
+        for (size_t k = 1; k <= need; ++k) {
+            if ((p[i + k] & 0xc0) != 0x80) return false;
+            cp = (cp << 6) | (p[i + k] & 0x3f);
+        }
+        if (cp < min || cp > 0x10ffff || (cp >= 0xd800 && cp <= 0xdfff)) return false;
+        i += need + 1;
+    }
+    return true;
+}
+
+// read_vorbis_comment_block, metadata.rs:402-513.  `c` stands right behind the block header.
+int read_vorbis_comment(ByteCursor& c, uint32_t length, clx_tags& out, uint32_t* msg) {
+    if (length < 8) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_TOO_SHORT);
+    if (length > 10u * 1024 * 1024) return fail(msg, CLX_UNSUPPORTED, CLX_MSG_VC_TOO_LARGE);
+    auto le32 = [&](uint32_t* v) { uint32_t r = 0; for (int i = 0; i < 4; ++i) { uint32_t b; if (!c.u8(&b)) return false; r |= b << (8 * i); } *v = r; return true; };
+    auto take = [&](size_t n, const uint8_t** p) { if (n > c.n - c.pos) return false; *p = c.p + c.pos; c.pos += n; return true; };
+    uint32_t vendor_len;
+    if (!le32(&vendor_len)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    if (vendor_len > length - 8) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_VENDOR_TOO_LONG);
+    const uint8_t* bytes;
+    if (!take(vendor_len, &bytes)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    if (!valid_utf8(bytes, vendor_len)) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_NOT_UTF8);
+    out.vendor.assign((const char*)bytes, vendor_len);
+    uint32_t comments_len;
+    if (!le32(&comments_len)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    if (comments_len >= length / 4) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_TOO_MANY_ENTRIES);
+    uint32_t bytes_left = length - 8 - vendor_len;
+    while (bytes_left >= 4 && out.comments.size() < comments_len) {
+        uint32_t clen;
+        if (!le32(&clen)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        bytes_left -= 4;
+        if (clen > bytes_left) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_COMMENT_TOO_LONG);
+        if (clen == 0) { comments_len -= 1; continue; }          // empty comments occur in the wild: skipped (metadata.rs:465-472)
+        if (!take(clen, &bytes)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        bytes_left -= clen;
+        size_t sep = clen;
+        for (size_t i = 0; i < clen; ++i) if (bytes[i] == '=') { sep = i; break; }
+        if (sep == clen) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_NO_EQUALS);
+        for (size_t i = 0; i < sep; ++i) if (bytes[i] < 0x20 || bytes[i] > 0x7d) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_NAME_INVALID_BYTE);
+        if (!valid_utf8(bytes, clen)) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_NOT_UTF8);
+        out.comments.emplace_back(std::string((const char*)bytes, clen), sep);
+    }
+    if (bytes_left != 0) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_EXCESS_DATA);
+    if (out.comments.size() != comments_len) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_VC_WRONG_COUNT);
+    return CLX_OK;
+}
+}  // namespace
+
+extern "C" int clx_read_stream_header_ext(const uint8_t* d, size_t len, uint32_t options, clx_streaminfo* info,
+                                          size_t* audio_offset, clx_tags** tags_out, uint32_t* msg) {
     if (msg) *msg = CLX_MSG_NONE;
+    if (tags_out) *tags_out = nullptr;
     if (!info || !audio_offset || (!d && len)) return CLX_API_ERROR;
     ByteCursor c{ d, len, 0 };
     auto be = [&](int nbytes, uint64_t* v) { uint64_t r = 0; for (int i = 0; i < nbytes; ++i) { uint32_t b; if (!c.u8(&b)) return false; r = (r << 8) | b; } *v = r; return true; };
@@ -576,6 +656,9 @@ extern "C" int clx_read_stream_header(const uint8_t* d, size_t len, clx_streamin
     if (!be(4, &magic)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
     if (magic != 0x664c6143ull)
         return fail(msg, CLX_FORMAT_ERROR, (magic & 0xffffff00ull) == 0x49443300ull ? CLX_MSG_ID3_HEADER : CLX_MSG_INVALID_STREAM_HEADER);
+    const bool metadata_only = (options & CLX_OPT_METADATA_ONLY) != 0;
+    bool want_vc = (options & CLX_OPT_NO_VORBIS_COMMENT) == 0;     // opts_current.read_vorbis_comment (lib.rs:232, 265)
+    std::unique_ptr<clx_tags> vc;
     bool first = true;
     for (;;) {
         uint32_t hb; uint64_t length;
@@ -607,6 +690,15 @@ extern "C" int clx_read_stream_header(const uint8_t* d, size_t len, clx_streamin
             if (s.sample_rate == 0 || s.sample_rate > 655350) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_SAMPLE_RATE);
             if (!first) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_SECOND_STREAMINFO);
             *info = s;
+        } else if (type == 4) {
+            // the block is always parsed (metadata.rs:291-294), so its errors surface whatever the options say
+            std::unique_ptr<clx_tags> t(new clx_tags());
+            const int st = read_vorbis_comment(c, (uint32_t)length, *t, msg);
+            if (st != CLX_OK) return st;
+            if (first) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_STREAMINFO_MISSING);
+            if (vc) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_SECOND_VORBIS_COMMENT);       // lib.rs:257-259
+            vc = std::move(t);
+            want_vc = false;
         } else {
             if (type == 127) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_METADATA_BLOCK_TYPE);
             if (type == 2) {
@@ -617,12 +709,54 @@ extern "C" int clx_read_stream_header(const uint8_t* d, size_t len, clx_streamin
             c.pos += (size_t)length;
             if (first) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_STREAMINFO_MISSING);
         }
+        // the streaminfo block is read on its own (lib.rs:243-248); the early-out is only evaluated after a LATER block
+        // (lib.rs:273-277), so even a metadata-only reader that wants no tags reads the block after the streaminfo
+        const bool was_first = first;
         first = false;
         if (is_last) break;
+        if (!was_first && metadata_only && !want_vc) break;
     }
+    if (options & CLX_OPT_NO_VORBIS_COMMENT) vc.reset();                                      // lib.rs:283-285
+    if (tags_out) *tags_out = vc.release();
     *audio_offset = c.pos;
     return CLX_OK;
 }
+
+extern "C" int clx_read_stream_header(const uint8_t* d, size_t len, clx_streaminfo* info, size_t* audio_offset, uint32_t* msg) {
+    return clx_read_stream_header_ext(d, len, 0, info, audio_offset, nullptr, msg);
+}
+
+extern "C" const char* clx_tags_vendor(const clx_tags* t, size_t* len) {
+    if (!t) { if (len) *len = 0; return nullptr; }
+    if (len) *len = t->vendor.size();
+    return t->vendor.c_str();
+}
+extern "C" size_t clx_tags_count(const clx_tags* t) { return t ? t->comments.size() : 0; }
+extern "C" int clx_tags_get(const clx_tags* t, size_t i, const char** name, size_t* name_len, const char** value, size_t* value_len) {
+    if (!t || i >= t->comments.size()) return CLX_API_ERROR;
+    const std::string& s = t->comments[i].first;
+    const size_t sep = t->comments[i].second;
+    if (name) *name = s.data();
+    if (name_len) *name_len = sep;
+    if (value) *value = s.data() + sep + 1;
+    if (value_len) *value_len = s.size() - sep - 1;
+    return CLX_OK;
+}
+extern "C" const char* clx_tags_lookup(const clx_tags* t, const char* name, size_t occurrence, size_t* value_len) {
+    if (!t || !name) return nullptr;
+    const size_t nlen = std::strlen(name);
+    auto lower = [](unsigned char ch) { return (ch >= 'A' && ch <= 'Z') ? (unsigned char)(ch + 32) : ch; };    // eq_ignore_ascii_case
+    for (const auto& c : t->comments) {
+        if (c.second != nlen) continue;
+        bool eq = true;
+        for (size_t i = 0; i < nlen && eq; ++i) eq = lower((unsigned char)c.first[i]) == lower((unsigned char)name[i]);
+        if (!eq) continue;
+        if (occurrence == 0) { if (value_len) *value_len = c.first.size() - c.second - 1; return c.first.data() + c.second + 1; }
+        --occurrence;
+    }
+    return nullptr;
+}
+extern "C" void clx_tags_free(clx_tags* t) { delete t; }
 
 // ------------------------------------------------------------------------------------------------
 // frame indexer (host): sync code + CRC-8-valid header, chain confirmed by the previous frame's CRC-16
@@ -928,7 +1062,8 @@ FrameResult FrameReader::read_next_or_eof(std::vector<int32_t> buffer) {
 struct FlacReader::Impl {
     clx_streaminfo info{};
     FrameReader* frames = nullptr;
-    ~Impl() { delete frames; }
+    clx_tags* tags = nullptr;
+    ~Impl() { delete frames; clx_tags_free(tags); }
 };
 
 FlacReader::FlacReader() : impl_(new Impl()) {}
@@ -938,9 +1073,11 @@ FlacReader::~FlacReader() { delete impl_; }
 Result<FlacReader> FlacReader::create(clx_ctx* ctx, const uint8_t* data, size_t len) {
     Result<FlacReader> r;
     clx_streaminfo si; size_t off = 0; uint32_t msg = 0;
-    int st = clx_read_stream_header(data, len, &si, &off, &msg);
+    clx_tags* tags = nullptr;
+    int st = clx_read_stream_header_ext(data, len, 0, &si, &off, &tags, &msg);
     if (st != CLX_OK) { r.is_err = true; r.error = Error::from(st, msg); return r; }
     r.value.impl_->info = si;
+    r.value.impl_->tags = tags;
     r.value.impl_->frames = new FrameReader(ctx, data + off, len - off);
     return r;
 }
@@ -958,6 +1095,31 @@ Result<FlacReader> FlacReader::open(clx_ctx* ctx, const char* path) {
 }
 
 const clx_streaminfo& FlacReader::streaminfo() const { return impl_->info; }
+const clx_tags* FlacReader::raw_tags() const { return impl_->tags; }
+bool FlacReader::vendor(std::string* out) const {
+    if (!impl_->tags) return false;
+    size_t n = 0; const char* v = clx_tags_vendor(impl_->tags, &n);
+    if (out) out->assign(v, n);
+    return true;
+}
+std::vector<std::pair<std::string, std::string>> FlacReader::tags() const {
+    std::vector<std::pair<std::string, std::string>> out;
+    for (size_t i = 0; i < clx_tags_count(impl_->tags); ++i) {
+        const char *n, *v; size_t nl, vl;
+        clx_tags_get(impl_->tags, i, &n, &nl, &v, &vl);
+        out.emplace_back(std::string(n, nl), std::string(v, vl));
+    }
+    return out;
+}
+std::vector<std::string> FlacReader::get_tag(const char* name) const {
+    std::vector<std::string> out;
+    for (size_t k = 0;; ++k) {
+        size_t vl = 0; const char* v = clx_tags_lookup(impl_->tags, name, k, &vl);
+        if (!v) break;
+        out.emplace_back(v, vl);
+    }
+    return out;
+}
 FrameReader& FlacReader::blocks() { return *impl_->frames; }
 
 }  // namespace claxon
@@ -966,6 +1128,7 @@ FrameReader& FlacReader::blocks() { return *impl_->frames; }
 // C handles over the C++ reader
 // ------------------------------------------------------------------------------------------------
 struct clx_reader { claxon::FlacReader reader; std::vector<int32_t> recycle; };
+extern "C" const clx_tags* clx_reader_tags(const clx_reader* r) { return r ? r->reader.raw_tags() : nullptr; }
 
 extern "C" int clx_reader_new(clx_ctx* ctx, const uint8_t* data, size_t len, clx_reader** out, uint32_t* msg) {
     if (msg) *msg = CLX_MSG_NONE;

@@ -154,6 +154,10 @@ public:
     static Result<FlacReader> open(clx_ctx* ctx, const char* path);                      // lib.rs:455
     static Result<FlacReader> create(clx_ctx* ctx, const uint8_t* data, size_t len);     // FlacReader::new, lib.rs:217
     const clx_streaminfo& streaminfo() const;                                            // lib.rs:312
+    bool vendor(std::string* out) const;                                                 // lib.rs:321 (false: no Vorbis comment block)
+    std::vector<std::pair<std::string, std::string>> tags() const;                       // lib.rs:335 (name, value) in stream order
+    std::vector<std::string> get_tag(const char* name) const;                            // lib.rs:356 ASCII-case-insensitive, all matches
+    const clx_tags* raw_tags() const;
     FrameReader& blocks();                                                               // lib.rs:367
     FlacSamples samples() { return FlacSamples(blocks()); }                              // lib.rs:396
     FlacReader();

@@ -87,6 +87,18 @@ typedef enum clx_msg {
     CLX_MSG_INVALID_SAMPLE_RATE,         /* metadata.rs:373 */
     CLX_MSG_APPLICATION_BLOCK_TOO_SHORT, /* metadata.rs:527 */
     CLX_MSG_APPLICATION_BLOCK_TOO_LARGE, /* metadata.rs:534 (Unsupported) */
+    /* VORBIS_COMMENT (FLAC tags), metadata.rs:402-513 */
+    CLX_MSG_VC_TOO_SHORT,                /* metadata.rs:406 */
+    CLX_MSG_VC_TOO_LARGE,                /* metadata.rs:423 (Unsupported) */
+    CLX_MSG_VC_VENDOR_TOO_LONG,          /* metadata.rs:431 */
+    CLX_MSG_VC_TOO_MANY_ENTRIES,         /* metadata.rs:448 */
+    CLX_MSG_VC_COMMENT_TOO_LONG,         /* metadata.rs:462 */
+    CLX_MSG_VC_NAME_INVALID_BYTE,        /* metadata.rs:491 */
+    CLX_MSG_VC_NO_EQUALS,                /* metadata.rs:498 */
+    CLX_MSG_VC_EXCESS_DATA,              /* metadata.rs:503 */
+    CLX_MSG_VC_WRONG_COUNT,              /* metadata.rs:507 */
+    CLX_MSG_VC_NOT_UTF8,                 /* error.rs:92 */
+    CLX_MSG_SECOND_VORBIS_COMMENT,       /* lib.rs:258 */
     CLX_MSG_COUNT
 } clx_msg;
 
@@ -251,6 +263,27 @@ typedef struct clx_reader clx_reader;
  * (lib.rs:186-205, 230-307; metadata.rs:214-400).  *audio_offset = first frame byte. */
 int clx_read_stream_header(const uint8_t* data, size_t len, clx_streaminfo* info,
                            size_t* audio_offset, uint32_t* msg);
+
+/* FLAC tags (VORBIS_COMMENT block; FlacReader::vendor / tags / get_tag, lib.rs:321-360, metadata.rs:73-212). */
+typedef struct clx_tags clx_tags;
+enum {
+    CLX_OPT_METADATA_ONLY        = 1u << 0,   /* FlacReaderOptions::metadata_only (lib.rs:131): stop once the wanted metadata is in */
+    CLX_OPT_NO_VORBIS_COMMENT    = 1u << 1    /* FlacReaderOptions::read_vorbis_comment = false (lib.rs:141) */
+};
+/* FlacReader::new_ext (lib.rs:230-307) on an in-memory stream: clx_read_stream_header plus the tags.  *tags (may be
+ * NULL on return: the stream has no Vorbis comment block, or it was not asked for) is owned by the caller. */
+int clx_read_stream_header_ext(const uint8_t* data, size_t len, uint32_t options, clx_streaminfo* info,
+                               size_t* audio_offset, clx_tags** tags, uint32_t* msg);
+const char* clx_tags_vendor(const clx_tags* t, size_t* len);              /* the vendor string (UTF-8, not NUL-safe: use *len) */
+size_t      clx_tags_count(const clx_tags* t);
+/* i-th "NAME=value" pair in stream order; pointers stay valid until clx_tags_free */
+int         clx_tags_get(const clx_tags* t, size_t i, const char** name, size_t* name_len, const char** value, size_t* value_len);
+/* value of the `occurrence`-th tag whose name equals `name` ASCII-case-insensitively (metadata::GetTag, metadata.rs:197-211);
+ * NULL when there is none */
+const char* clx_tags_lookup(const clx_tags* t, const char* name, size_t occurrence, size_t* value_len);
+void        clx_tags_free(clx_tags* t);
+/* tags of an open reader (NULL if the stream has none); owned by the reader */
+const clx_tags* clx_reader_tags(const clx_reader* r);
 
 int  clx_reader_open(clx_ctx* ctx, const char* path, clx_reader** out, uint32_t* msg);       /* lib.rs:455 */
 int  clx_reader_new(clx_ctx* ctx, const uint8_t* data, size_t len, clx_reader** out, uint32_t* msg); /* lib.rs:217 */

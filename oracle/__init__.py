@@ -190,6 +190,38 @@ def stream_open(data):
     return st, int(msg.value), si, int(off.value)
 
 
+def stream_open_ext(data, metadata_only=False, read_vorbis_comment=True):
+    """FlacReader::new_ext (lib.rs:230-307).  Returns (status, msg, streaminfo, audio offset, vendor|None, [(name, value)])
+    with vendor / names / values as bytes."""
+    import struct
+    a = _bytes_arr(data)
+    si = StreamInfo()
+    off = C.c_uint64(0)
+    msg = C.c_uint32(0)
+    cap = a.size + 64
+    buf = np.zeros(cap, dtype=np.uint8)
+    tl = C.c_size_t(0)
+    L = lib()
+    L.clxo_stream_open_ext.restype = C.c_int
+    L.clxo_stream_open_ext.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(StreamInfo), C.POINTER(C.c_uint64),
+                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+    opts = (1 if metadata_only else 0) | (0 if read_vorbis_comment else 2)
+    st = L.clxo_stream_open_ext(_ptr(a), a.size, opts, C.byref(si), C.byref(off), buf.ctypes.data, cap, C.byref(tl), C.byref(msg))
+    vendor, tags = None, []
+    if st == STATUS_OK and tl.value:
+        raw = buf[:tl.value].tobytes()
+        (vl,) = struct.unpack_from("=I", raw, 0)
+        vendor = raw[4:4 + vl]
+        (n,) = struct.unpack_from("=I", raw, 4 + vl)
+        p = 8 + vl
+        for _ in range(n):
+            ln, sep = struct.unpack_from("=II", raw, p)
+            c = raw[p + 8:p + 8 + ln]
+            tags.append((c[:sep], c[sep + 1:]))
+            p += 8 + ln
+    return st, int(msg.value), si, int(off.value), vendor, tags
+
+
 def decode_stream(data, check_crc=True):
     """FlacReader::new + blocks() loop.  Returns (streaminfo, [(FrameInfo, samples)], final_status, final_msg)."""
     a = _bytes_arr(data)

@@ -734,13 +734,89 @@ static int cur_be(const uint8_t* d, size_t len, size_t* pos, int nbytes, uint64_
     *v = r; return 1;
 }
 
-/* FlacReader::new_ext with default options, lib.rs:230-307: `fLaC` marker
- * (lib.rs:186-205), STREAMINFO first (metadata.rs:321-400), then every other
- * block skipped by its length until the last-block flag (metadata.rs:214-319,
- * 557-609).  VORBIS_COMMENT contents are not parsed (out of scope):
- * it is skipped like padding, so the DoS / UTF-8 errors of metadata.rs:402-513
- * are NOT modelled. */
+/* ---- VORBIS_COMMENT (metadata.rs:402-513): a flat record of the parsed block for the tests ----
+ * out layout: [u32 vendor_len][vendor bytes][u32 n][ n x { u32 len, u32 sep, bytes } ]  (native endian) */
+static int utf8_ok(const uint8_t* p, size_t n) {           /* String::from_utf8 */
+    size_t i = 0;
+    while (i < n) {
+        uint8_t b = p[i];
+        uint32_t cp, min; size_t need;
+        if (b < 0x80) { i++; continue; }
+        if ((b & 0xe0) == 0xc0) { need = 1; cp = b & 0x1f; min = 0x80; }
+        else if ((b & 0xf0) == 0xe0) { need = 2; cp = b & 0x0f; min = 0x800; }
+        else if ((b & 0xf8) == 0xf0) { need = 3; cp = b & 0x07; min = 0x10000; }
+        else return 0;
+        if (i + need >= n) return 0;
+        for (size_t k = 1; k <= need; k++) { if ((p[i + k] & 0xc0) != 0x80) return 0; cp = (cp << 6) | (p[i + k] & 0x3f); }
+        if (cp < min || cp > 0x10ffff || (cp >= 0xd800 && cp <= 0xdfff)) return 0;
+        i += need + 1;
+    }
+    return 1;
+}
+static int cur_le32(const uint8_t* d, size_t len, size_t* pos, uint32_t* v) {
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) { uint32_t b; if (!cur_u8(d, len, pos, &b)) return 0; r |= b << (8 * i); }
+    *v = r; return 1;
+}
+static void put32(uint8_t* out, size_t cap, size_t* w, uint32_t v) { if (out && *w + 4 <= cap) memcpy(out + *w, &v, 4); *w += 4; }
+static void putn(uint8_t* out, size_t cap, size_t* w, const uint8_t* p, size_t n) { if (out && *w + n <= cap) memcpy(out + *w, p, n); *w += n; }
+
+static int read_vorbis_comment_block(const uint8_t* d, size_t len, size_t* pos, uint32_t length, uint8_t* out, size_t cap, size_t* w, uint32_t* msg) {
+    if (length < 8) { *msg = CLX_MSG_VC_TOO_SHORT; return CLX_FORMAT_ERROR; }                       /* metadata.rs:403-407 */
+    if (length > 10u * 1024 * 1024) { *msg = CLX_MSG_VC_TOO_LARGE; return CLX_UNSUPPORTED; }         /* 422-425 */
+    uint32_t vendor_len;
+    if (!cur_le32(d, len, pos, &vendor_len)) goto eof;                                               /* 430 */
+    if (vendor_len > length - 8) { *msg = CLX_MSG_VC_VENDOR_TOO_LONG; return CLX_FORMAT_ERROR; }     /* 431 */
+    if (vendor_len > len - *pos) goto eof;                                                           /* 438 read_into */
+    if (!utf8_ok(d + *pos, vendor_len)) { *msg = CLX_MSG_VC_NOT_UTF8; return CLX_FORMAT_ERROR; }     /* 439 */
+    put32(out, cap, w, vendor_len); putn(out, cap, w, d + *pos, vendor_len);
+    *pos += vendor_len;
+    uint32_t comments_len;
+    if (!cur_le32(d, len, pos, &comments_len)) goto eof;                                             /* 446 */
+    if (comments_len >= length / 4) { *msg = CLX_MSG_VC_TOO_MANY_ENTRIES; return CLX_FORMAT_ERROR; } /* 447-449 */
+    size_t count_at = *w;
+    put32(out, cap, w, 0);
+    uint32_t n = 0, bytes_left = length - 8 - vendor_len;
+    while (bytes_left >= 4 && n < comments_len) {                                                    /* 456 */
+        uint32_t clen;
+        if (!cur_le32(d, len, pos, &clen)) goto eof;
+        bytes_left -= 4;
+        if (clen > bytes_left) { *msg = CLX_MSG_VC_COMMENT_TOO_LONG; return CLX_FORMAT_ERROR; }      /* 460-462 */
+        if (clen == 0) { comments_len -= 1; continue; }                                              /* 467-471 */
+        if (clen > len - *pos) goto eof;                                                             /* 476 */
+        const uint8_t* c = d + *pos;
+        *pos += clen;
+        bytes_left -= clen;
+        uint32_t sep = clen;
+        for (uint32_t i = 0; i < clen; i++) if (c[i] == '=') { sep = i; break; }                     /* 480 */
+        if (sep == clen) { *msg = CLX_MSG_VC_NO_EQUALS; return CLX_FORMAT_ERROR; }                   /* 497-499 */
+        for (uint32_t i = 0; i < sep; i++) if (c[i] < 0x20 || c[i] > 0x7d) { *msg = CLX_MSG_VC_NAME_INVALID_BYTE; return CLX_FORMAT_ERROR; }   /* 488-492 */
+        if (!utf8_ok(c, clen)) { *msg = CLX_MSG_VC_NOT_UTF8; return CLX_FORMAT_ERROR; }              /* 495 */
+        put32(out, cap, w, clen); put32(out, cap, w, sep); putn(out, cap, w, c, clen);
+        n++;
+    }
+    if (bytes_left != 0) { *msg = CLX_MSG_VC_EXCESS_DATA; return CLX_FORMAT_ERROR; }                 /* 502-504 */
+    if (n != comments_len) { *msg = CLX_MSG_VC_WRONG_COUNT; return CLX_FORMAT_ERROR; }               /* 506-508 */
+    if (out && count_at + 4 <= cap) memcpy(out + count_at, &n, 4);
+    return CLX_OK;
+eof:
+    *msg = CLX_MSG_UNEXPECTED_EOF;
+    return CLX_IO_ERROR;
+}
+
+/* FlacReader::new_ext, lib.rs:230-307: `fLaC` marker (lib.rs:186-205), STREAMINFO first (metadata.rs:321-400), the
+ * Vorbis comment block parsed (metadata.rs:402-513; a second one is an error, lib.rs:257-259), every other block
+ * skipped by its length (metadata.rs:266-318) until the last-block flag or the options' early-out (lib.rs:273-277).
+ * options: bit 0 metadata_only, bit 1 read_vorbis_comment = false.  tags_out (may be NULL) receives the flat record
+ * described above, *tags_len its length (0: no Vorbis comment kept). */
+int clxo_stream_open_ext(const uint8_t* d, size_t len, uint32_t options, clx_streaminfo* si, uint64_t* audio_off,
+                         uint8_t* tags_out, size_t tags_cap, size_t* tags_len, uint32_t* msg);
 int clxo_stream_open(const uint8_t* d, size_t len, clx_streaminfo* si, uint64_t* audio_off, uint32_t* msg) {
+    size_t tl = 0;
+    return clxo_stream_open_ext(d, len, 0, si, audio_off, NULL, 0, &tl, msg);
+}
+int clxo_stream_open_ext(const uint8_t* d, size_t len, uint32_t options, clx_streaminfo* si, uint64_t* audio_off,
+                         uint8_t* tags_out, size_t tags_cap, size_t* tags_len, uint32_t* msg) {
     size_t pos = 0;
     uint64_t hdr;
     *msg = CLX_MSG_NONE;
@@ -749,7 +825,10 @@ int clxo_stream_open(const uint8_t* d, size_t len, clx_streaminfo* si, uint64_t*
         *msg = ((hdr & 0xffffff00u) == 0x49443300u) ? CLX_MSG_ID3_HEADER : CLX_MSG_INVALID_STREAM_HEADER;
         return CLX_FORMAT_ERROR;
     }
-    int first = 1, have_si = 0;
+    int first = 1, have_si = 0, have_vc = 0;
+    const int metadata_only = (options & 1u) != 0;
+    int want_vc = (options & 2u) == 0;
+    *tags_len = 0;
     for (;;) {
         uint32_t b;
         uint64_t length;
@@ -787,6 +866,13 @@ int clxo_stream_open(const uint8_t* d, size_t len, clx_streaminfo* si, uint64_t*
             if (s.sample_rate == 0 || s.sample_rate > 655350) { *msg = CLX_MSG_INVALID_SAMPLE_RATE; return CLX_FORMAT_ERROR; }
             if (!first) { *msg = CLX_MSG_SECOND_STREAMINFO; return CLX_FORMAT_ERROR; }   /* lib.rs:267-269 */
             *si = s; have_si = 1;
+        } else if (block_type == 4) {
+            size_t w = 0;
+            int st = read_vorbis_comment_block(d, len, &pos, (uint32_t)length, tags_out, tags_cap, &w, msg);   /* metadata.rs:291-294 */
+            if (st != CLX_OK) return st;
+            if (first) { *msg = CLX_MSG_STREAMINFO_MISSING; return CLX_FORMAT_ERROR; }                  /* lib.rs:244-248 */
+            if (have_vc) { *msg = CLX_MSG_SECOND_VORBIS_COMMENT; return CLX_FORMAT_ERROR; }             /* lib.rs:257-259 */
+            have_vc = 1; want_vc = 0; *tags_len = w;
         } else {
             if (first) {
                 /* lib.rs:244-248: the first block must be streaminfo.  The block is
@@ -801,10 +887,15 @@ int clxo_stream_open(const uint8_t* d, size_t len, clx_streaminfo* si, uint64_t*
             pos += (size_t)length;
             if (first) { *msg = CLX_MSG_STREAMINFO_MISSING; return CLX_FORMAT_ERROR; }
         }
-        first = 0;
-        if (is_last) break;
+        {
+            const int was_first = first;
+            first = 0;
+            if (is_last) break;
+            if (!was_first && metadata_only && !want_vc) break;                                          /* lib.rs:273-277 */
+        }
     }
     (void)have_si;
+    if (options & 2u) *tags_len = 0;                                                                  /* lib.rs:283-285 */
     *audio_off = pos;
     return CLX_OK;
 eof:
