@@ -556,7 +556,7 @@ __device__ __forceinline__ void clx_iir_block(const int32_t (&x)[CLX_BLK], int32
             for (int j = OMAX - 1; j >= 0; --j) acc += (int64_t)c[j] * (int64_t)hist[j];   // newest tap last: shortest dependent chain
             pred = (int32_t)(acc >> shift);
         } else {
-            const int32_t acc = clx_dot24<OMAX>(c, hist, 0);                               // v_mad_i32_i24 chain, newest tap last
+            const int32_t acc = clx_dot24z<OMAX>(c, hist);                               // v_mad_i32_i24 chain, newest tap last
             pred = acc >> shift;
         }
         int32_t s;
@@ -670,12 +670,13 @@ struct K2Predictor {
 
 // wasted-bits shift (subframe.rs:216-225) and stereo decorrelation (frame.rs:319-389) of a finished block
 struct K2Finisher {
-    uint32_t wasted, sgn, rmask, s1, bit, sg;
+    uint32_t wasted, sgn, nsg, rmask, s1, bit, sg;
     bool p_other, r_other, any_decor, all_ms, any_wasted;
     __device__ __forceinline__ void init(const K2Slot& S, int lane) {
         const bool odd = (lane & 1) != 0;
         wasted = S.wasted;
         sgn = odd ? 0xffffffffu : 0u;                          // (x ^ sgn) - sgn = odd ? -x : x
+        nsg = odd ? 1u : 0u;
         // per-lane constants of the generic formula  v = ((P << s1 | R & bit) + (R ^ sg) - sg) >> s1
         //   mid/side  even: P = mid (mine),  R = side (other), s1 = 1              frame.rs:382-384
         //             odd : P = mid (other), R = side (mine),  s1 = 1, minus
@@ -707,12 +708,9 @@ struct K2Finisher {
 #pragma unroll
         for (int i = 0; i < CLX_BLK; ++i) {
             if (MODE == 0) {
-                // every lane belongs to a mid/side pair: two DPP broadcasts give (mid, side) to both lanes of the pair
-                const int32_t mid = __builtin_amdgcn_update_dpp(0, y[i], 0xA0, 0xF, 0xF, false);     // quad_perm [0,0,2,2]
-                const int32_t side = __builtin_amdgcn_update_dpp(0, y[i], 0xF5, 0xF, 0xF, false);    // quad_perm [1,1,3,3]
-                const uint32_t m = ((uint32_t)mid << 1) | ((uint32_t)side & 1u);
-                // left = (m + side) >> 1, right = (m - side) >> 1 (frame.rs:382-384; m +- side is even)
-                y[i] = (int32_t)(m + (((uint32_t)side ^ sgn) - sgn)) >> 1;
+                // every lane belongs to a mid/side pair: left = (m + side) >> 1, right = (m - side) >> 1 with
+                // m = (mid << 1) | (side & 1)  (frame.rs:382-384; m +- side is even)
+                y[i] = clx_ms_pair(y[i], sgn, nsg, 1u);
             } else if (MODE == 1) {
                 const int32_t mine = y[i];
                 const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);   // lane ^ 1

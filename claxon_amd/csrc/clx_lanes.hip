@@ -412,7 +412,7 @@ __device__ __forceinline__ int32_t clx_lpredict(const int32_t (&c)[OMAX], const 
         for (int j = OMAX - 1; j >= 0; --j) acc += (int64_t)c[j] * (int64_t)hist[j];
         return (int32_t)(acc >> shift);
     } else {
-        return clx_dot24<OMAX>(c, hist, 0) >> shift;                              // v_mad_i32_i24 chain, newest tap last
+        return clx_dot24z<OMAX>(c, hist) >> shift;                              // v_mad_i32_i24 chain, newest tap last
     }
 }
 
@@ -512,12 +512,8 @@ __device__ __forceinline__ Finish clx_lfinish_setup(uint32_t n, uint32_t wasted,
 __device__ __forceinline__ int32_t clx_lfinish(int32_t s, const Finish& F) {
     int32_t mine = F.any_wasted ? (int32_t)((uint32_t)s << F.wasted) : s;
     if (F.all_ms) {
-        // every lane belongs to a mid/side pair: two DPP broadcasts give (mid, side) to both lanes of the pair
-        const int32_t mid = __builtin_amdgcn_update_dpp(0, mine, 0xA0, 0xF, 0xF, false);      // quad_perm [0,0,2,2]
-        const int32_t side = __builtin_amdgcn_update_dpp(0, mine, 0xF5, 0xF, 0xF, false);     // quad_perm [1,1,3,3]
-        const uint32_t m = ((uint32_t)mid << 1) | ((uint32_t)side & 1u);
-        // left = (m + side) >> 1, right = (m - side) >> 1 (frame.rs:382-384; m +- side is even)
-        return (int32_t)(m + (((uint32_t)side ^ F.sgn) - F.sgn)) >> 1;
+        // every lane belongs to a mid/side pair: left = (m + side) >> 1, right = (m - side) >> 1 (frame.rs:382-384)
+        return clx_ms_pair(mine, F.sgn, F.sgn & 1u, 1u);
     }
     if (F.any_decor) {
         const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);       // lane ^ 1

@@ -52,6 +52,47 @@ template <> __device__ __forceinline__ int32_t clx_dot24<32>(const int32_t* c, c
     acc = clx_dot24<8>(c + 24, h + 24, acc); acc = clx_dot24<8>(c + 16, h + 16, acc);
     acc = clx_dot24<8>(c + 8, h + 8, acc);   return clx_dot24<8>(c, h, acc);
 }
+// The same starting from zero: the first mad takes the constant 0 as its addend, which saves the v_mov that would
+// otherwise clear the accumulator for every sample.
+template <int N> __device__ __forceinline__ int32_t clx_dot24z(const int32_t* c, const int32_t* h);
+template <> __device__ __forceinline__ int32_t clx_dot24z<4>(const int32_t* c, const int32_t* h) {
+    int32_t acc;
+    asm volatile("v_mad_i32_i24 %0, %1, %2, 0\n\tv_mad_i32_i24 %0, %3, %4, %0\n\tv_mad_i32_i24 %0, %5, %6, %0\n\tv_mad_i32_i24 %0, %7, %8, %0"
+                 : "=&v"(acc) : "v"(c[3]), "v"(h[3]), "v"(c[2]), "v"(h[2]), "v"(c[1]), "v"(h[1]), "v"(c[0]), "v"(h[0]));
+    return acc;
+}
+template <> __device__ __forceinline__ int32_t clx_dot24z<8>(const int32_t* c, const int32_t* h) {
+    int32_t acc;
+    asm volatile("v_mad_i32_i24 %0, %1, %2, 0\n\tv_mad_i32_i24 %0, %3, %4, %0\n\tv_mad_i32_i24 %0, %5, %6, %0\n\tv_mad_i32_i24 %0, %7, %8, %0\n\t"
+                 "v_mad_i32_i24 %0, %9, %10, %0\n\tv_mad_i32_i24 %0, %11, %12, %0\n\tv_mad_i32_i24 %0, %13, %14, %0\n\tv_mad_i32_i24 %0, %15, %16, %0"
+                 : "=&v"(acc) : "v"(c[7]), "v"(h[7]), "v"(c[6]), "v"(h[6]), "v"(c[5]), "v"(h[5]), "v"(c[4]), "v"(h[4]),
+                                "v"(c[3]), "v"(h[3]), "v"(c[2]), "v"(h[2]), "v"(c[1]), "v"(h[1]), "v"(c[0]), "v"(h[0]));
+    return acc;
+}
+template <> __device__ __forceinline__ int32_t clx_dot24z<12>(const int32_t* c, const int32_t* h) {
+    return clx_dot24<8>(c, h, clx_dot24z<4>(c + 8, h + 8));
+}
+template <> __device__ __forceinline__ int32_t clx_dot24z<32>(const int32_t* c, const int32_t* h) {
+    int32_t acc = clx_dot24z<8>(c + 24, h + 24); acc = clx_dot24<8>(c + 16, h + 16, acc);
+    acc = clx_dot24<8>(c + 8, h + 8, acc);       return clx_dot24<8>(c, h, acc);
+}
+// Mid/side reconstruction of one sample for a lane pair (even lane = mid -> left, odd lane = side -> right; frame.rs:371-389):
+//   m = (mid << 1) | (side & 1);   y = (m + (odd ? -side : side)) >> 1        with sgn = odd ? ~0 : 0, nsg = odd ? 1 : 0
+// Six instructions: the partner's value enters the AND / XOR as a DPP operand instead of through v_mov_dpp copies (which
+// also need their destination cleared first).  The leading s_nop covers the two wait states a DPP read needs after a
+// VALU write of the same register -- hipcc cannot see into the statement.
+__device__ __forceinline__ int32_t clx_ms_pair(int32_t y, uint32_t sgn, uint32_t nsg, uint32_t one) {
+    int32_t out; uint32_t t, x, mid;
+    asm volatile("s_nop 1\n\t"
+                 "v_and_b32_dpp %1, %4, %7 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %2, %4, %5 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %3, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_lshl_or_b32 %3, %3, 1, %1\n\t"
+                 "v_add3_u32 %0, %3, %2, %6\n\t"
+                 "v_ashrrev_i32 %0, 1, %0"
+                 : "=&v"(out), "=&v"(t), "=&v"(x), "=&v"(mid) : "v"(y), "v"(sgn), "v"(nsg), "v"(one));
+    return out;
+}
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at lds_base + 16*lane (no VGPR
 // round trip, asynchronous, counted by vmcnt).  Inline asm on purpose: hipcc drains vmcnt(0) before the next LDS read
 // when it can see the DMA, which would serialise a prefetch ring; with asm the waits are placed by hand

@@ -20,6 +20,14 @@ template <int N> static inline int32_t clx_dot24(const int32_t* c, const int32_t
     for (int j = N - 1; j >= 0; --j) acc = clx_mad24(c[j], h[j], acc);
     return acc;
 }
+template <int N> static inline int32_t clx_dot24z(const int32_t* c, const int32_t* h) { return clx_dot24<N>(c, h, 0); }
+static inline int32_t clx_ms_pair_(int line, int32_t y, uint32_t sgn, uint32_t nsg, uint32_t one) {
+    const uint32_t side = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xF5, 0xF, 0xF, false);
+    const uint32_t mid = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xA0, 0xF, 0xF, false);
+    const uint32_t m = (mid << 1) | (side & one);
+    return (int32_t)(m + (side ^ sgn) + nsg) >> 1;
+}
+#define clx_ms_pair(y, sgn, nsg, one) clx_ms_pair_(__LINE__, (y), (sgn), (nsg), (one))
 // LDS-DMA in the simulator: synchronous copy; the "LDS address" is simply the host pointer of the shared object.
 static inline uintptr_t clx_lds_addr(const void* p) { return (uintptr_t)p; }
 static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {
