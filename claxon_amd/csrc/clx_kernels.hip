@@ -4,12 +4,14 @@
 //                        Rice/Rice2 partitioned residual decode (wave-parallel), CONSTANT / VERBATIM fill.
 //                        Replaces subframe.rs:29-91, 236-415, 492-511, 651-708 and the channel dispatch
 //                        of frame.rs:705-742 (one bit cursor, subframes in sequence).
-//   K2  clx_k_predict    one lane per channel: fixed / LPC synthesis as an integer IIR (i64 accumulate,
-//                        arithmetic >> shift, wrapping i32), wasted-bits shift, and the left/side,
-//                        right/side, mid/side decorrelation fused into the coalesced write-back.
-//                        Replaces subframe.rs:216-225, 417-474, 524-614 and frame.rs:319-389.
+//   K2  clx_k_predict    one lane per channel, two waves per 64 channels: fixed / LPC synthesis as an integer
+//                        IIR (i64 accumulate, arithmetic >> shift, wrapping i32) in the predictor wave;
+//                        wasted-bits shift, left/side, right/side, mid/side decorrelation and the write-back
+//                        in the finisher wave.  Replaces subframe.rs:216-225, 417-474, 524-614, frame.rs:319-389.
 //   K3  clx_k_crc16      one wavefront per frame: CRC-16 of the frame's bytes against its footer
 //                        (frame.rs:752-763, crc.rs:109-112) as a GF(2) fold of per-lane partial CRCs.
+//   K4  clx_k_interleave planar i32 -> channel-interleaved little-endian PCM (lib.rs:473-520).
+//   K5-K7 clx_k_find_headers / clx_k_span_crc16 / clx_k_gather_headers: frame indexer for raw streams (8 f2).
 //
 // No MFMA anywhere: this is bit-serial / integer-recurrence work bounded by HBM traffic and issue
 // latency, not a dense contraction.  All data-dependent control flow around cross-lane operations
@@ -524,19 +526,18 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 
 // ------------------------------------------------------------------------------------------------
 // K2: predictor synthesis + wasted-bits shift + stereo decorrelation.  One lane per subframe
-// ("predictor slot"), 64 slots per wave, everything in registers: each lane streams its own channel
-// with 16-byte loads / stores, BLK = 16 samples at a time (one 64-byte segment per row per block, so
-// every HBM sector that is touched is fully used), the next block in flight while the current one is
-// computed.  The recurrence
+// ("predictor slot"), 64 slots per pair of waves, BLK = 16 samples per turn: a tile of 64 rows x 64 bytes
+// travels HBM -> LDS (DMA) -> predictor wave -> LDS -> finisher wave -> HBM (the memory side and the
+// two-wave schedule are described further down, above clx_predict_wave).  The recurrence
 //     s[i] = x[i] + ((sum_j c[j]*s[i-1-j]) >> shift)          subframe.rs:559-566, 575-582, 606-613
 // needs an i64 accumulator in general.  When K1 proved  sum|c| * 2^(sf_bps-1) < 2^31  and
 // sf_bps <= 24  (clx_sf_desc::lim_log2), the sum of a VALID stream fits i32 and every factor fits
 // 24 bits, so the block is first run with v_mad_i32_i24 (full rate) and its outputs are range-checked;
 // a block in which any lane leaves the proven range (corrupt streams only) is re-run with
 // v_mad_i64_i32, which is exact for any input -- garbage in, the reference's garbage out.
-// The stereo partner sits in lane^1 (host aligns decorrelated pairs to even slots) and is fetched
-// with a DPP quad permute; decorrelation (frame.rs:319-389) happens on the finished block, off the
-// recurrence's critical path.
+// The stereo partner sits in lane^1 (host aligns decorrelated pairs to even slots) and enters the
+// finisher's arithmetic as a DPP operand; decorrelation (frame.rs:319-389) is off the recurrence's
+// critical path, in a different wave.
 // ------------------------------------------------------------------------------------------------
 #define CLX_BLK 16
 
