@@ -242,6 +242,17 @@ __device__ __forceinline__ Win clx_win_load(const uint32_t* row, uint32_t pos) {
     w.e = off ? clx_alignbit(w4, w5, sh) : w4;
     return w;
 }
+// the same with 64-bit shifts: five instructions instead of five funnel shifts + five selects for off == 0
+__device__ __forceinline__ Win clx_win_load64(const uint32_t* row, uint32_t pos) {
+    const uint32_t s = (pos >> 5) & (CLX_RING - 1u);
+    const uint32_t w0 = row[s], w1 = row[s + 1u], w2 = row[s + 2u], w3 = row[s + 3u], w4 = row[s + 4u], w5 = row[s + 5u];
+    const uint32_t off = pos & 31u;
+    Win w;
+    w.a = (uint32_t)(((((uint64_t)w0 << 32) | w1) << off) >> 32); w.b = (uint32_t)(((((uint64_t)w1 << 32) | w2) << off) >> 32);
+    w.c = (uint32_t)(((((uint64_t)w2 << 32) | w3) << off) >> 32); w.d = (uint32_t)(((((uint64_t)w3 << 32) | w4) << off) >> 32);
+    w.e = (uint32_t)(((((uint64_t)w4 << 32) | w5) << off) >> 32);
+    return w;
+}
 // drop nb (1..32) bits
 __device__ __forceinline__ void clx_win_skip(Win& w, uint32_t nb) {
     const uint32_t sh = 32u - nb;                         // alignbit uses sh & 31: nb = 32 -> whole-register move
@@ -328,9 +339,28 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         if (lmax != 0u) clx_ring_reset(g, row, r.pos >> 5, r.limit);
         for (uint32_t i0 = 0; i0 < lmax; i0 += 4u) {
             if ((i0 & 12u) == 0u && i0 != 0u) clx_ring_pump(g, row, r.pos, r.limit);
-            // fast block: 4 codes from a register window, no EOF possible, every code <= 32 bits; committed only if
-            // every lane stayed on the common path
             const bool busy = left >= 4u;
+            // lean block: 4 codes of ONE partition (the common case: lanes that decode subframes of the same shape meet
+            // their partition boundaries in the same block) -- count zeros, add, shift the window, nothing else; one vote
+            {
+                Win w = clx_win_load64(row, r.pos);
+                uint32_t p = r.pos, mx = 0;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const uint32_t nb = (uint32_t)__clz((int)w.a) + k1;        // 32 + k1 when the window is all zeros
+                    mx = nb > mx ? nb : mx;
+                    clx_win_skip(w, nb);
+                    p += nb;
+                }
+                // (a lane with 1..3 codes left sends the wave to the general block, which finishes tails)
+                const bool lean_ok = busy ? (pcnt >= 4u && r.pos <= g.fast_lim && mx <= 32u) : (left == 0u || r.err != 0u);
+                if (__all(lean_ok)) {
+                    if (busy) { r.pos = p; pcnt -= 4u; left -= 4u; }
+                    continue;
+                }
+            }
+            // general block: 4 codes from a register window with partition parameters in between, no EOF possible, every
+            // code <= 32 bits; committed only if every lane stayed on the common path
             uint32_t pos2 = r.pos, pcnt2 = pcnt, k_2 = k, k1_2 = k1, parts2 = parts_left, next2 = next_cnt;
             bool ok = !busy || r.pos <= g.fast_lim;
             {
