@@ -579,109 +579,167 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     }
     // ---- steady state: blocks of 4 samples through the LDS ring, rolled back to careful steps when anything is unusual
     if (i0 < nmax) clx_ring_reset(g, ringrow, r.pos >> 5, r.limit);
-    bool wide = false;                                   // wave-uniform, sticky: i64 accumulate from now on
+    bool wide = false;                                   // sticky: i64 accumulate from now on (made wave-uniform where it is used)
+    bool no_lean = false;                                // wave-uniform, sticky: the lean block cannot succeed any more
     for (uint32_t t0 = i0; t0 < nmax; t0 += 4u) {
         if ((t0 & 12u) == 0u && t0 != i0) clx_ring_pump(g, ringrow, r.pos, r.limit);
         const bool live = (n != 0u) && !r.err && t0 < n;
-        const bool rice_on = live && S.phase == 1u;
-        const bool verb_on = live && S.phase == 0u;
-        bool can = true;
-        if (live) {
-            can = (t0 + 4u <= n) && S.phase != 3u;
-            if (S.phase != 2u) can = can && r.pos <= g.fast_lim;
-            if (S.phase == 1u) can = can && S.transitioned;
-        }
-        if (S.lim < 0 && live && S.order != 0u) wide = true;
-        uint32_t pos2 = r.pos, pcnt2 = S.pcnt, k_2 = S.k, k1_2 = S.k1, parts2 = S.parts_left, next2 = S.next_cnt;
-        int32_t xs[4];
-        bool ok = can;
-        const bool any_verb = __any(verb_on);
-        {
-            Win w = clx_win_load(ringrow, pos2);
-            const uint32_t vsh = (32u - h.sf_bps) & 31u;
+        int32_t y[4];
+        bool lean_done = false;
+        // ---- lean block: every live lane is in the middle of a Rice partition (or repeats a constant), nothing is near an
+        //      edge, the 24-bit predictor holds: four codes, four predictor steps, ONE vote.  Lanes that decode subframes
+        //      of the same shape meet their partition boundaries in the same block, so this is the common case by far.
+        if (!no_lean) {
+            const bool rice = S.phase == 1u;
+            const uint32_t rmask = rice ? 0xffffffffu : 0u;                    // constant lanes consume no bits
+            Win w = clx_win_load64(ringrow, r.pos);
+            uint32_t p = r.pos, mx = 0;
+            int32_t xs[4];
+            const uint32_t kk = S.k & 31u;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
-                if (__any(rice_on && pcnt2 == 0u)) {
-                    if (rice_on && pcnt2 == 0u) {                    // partition parameter (subframe.rs:314-319 / 362-367)
-                        const uint32_t pb = S.rice2 ? 5u : 4u;
-                        k_2 = w.a >> (32u - pb);
-                        if (k_2 == (S.rice2 ? 31u : 15u) || parts2 == 0u || next2 == 0u) ok = false;
-                        k1_2 = k_2 + 1u; pos2 += pb; parts2 -= 1u; pcnt2 = next2; next2 = S.per;
-                        clx_win_skip(w, pb);
+                const uint32_t z = (uint32_t)__clz((int)w.a);                  // 32 when the window is all zeros
+                const uint32_t nb = z + S.k1;
+                const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);    // (q << k) | r, subframe.rs:337-341
+                const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);      // rice_to_signed (subframe.rs:157-170)
+                xs[ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
+                const uint32_t nbm = nb & rmask;
+                mx = nbm > mx ? nbm : mx;
+                clx_win_skip(w, nb);
+                p += nbm;
+            }
+            int32_t hh[OMAX];
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) hh[j] = S.hist[j];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int32_t pred = clx_lpredict<OMAX, false>(S.c, hh, S.shift);      // taps beyond the order are zero
+                const int32_t sm = (int32_t)((uint32_t)xs[ii] + (uint32_t)pred);
+#pragma unroll
+                for (int j = OMAX - 1; j > 0; --j) hh[j] = hh[j - 1];
+                hh[0] = sm;
+                y[ii] = sm;
+            }
+            int32_t hi = clx_max3(y[0], y[1], y[2]), lo = clx_min3(y[0], y[1], y[2]);
+            hi = y[3] > hi ? y[3] : hi; lo = y[3] < lo ? y[3] : lo;
+            const bool in_range = S.order == 0u || (hi < S.lim && lo >= -S.lim);
+            const bool lean_ok = !live || ((rice ? (S.transitioned && S.pcnt >= 4u && r.pos <= g.fast_lim && mx <= 32u) : S.phase == 2u)
+                                           && t0 + 4u <= n && S.lim >= 0 && in_range);
+            if (__all(lean_ok)) {
+                if (live) {
+                    r.pos = p;
+                    if (rice) S.pcnt -= 4u;
+#pragma unroll
+                    for (int j = 0; j < OMAX; ++j) S.hist[j] = hh[j];
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], F);
+                lean_done = true;
+            } else if (__any(live && S.lim < 0 && S.order != 0u)) no_lean = true;   // a lane needs the i64 predictor from now on
+        }
+        if (!lean_done) {
+            const bool rice_on = live && S.phase == 1u;
+            const bool verb_on = live && S.phase == 0u;
+            bool can = true;
+            if (live) {
+                can = (t0 + 4u <= n) && S.phase != 3u;
+                if (S.phase != 2u) can = can && r.pos <= g.fast_lim;
+                if (S.phase == 1u) can = can && S.transitioned;
+            }
+            if (S.lim < 0 && live && S.order != 0u) wide = true;
+            uint32_t pos2 = r.pos, pcnt2 = S.pcnt, k_2 = S.k, k1_2 = S.k1, parts2 = S.parts_left, next2 = S.next_cnt;
+            int32_t xs[4];
+            bool ok = can;
+            const bool any_verb = __any(verb_on);
+            {
+                Win w = clx_win_load(ringrow, pos2);
+                const uint32_t vsh = (32u - h.sf_bps) & 31u;
+    #pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    if (__any(rice_on && pcnt2 == 0u)) {
+                        if (rice_on && pcnt2 == 0u) {                    // partition parameter (subframe.rs:314-319 / 362-367)
+                            const uint32_t pb = S.rice2 ? 5u : 4u;
+                            k_2 = w.a >> (32u - pb);
+                            if (k_2 == (S.rice2 ? 31u : 15u) || parts2 == 0u || next2 == 0u) ok = false;
+                            k1_2 = k_2 + 1u; pos2 += pb; parts2 -= 1u; pcnt2 = next2; next2 = S.per;
+                            clx_win_skip(w, pb);
+                        }
+                    }
+                    // one Rice code (subframe.rs:337-341): z zeros, a one, k remainder bits
+                    const uint32_t z = (uint32_t)__clz((int)w.a);        // 32 when the window is all zeros
+                    uint32_t nb = z + k1_2;
+                    if (rice_on && nb > 32u) ok = false;
+                    const uint32_t u = (z << (k_2 & 31u)) | clx_bfe(w.a, 32u - nb, k_2);
+                    int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);  // rice_to_signed (subframe.rs:157-170)
+                    if (any_verb) {                                      // verbatim rows ride along (subframe.rs:397-415)
+                        if (verb_on) { x = (int32_t)w.a >> vsh; nb = h.sf_bps; }
+                    }
+                    if (!rice_on && !verb_on) { x = S.cval; nb = 32u; }  // constant / idle lanes: window contents are irrelevant
+                    clx_win_skip(w, nb);
+                    if (rice_on || verb_on) pos2 += nb;
+                    pcnt2 -= 1u;
+                    xs[ii] = x;
+                }
+            }
+            const bool all_ok = __all(ok);
+            if (all_ok) {
+                if (live) { r.pos = pos2; S.pcnt = pcnt2; S.k = k_2; S.k1 = k1_2; S.parts_left = parts2; S.next_cnt = next2; }
+                // predictor over the block: 24-bit evaluation, range-checked; exact i64 re-run when outside the proven range
+                wide = __any(wide);
+                bool redo = wide;
+                int32_t h0[OMAX];
+    #pragma unroll
+                for (int j = 0; j < OMAX; ++j) h0[j] = S.hist[j];
+                if (!wide) {
+    #pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int32_t pred = clx_lpredict<OMAX, false>(S.c, S.hist, S.shift);
+                        const int32_t s = (int32_t)((uint32_t)xs[ii] + (S.order != 0u ? (uint32_t)pred : 0u));
+    #pragma unroll
+                        for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
+                        S.hist[0] = s;
+                        y[ii] = s;
+                    }
+                    int32_t mx = clx_max3(y[0], y[1], y[2]), mn = clx_min3(y[0], y[1], y[2]);
+                    mx = y[3] > mx ? y[3] : mx; mn = y[3] < mn ? y[3] : mn;
+                    const bool in_range = !live || S.order == 0u || (mx < S.lim && mn >= -S.lim);
+                    if (!__all(in_range)) { redo = true; wide = true; }
+                }
+                if (redo) {
+    #pragma unroll
+                    for (int j = 0; j < OMAX; ++j) S.hist[j] = h0[j];
+    #pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int32_t pred = clx_lpredict<OMAX, true>(S.c, S.hist, S.shift);
+                        const int32_t s = (int32_t)((uint32_t)xs[ii] + (S.order != 0u ? (uint32_t)pred : 0u));
+    #pragma unroll
+                        for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
+                        S.hist[0] = s;
+                        y[ii] = s;
                     }
                 }
-                // one Rice code (subframe.rs:337-341): z zeros, a one, k remainder bits
-                const uint32_t z = (uint32_t)__clz((int)w.a);        // 32 when the window is all zeros
-                uint32_t nb = z + k1_2;
-                if (rice_on && nb > 32u) ok = false;
-                const uint32_t u = (z << (k_2 & 31u)) | clx_bfe(w.a, 32u - nb, k_2);
-                int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);  // rice_to_signed (subframe.rs:157-170)
-                if (any_verb) {                                      // verbatim rows ride along (subframe.rs:397-415)
-                    if (verb_on) { x = (int32_t)w.a >> vsh; nb = h.sf_bps; }
-                }
-                if (!rice_on && !verb_on) { x = S.cval; nb = 32u; }  // constant / idle lanes: window contents are irrelevant
-                clx_win_skip(w, nb);
-                if (rice_on || verb_on) pos2 += nb;
-                pcnt2 -= 1u;
-                xs[ii] = x;
-            }
-        }
-        const bool all_ok = __all(ok);
-        int32_t y[4];
-        if (all_ok) {
-            if (live) { r.pos = pos2; S.pcnt = pcnt2; S.k = k_2; S.k1 = k1_2; S.parts_left = parts2; S.next_cnt = next2; }
-            // predictor over the block: 24-bit evaluation, range-checked; exact i64 re-run when outside the proven range
-            wide = __any(wide);
-            bool redo = wide;
-            int32_t h0[OMAX];
-#pragma unroll
-            for (int j = 0; j < OMAX; ++j) h0[j] = S.hist[j];
-            if (!wide) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int32_t pred = clx_lpredict<OMAX, false>(S.c, S.hist, S.shift);
-                    const int32_t s = (int32_t)((uint32_t)xs[ii] + (S.order != 0u ? (uint32_t)pred : 0u));
-#pragma unroll
-                    for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
-                    S.hist[0] = s;
-                    y[ii] = s;
-                }
-                int32_t mx = clx_max3(y[0], y[1], y[2]), mn = clx_min3(y[0], y[1], y[2]);
-                mx = y[3] > mx ? y[3] : mx; mn = y[3] < mn ? y[3] : mn;
-                const bool in_range = !live || S.order == 0u || (mx < S.lim && mn >= -S.lim);
-                if (!__all(in_range)) { redo = true; wide = true; }
-            }
-            if (redo) {
-#pragma unroll
-                for (int j = 0; j < OMAX; ++j) S.hist[j] = h0[j];
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
+    #pragma unroll
+                for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], F);
+            } else {
+                int32_t* const ys = reinterpret_cast<int32_t*>(&stage[(t0 >> 2) & 3u]);
+    #pragma unroll 1
+                for (uint32_t ii = 0; ii < 4u; ++ii) {
+                    const uint32_t i = t0 + ii;
+                    const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
                     const int32_t pred = clx_lpredict<OMAX, true>(S.c, S.hist, S.shift);
-                    const int32_t s = (int32_t)((uint32_t)xs[ii] + (S.order != 0u ? (uint32_t)pred : 0u));
-#pragma unroll
+                    const uint32_t use = (S.order != 0u && i >= S.order && i >= S.trans_at) ? 0xffffffffu : 0u;
+                    const int32_t s = (int32_t)((uint32_t)x + ((uint32_t)pred & use));
+    #pragma unroll
                     for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
                     S.hist[0] = s;
-                    y[ii] = s;
+                    ys[ii] = clx_lfinish(s, F);
                 }
+                const int4 yv = stage[(t0 >> 2) & 3u];
+                y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
             }
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], F);
-        } else {
-            int32_t* const ys = reinterpret_cast<int32_t*>(&stage[(t0 >> 2) & 3u]);
-#pragma unroll 1
-            for (uint32_t ii = 0; ii < 4u; ++ii) {
-                const uint32_t i = t0 + ii;
-                const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
-                const int32_t pred = clx_lpredict<OMAX, true>(S.c, S.hist, S.shift);
-                const uint32_t use = (S.order != 0u && i >= S.order && i >= S.trans_at) ? 0xffffffffu : 0u;
-                const int32_t s = (int32_t)((uint32_t)x + ((uint32_t)pred & use));
-#pragma unroll
-                for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
-                S.hist[0] = s;
-                ys[ii] = clx_lfinish(s, F);
-            }
-            const int4 yv = stage[(t0 >> 2) & 3u];
-            y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
+            // once a lane has left the proven range its history may hold values the 24-bit predictor cannot take:
+            // from here on only the general block (which then accumulates in i64) may run
+            if (__any(wide)) no_lean = true;
         }
         // ---- output: stage 16 bytes per block, write the row one full 64-byte segment at a time (scattered 16-byte
         //      stores issued microseconds apart reach HBM as partial-line writes: 2.8x write traffic when measured)

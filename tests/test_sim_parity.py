@@ -38,7 +38,7 @@ def test_sim_truncations(oracle, sim):
 
 
 def test_sim_bitflips(oracle, sim):
-    seen = pc.check_bitflips(oracle, sim, n_frames=10, trials=12)
+    seen = pc.check_bitflips(oracle, sim, n_frames=24, trials=20)      # same cases as the GPU test
     assert len(seen) >= 5
 
 
