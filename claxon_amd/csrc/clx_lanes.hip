@@ -156,11 +156,11 @@ __device__ __forceinline__ void clx_report_error(uint32_t* errkey, uint32_t fram
 // peek is one ds_read2_b32 + a funnel shift instead of a dependent global load (an L1 hit with 64
 // divergent lines costs >300 cycles; the code chain is serial in the bit position).  The ring is
 // filled split-phase with 16-byte loads: a granule requested at one block boundary is written to LDS
-// at the next, so HBM/L2 latency never sits on the decode chain.  Slots CLX_RING..CLX_RING+4 mirror slots
-// 0..4, so reading six consecutive dwords (one block's 160-bit register window) never wraps.
+// at the next, so HBM/L2 latency never sits on the decode chain.  Slots CLX_RING..CLX_RING+7 mirror slots
+// 0..7, so reading six consecutive dwords (one block's 160-bit register window) never wraps.
 // ------------------------------------------------------------------------------------------------
 #define CLX_RING 32u
-#define CLX_ROW (CLX_RING + 5u)
+#define CLX_ROW (CLX_RING + 8u)       // 40 dwords: rows stay 16-byte aligned, so a granule is one ds_write_b128
 struct LanesLds {
     uint32_t ring[64][CLX_ROW];
     int4 stage[64][4];         // per lane: the last (up to) 16 output samples, flushed as one 64-byte segment
@@ -181,13 +181,10 @@ __device__ __forceinline__ uint4 clx_ring_fetch(const Ring& g, uint32_t dw) {
     return v;
 }
 __device__ __forceinline__ void clx_ring_put(uint32_t* row, uint32_t dw, const uint4 v) {
-    const uint32_t s = dw & (CLX_RING - 1u);
-    row[s] = __builtin_bswap32(v.x); row[s + 1u] = __builtin_bswap32(v.y);
-    row[s + 2u] = __builtin_bswap32(v.z); row[s + 3u] = __builtin_bswap32(v.w);
-    if (s == 0u) {
-        row[CLX_RING] = __builtin_bswap32(v.x); row[CLX_RING + 1u] = __builtin_bswap32(v.y);
-        row[CLX_RING + 2u] = __builtin_bswap32(v.z); row[CLX_RING + 3u] = __builtin_bswap32(v.w);
-    } else if (s == 4u) row[CLX_RING + 4u] = __builtin_bswap32(v.x);
+    const uint32_t s = dw & (CLX_RING - 1u);                 // multiple of 4: granules are 16-byte aligned in the stream
+    const uint4 b = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+    *reinterpret_cast<uint4*>(row + s) = b;
+    if (s < 8u) *reinterpret_cast<uint4*>(row + CLX_RING + s) = b;      // slots 32..39 mirror slots 0..7
 }
 // A fast block (4 codes, <= 32 bits each, + partition parameters) reads at most 160+ bits: it may start at `pos` when
 // the ring holds 8 more dwords and the readable stream 160 more bits.

@@ -47,6 +47,7 @@ for kid, name, nw in kernels:
     if tl[:, 6:14].any():
         ph = tl[:, 6:14].astype(np.float64).sum(axis=0)
         print('   phase shares of wave time %:', ' '.join(f'{v:.1f}' for v in ph / (c1 - c0).sum() * 100))
+        print('   raw phase sums per wave:', ' '.join(f'{v:.0f}' for v in ph / tl.shape[0]))
     for i in np.argsort(end_us)[-3:]:
         print(f"     wave {i}: start {start_us[i]:.1f} end {end_us[i]:.1f} us")
     simd = (hwid >> 4) & 3
