@@ -327,11 +327,11 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     }
     for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
     // path: explicit flag, else by batch shape -- the lane-serial kernels need many independent subframes to fill
-    // the machine (their duration is one lane's serial chain: ~1.9 ms for 4096-sample subframes however few there
-    // are, until every SIMD has a wave), the wave-per-frame kernels scale with the batch (0.54 ms per 10k stereo
-    // frames).  Measured crossover on MI355X: 80k subframes 1.90 ms (waves) vs 2.11 ms
-    // (lanes); 128k subframes 2.84 vs 2.24 ms.
-    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 92000);
+    // the machine (their duration is one lane's serial chain: ~1.3 ms for 4096-sample subframes however few there
+    // are, until every SIMD has a wave), the wave-per-frame kernels scale with the batch (0.53 ms per 10k stereo
+    // frames).  Measured on MI355X: 20k subframes 0.53 ms (waves) vs 1.29 ms (lanes);
+    // 64k subframes 1.55 (waves, est.) vs 1.32 ms; 80k subframes 1.90 vs 1.55 ms; 128k subframes 2.84 vs 1.82 ms.
+    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 50000);
     if (!b->lanes) {
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
