@@ -219,6 +219,13 @@ struct clx_ctx {
     std::string last_error;
 };
 
+// K2 build by batch size (groups of 64 predictor slots); env CLX_K2_LATENCY_GROUPS overrides it for experiments
+static unsigned k2_latency_groups() {
+    static const unsigned v = [] { const char* e = std::getenv("CLX_K2_LATENCY_GROUPS"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 512u; }();
+    return v;
+}
+#define CLX_K2_LATENCY_GROUPS k2_latency_groups()
+
 struct clx_batch {
     clx_ctx* ctx = nullptr;
     size_t n = 0;
@@ -411,9 +418,20 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         if (!mark("clx_k_residual")) return CLX_API_ERROR;
         hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), 0, stream,
                            d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
-        if (!mark("clx_k_predict")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_predict, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_out,
-                           (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
+        // K2: the two-wave (latency) build while the groups of 64 rows are few, the one-wave (throughput) build beyond
+        const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
+        if (groups <= CLX_K2_LATENCY_GROUPS) {
+            if (!mark("clx_k_predict")) return CLX_API_ERROR;
+            hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(256), 0, stream, d_out,
+                               (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
+        } else {
+            if (!mark("clx_k_predict_1w")) return CLX_API_ERROR;
+            hipLaunchKernelGGL(clx_k_predict_1w, dim3(groups), dim3(64), 0, stream, d_out,
+                               (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
+            if (!mark("clx_k_predict_1w_hi")) return CLX_API_ERROR;         // groups with a predictor order above 12
+            hipLaunchKernelGGL(clx_k_predict_1w_hi, dim3(groups), dim3(64), 0, stream, d_out,
+                               (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
+        }
     }
     if (b->flags & CLX_VERIFY_CRC16) {
         if (!mark("clx_k_crc16")) return CLX_API_ERROR;

@@ -876,6 +876,74 @@ __device__ __forceinline__ void clx_finish_wave(int4 (*ring)[4][64], int4 (*scra
     clx_wait_vmcnt<0>();
 }
 
+// ---- aligned rows, throughput build: one wave per 64 rows ----------------------------------------------------------------
+// The two-wave schedule above buys latency: it halves ONE wave's instruction stream, which is what a small batch waits
+// for.  A large batch (several workgroups per CU) is bound by issue slots and LDS instead, and the barrier per turn
+// turns into convoys between workgroups that share SIMDs (measured: 80 000 rows take 0.77 ms in the two-wave build,
+// although their instructions fit in 0.25 ms).  This build keeps everything in one wave -- same tiles, same shapes, no
+// barrier -- with a short ring (the other waves of the SIMD hide the memory latency).
+//   turn i: wait DMA(i+1) | read x(i+1) | recurrence + finish on x(i) | tile | transposed read | 4 stores | DMA(i+DEPTH)
+//   VMEM ops younger than DMA(i+1) when turn i starts: turns i+2-DEPTH .. i-1, 8 each = 8*(DEPTH-2)
+template <int OMAX, int MODE, int DEPTH>
+__device__ __forceinline__ void clx_predict_single(int4 (*ring)[4][64], int32_t* __restrict__ out, const K2Slot& S, const K2Finisher& F,
+                                                   int32_t* __restrict__ dump, uint32_t nblk, int lane) {
+    K2Predictor<OMAX> P; P.init(S);
+    K2Mover M; M.init(out, S, lane);
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // lane = row view
+    auto dma = [&](uint32_t blk) __attribute__((always_inline)) {
+        const uint32_t t = blk * CLX_BLK + 4u * M.pc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t last = M.rn[k] >= 4u ? M.rn[k] - 4u : 0u;              // clamped: what lies past a row's end is never stored
+            clx_glds16(M.rp[k] + (t < last ? t : last), clx_lds_addr(&ring[blk % DEPTH][k][0]));
+        }
+    };
+    auto fetch = [&](int32_t (&x)[CLX_BLK], uint32_t blk) __attribute__((always_inline)) {
+        const int4* tile = &ring[blk % DEPTH][0][0];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const int4 v = tile[(uint32_t)lane * 4u + (q ^ sw)];
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+    };
+    int32_t xa[CLX_BLK], xb[CLX_BLK], y[CLX_BLK];
+    for (uint32_t i = 0; i < (uint32_t)DEPTH; ++i) dma(i);
+    clx_wait_vmcnt<4 * (DEPTH - 1)>();
+    clx_wave_sync();
+    fetch(xa, 0u);
+    auto turn = [&](int32_t (&xc)[CLX_BLK], int32_t (&xn)[CLX_BLK], uint32_t i) __attribute__((always_inline)) {
+        if (i + 2u <= (uint32_t)DEPTH) clx_wait_vmcnt<4 * (DEPTH - 2)>(); else clx_wait_vmcnt<8 * (DEPTH - 2)>();
+        clx_wave_sync();
+        fetch(xn, i + 1u);
+        P.block(xc, y, i * CLX_BLK, K2NoHook());
+        F.template block<MODE>(y, K2NoHook());
+        int4* tile = &ring[i % DEPTH][0][0];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) tile[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        clx_wave_sync();
+        const uint32_t t = i * CLX_BLK + 4u * M.pc;
+        int4 w0 = tile[lane], w1 = tile[64 + lane], w2 = tile[128 + lane], w3 = tile[192 + lane];
+        *reinterpret_cast<int4*>(t < M.rn[0] ? const_cast<int32_t*>(M.rp[0]) + t : dump + 0) = w0;
+        *reinterpret_cast<int4*>(t < M.rn[1] ? const_cast<int32_t*>(M.rp[1]) + t : dump + 4) = w1;
+        *reinterpret_cast<int4*>(t < M.rn[2] ? const_cast<int32_t*>(M.rp[2]) + t : dump + 8) = w2;
+        *reinterpret_cast<int4*>(t < M.rn[3] ? const_cast<int32_t*>(M.rp[3]) + t : dump + 12) = w3;
+        clx_wait_lds();                          // the tile has been read: the DMA may overwrite it
+        dma(i + DEPTH);
+    };
+    for (uint32_t i = 0; i < nblk; i += 2u) { turn(xa, xb, i); turn(xb, xa, i + 1u); }     // (a turn past the last block stores to the dump area)
+    clx_wait_vmcnt<0>();
+}
+
+template <int OMAX, int DEPTH>
+__device__ __forceinline__ void clx_predict_single_mode(int4 (*ring)[4][64], int32_t* __restrict__ out, const K2Slot& S, int32_t* __restrict__ dump,
+                                                        uint32_t nblk, int lane) {
+    K2Finisher F; F.init(S, lane);
+    const int mode = F.mode();
+    if (mode == 0)      clx_predict_single<OMAX, 0, DEPTH>(ring, out, S, F, dump, nblk, lane);
+    else if (mode == 1) clx_predict_single<OMAX, 1, DEPTH>(ring, out, S, F, dump, nblk, lane);
+    else                clx_predict_single<OMAX, 2, DEPTH>(ring, out, S, F, dump, nblk, lane);
+}
+
 // Workgroup = 4 waves = two (predictor, finisher) pairs, 64 rows each.  Four waves so that a workgroup fills the four
 // SIMDs of its CU by construction: with two-wave workgroups, CUs that receive two workgroups sometimes get both
 // predictors on ONE SIMD (measured with tools/timeline.py: 245 us against 170 us for an undisturbed pair, and the
@@ -941,6 +1009,62 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
         else                  clx_predict_unaligned<32>(S, dump, nmax, lane);
     }
     CLX_TL_END(1, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
+// K2, throughput build (see clx_predict_single): one wave per 64 rows, picked by the host for large batches.
+// Two kernels: groups whose highest predictor order is <= 12, and the rest.  The 32-tap predictor needs ~190 VGPRs; in a
+// kernel of its own it does not halve the occupancy of the common case.
+template <bool HI>
+__device__ __forceinline__ void clx_predict_1w_groups(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    constexpr int DEPTH = 3;
+    __shared__ int4 ring[DEPTH][4][64];           // 12 KiB
+    const int lane = (int)threadIdx.x;
+    const uint32_t group = blockIdx.x;
+    const uint32_t slot = group * 64u + (uint32_t)lane;
+    K2Slot S;
+    S.d = &sfd[slot < n_slots ? slot : 0];
+    S.n = 0; S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0;
+    uint64_t base = 0;
+    if (slot < n_slots) {
+        S.n = S.d->n; S.order = S.d->order; S.shift = S.d->shift; S.wasted = S.d->wasted; S.decor = S.d->decor; base = S.d->out_base;
+        S.lim_log2 = S.d->lim_log2;
+    }
+    if (S.n == 0u) { S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0; base = 0; }
+    S.row = out + base;
+    const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.n, 0xB1, 0xF, 0xF, false);
+    const uint32_t pd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.decor, 0xB1, 0xF, 0xF, false);
+    S.pair_ok = (S.decor != CLX_CH_INDEPENDENT) && pn == S.n && pd == S.decor && S.n != 0u;
+    uint32_t nmax = S.n, omax = S.order;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
+        uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
+    }
+    int32_t* const dump = dump_all + (size_t)(group * 64u + (uint32_t)lane) * CLX_BLK;
+    const bool work = (S.order != 0u) || (S.wasted != 0u) || S.pair_ok;
+    if (nmax == 0u || !__any(work)) return;
+    if ((omax > 12u) != HI) return;                // the other kernel's group
+    const bool al = (S.n == 0u) || ((((uintptr_t)S.row) & 15u) == 0u && (S.n & 3u) == 0u);
+    if (__all(al)) {
+        const uint32_t nblk = (nmax + CLX_BLK - 1u) / CLX_BLK;
+        if (HI)               clx_predict_single_mode<32, DEPTH>(ring, out, S, dump, nblk, lane);
+        else if (omax <= 4u)  clx_predict_single_mode<4, DEPTH>(ring, out, S, dump, nblk, lane);
+        else if (omax <= 8u)  clx_predict_single_mode<8, DEPTH>(ring, out, S, dump, nblk, lane);
+        else                  clx_predict_single_mode<12, DEPTH>(ring, out, S, dump, nblk, lane);
+    } else {
+        if (HI)               clx_predict_unaligned<32>(S, dump, nmax, lane);
+        else if (omax <= 4u)  clx_predict_unaligned<4>(S, dump, nmax, lane);
+        else if (omax <= 8u)  clx_predict_unaligned<8>(S, dump, nmax, lane);
+        else                  clx_predict_unaligned<12>(S, dump, nmax, lane);
+    }
+}
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_predict_1w(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    clx_predict_1w_groups<false>(out, sfd, n_slots, dump_all);
+}
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_predict_1w_hi(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    clx_predict_1w_groups<true>(out, sfd, n_slots, dump_all);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -32,7 +32,12 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
     if (sfd_out) memcpy(sfd_out, sfd.data(), n_slots * sizeof(clx_sf_desc));
     if (flags & 0x100u) return CLX_OK;     // stop after K1 (residual inspection)
     std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
-    SIM_LAUNCH(clx_k_predict, (n_slots + 127) / 128, 256, out, sfd.data(), (uint32_t)n_slots, dump.data());
+    // both builds of K2 are exercised: the two-wave one for even slot counts, the one-wave one for odd ones
+    if (n_slots & 1) {
+        SIM_LAUNCH(clx_k_predict_1w, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data());
+        SIM_LAUNCH(clx_k_predict_1w_hi, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data());
+    }
+    else SIM_LAUNCH(clx_k_predict, (n_slots + 127) / 128, 256, out, sfd.data(), (uint32_t)n_slots, dump.data());
     if (flags & CLX_VERIFY_CRC16)
         SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
     return CLX_OK;
