@@ -339,7 +339,7 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     // frames).  Measured on MI355X: 20k subframes 0.53 ms (waves) vs 1.29 ms (lanes);
     // 64k subframes 1.55 (waves, est.) vs 1.32 ms; 80k subframes 1.90 vs 1.55 ms; 128k subframes 2.84 vs 1.82 ms.
     b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 50000);
-    if (!b->lanes) {
+    {   // where stores that fall outside a row go (K2 and D2 keep their store instructions unconditional)
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
     }
@@ -407,9 +407,16 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
                                b->d_sf_start, b->d_errkey);
         }
         if (!mark("clx_k_lanes")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                           (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits);
+        // D2 (two waves per 64 subframes) unless CLX_LANES_FUSED=1 asks for the fused single-wave kernel (A/B runs)
+        static const bool fused = [] { const char* e = std::getenv("CLX_LANES_FUSED"); return e && e[0] == '1'; }();
+        if (fused)
+            hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits);
+        else
+            hipLaunchKernelGGL(clx_k_lanes2, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_arena, alloc_len,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits, b->d_dump);
         if (!mark("clx_k_finalize")) return CLX_API_ERROR;
         hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
                            (const uint32_t*)b->d_errkey, (const uint64_t*)b->d_endbits, (uint32_t)b->n, b->d_results);

@@ -864,6 +864,330 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 }
 
 // ------------------------------------------------------------------------------------------------
+// D2 (uses K2Predictor / K2Finisher / K2Mover of clx_kernels.hip, which every translation unit includes first):
+// the same work split over two waves per 64 subframes, as K2 is: a lone wave issues one
+// instruction every ~6 ticks and a lane-serial kernel lasts exactly as long as one wave's instruction stream, so the
+// stream is cut in two.
+//   wave R  (Rice):       header, warm-up, LPC parameters, Rice / Rice2 decode -> the raw value x of every sample
+//                         (residual, warm-up / verbatim sample, or the constant), 16 samples of each row per turn, into
+//                         an LDS tile; the predictor's parameters into an LDS descriptor as soon as they are parsed
+//   wave PF (predictor +  x from the tile -> recurrence (K2Predictor) -> wasted shift + decorrelation (K2Finisher) ->
+//            finisher):   tile -> HBM in the 64 B x 16 rows store shape (K2Mover)
+// One workgroup barrier per turn; PF works on tile T while R fills tile T+1 (two tiles per pair).  Workgroup = 4 waves
+// = two (R, PF) pairs, so that a CU's four SIMDs are filled by construction.
+// ------------------------------------------------------------------------------------------------
+struct Lanes2Lds {
+    uint32_t ring[64][CLX_ROW];      // R's bitstream ring
+    int4 tile[2][4][64];             // x / y tiles, layout as in K2 (int4 [row][pos], pos = piece ^ ((row >> 2) & 3))
+    clx_sf_desc desc[64];            // what PF needs to know about each row's predictor (written by R)
+};
+
+// publish the predictor of a row (after the transition) / its shape (at the start)
+__device__ __forceinline__ void clx_l2_publish(clx_sf_desc* d, const LaneState<32>& S, const SfHead& h, uint32_t n, bool with_coefs) {
+    d->n = (uint16_t)n;
+    d->order = (uint8_t)((n != 0u && h.kind >= 2u) ? h.order : 0u);
+    d->wasted = (uint8_t)h.wasted;
+    d->reserved = 0; d->decor = 0; d->out_base = 0;
+    if (!with_coefs) {
+        // until the transition nothing is predicted: no taps, and a range limit that lets warm-up samples through
+        d->shift = 0; d->lim_log2 = 23;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) d->coef[j] = 0;
+    } else {
+        d->shift = (uint8_t)S.shift;
+        d->lim_log2 = (uint8_t)(S.lim < 0 ? 0xffu : (uint32_t)(31 - __clz(S.lim)));
+#pragma unroll
+        for (int j = 0; j < 32; ++j) d->coef[j] = (int16_t)S.c[j];
+    }
+}
+
+// the Rice wave.  Returns through S.r (position, error) like clx_lanes_run.
+__device__ __forceinline__ void clx_rice_wave(LaneState<32>& S, Ring& g, uint32_t* ringrow, int4 (*tile)[4][64], clx_sf_desc* desc, const SfHead h,
+                                              uint32_t bs, uint32_t n, uint32_t nmax, uint32_t omax, int lane) {
+    LaneReader& r = S.r;
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+    bool published = false;
+    uint32_t i0 = (omax + 4u + 15u) & ~15u;              // careful prologue: warm-up samples, the transition, the first residuals
+    if (i0 > nmax) i0 = (nmax + 15u) & ~15u;
+    const uint32_t nturn = (nmax + 15u) >> 4;
+    bool ring_ready = false;
+    for (uint32_t T = 0; T < nturn; ++T) {
+        int4* const out4 = &tile[T & 1u][0][0];
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t t0 = 16u * T + 4u * q;
+            int32_t xs[4] = { 0, 0, 0, 0 };
+            if (t0 < i0) {
+#pragma unroll 1
+                for (uint32_t ii = 0; ii < 4u; ++ii) {
+                    const int32_t x = clx_lcareful_raw<32>(S, h, bs, t0 + ii, n);
+                    xs[0] = ii == 0u ? x : xs[0]; xs[1] = ii == 1u ? x : xs[1]; xs[2] = ii == 2u ? x : xs[2]; xs[3] = ii == 3u ? x : xs[3];
+                    if (S.transitioned && !published) { clx_l2_publish(desc, S, h, n, true); published = true; }
+                }
+            } else {
+                if (!ring_ready) { clx_ring_reset(g, ringrow, r.pos >> 5, r.limit); ring_ready = true; }      // (wave-uniform: t0 is)
+                else if ((t0 & 12u) == 0u) clx_ring_pump(g, ringrow, r.pos, r.limit);
+                const bool live = (n != 0u) && !r.err && t0 < n;
+                bool lean_done = false;
+                // lean block: see clx_lanes_body -- here without the predictor
+                {
+                    const bool rice = S.phase == 1u;
+                    const uint32_t rmask = rice ? 0xffffffffu : 0u;
+                    Win w = clx_win_load64(ringrow, r.pos);
+                    uint32_t p = r.pos, mx = 0;
+                    const uint32_t kk = S.k & 31u;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const uint32_t z = (uint32_t)__clz((int)w.a);
+                        const uint32_t nb = z + S.k1;
+                        const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);
+                        const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+                        xs[ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
+                        const uint32_t nbm = nb & rmask;
+                        mx = nbm > mx ? nbm : mx;
+                        clx_win_skip(w, nb);
+                        p += nbm;
+                    }
+                    const bool lean_ok = !live || ((rice ? (S.transitioned && S.pcnt >= 4u && r.pos <= g.fast_lim && mx <= 32u) : S.phase == 2u)
+                                                   && t0 + 4u <= n);
+                    if (__all(lean_ok)) {
+                        if (live) { r.pos = p; if (rice) S.pcnt -= 4u; }
+                        lean_done = true;
+                    }
+                }
+                if (!lean_done) {
+                    // general block: partition parameters between the codes, verbatim rows; careful steps when anything is unusual
+                    const bool rice_on = live && S.phase == 1u;
+                    const bool verb_on = live && S.phase == 0u;
+                    bool can = true;
+                    if (live) {
+                        can = (t0 + 4u <= n) && S.phase != 3u;
+                        if (S.phase != 2u) can = can && r.pos <= g.fast_lim;
+                        if (S.phase == 1u) can = can && S.transitioned;
+                    }
+                    uint32_t pos2 = r.pos, pcnt2 = S.pcnt, k_2 = S.k, k1_2 = S.k1, parts2 = S.parts_left, next2 = S.next_cnt;
+                    bool ok = can;
+                    const bool any_verb = __any(verb_on);
+                    {
+                        Win w = clx_win_load(ringrow, pos2);
+                        const uint32_t vsh = (32u - h.sf_bps) & 31u;
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            if (__any(rice_on && pcnt2 == 0u)) {
+                                if (rice_on && pcnt2 == 0u) {                    // partition parameter (subframe.rs:314-319 / 362-367)
+                                    const uint32_t pb = S.rice2 ? 5u : 4u;
+                                    k_2 = w.a >> (32u - pb);
+                                    if (k_2 == (S.rice2 ? 31u : 15u) || parts2 == 0u || next2 == 0u) ok = false;
+                                    k1_2 = k_2 + 1u; pos2 += pb; parts2 -= 1u; pcnt2 = next2; next2 = S.per;
+                                    clx_win_skip(w, pb);
+                                }
+                            }
+                            const uint32_t z = (uint32_t)__clz((int)w.a);
+                            uint32_t nb = z + k1_2;
+                            if (rice_on && nb > 32u) ok = false;
+                            const uint32_t u = (z << (k_2 & 31u)) | clx_bfe(w.a, 32u - nb, k_2);
+                            int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+                            if (any_verb) {
+                                if (verb_on) { x = (int32_t)w.a >> vsh; nb = h.sf_bps; }
+                            }
+                            if (!rice_on && !verb_on) { x = S.cval; nb = 32u; }
+                            clx_win_skip(w, nb);
+                            if (rice_on || verb_on) pos2 += nb;
+                            pcnt2 -= 1u;
+                            xs[ii] = x;
+                        }
+                    }
+                    if (__all(ok)) {
+                        if (live) { r.pos = pos2; S.pcnt = pcnt2; S.k = k_2; S.k1 = k1_2; S.parts_left = parts2; S.next_cnt = next2; }
+                    } else {
+#pragma unroll 1
+                        for (uint32_t ii = 0; ii < 4u; ++ii) {
+                            const int32_t x = clx_lcareful_raw<32>(S, h, bs, t0 + ii, n);
+                            xs[0] = ii == 0u ? x : xs[0]; xs[1] = ii == 1u ? x : xs[1]; xs[2] = ii == 2u ? x : xs[2]; xs[3] = ii == 3u ? x : xs[3];
+                            if (S.transitioned && !published) { clx_l2_publish(desc, S, h, n, true); published = true; }
+                        }
+                    }
+                }
+            }
+            out4[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(xs[0], xs[1], xs[2], xs[3]);
+        }
+        clx_wg_barrier();
+    }
+    // a subframe whose warm-up fills the whole block switches after its last sample; trailing parameters of empty
+    // partitions are part of the stream (they move the next subframe / the CRC)
+    if (n != 0u && !r.err && S.trans_at != 0xffffffffu && S.trans_at == n && !S.transitioned) clx_ltransition<32>(S, h, bs);
+    if (n != 0u && !r.err && S.transitioned) {
+        while (!r.err && S.parts_left != 0u) { (void)clx_lread_rice_param(r, S.rice2); S.parts_left -= 1u; }
+    }
+}
+
+// the predictor + finisher wave
+template <int OMAX, int MODE, bool ALIGNED>
+__device__ __forceinline__ void clx_pf_wave(int4 (*tile)[4][64], int32_t* __restrict__ out, const K2Slot& S, const K2Finisher& F,
+                                            int32_t* __restrict__ dump, uint32_t nturn, int lane) {
+    K2Predictor<OMAX> P; P.init(S);
+    K2Mover M; M.init(out, S, lane);
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+    for (uint32_t T = 0; T < nturn; ++T) {
+        clx_wg_barrier();                                  // tile T is complete (and so is the descriptor of every row that needs it by now)
+        if (T <= 2u) {                                     // coefficients arrive with the transition, at sample `order` <= 32
+            const clx_sf_desc* d = S.d;
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) P.c[j] = (P.n != 0u && (uint32_t)j < P.order) ? (int32_t)d->coef[j] : 0;
+            P.shift = d->shift;
+            const uint32_t ll = d->lim_log2;
+            P.lim = (ll <= 23u) ? (int32_t)(1u << ll) : -1;
+            bool in = P.lim >= 0;                          // the 24-bit evaluation needs every tap's history inside the proven range
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) in = in && P.hist[j] < P.lim && P.hist[j] >= -P.lim;
+            P.h_ok = in || P.trivial;
+        }
+        int4* const t4 = &tile[T & 1u][0][0];
+        int32_t x[CLX_BLK], y[CLX_BLK];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const int4 v = t4[(uint32_t)lane * 4u + (q ^ sw)];
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+        P.block(x, y, T * CLX_BLK, K2NoHook());
+        F.template block<MODE>(y, K2NoHook());
+        if (ALIGNED) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) t4[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+            clx_wave_sync();
+            const uint32_t t = T * CLX_BLK + 4u * M.pc;
+            const int4 w0 = t4[lane], w1 = t4[64 + lane], w2 = t4[128 + lane], w3 = t4[192 + lane];
+            *reinterpret_cast<int4*>(t < M.rn[0] ? const_cast<int32_t*>(M.rp[0]) + t : dump + 0) = w0;
+            *reinterpret_cast<int4*>(t < M.rn[1] ? const_cast<int32_t*>(M.rp[1]) + t : dump + 4) = w1;
+            *reinterpret_cast<int4*>(t < M.rn[2] ? const_cast<int32_t*>(M.rp[2]) + t : dump + 8) = w2;
+            *reinterpret_cast<int4*>(t < M.rn[3] ? const_cast<int32_t*>(M.rp[3]) + t : dump + 12) = w3;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)CLX_BLK; ++i) if (T * CLX_BLK + i < S.n) S.row[T * CLX_BLK + i] = y[i];
+        }
+    }
+}
+
+template <int OMAX, bool ALIGNED>
+__device__ __forceinline__ void clx_pf_wave_mode(int4 (*tile)[4][64], int32_t* __restrict__ out, const K2Slot& S, int32_t* __restrict__ dump,
+                                                 uint32_t nturn, int lane) {
+    K2Finisher F; F.init(S, lane);
+    const int mode = F.mode();
+    if (mode == 0)      clx_pf_wave<OMAX, 0, ALIGNED>(tile, out, S, F, dump, nturn, lane);
+    else if (mode == 1) clx_pf_wave<OMAX, 1, ALIGNED>(tile, out, S, F, dump, nturn, lane);
+    else                clx_pf_wave<OMAX, 2, ALIGNED>(tile, out, S, F, dump, nturn, lane);
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_lanes2(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
+                  const clx_dev_frame* __restrict__ frames,
+                  const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+                  const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
+                  uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all) {
+    __shared__ Lanes2Lds L2[2];
+    const int lane = (int)threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t pair = wave & 1u;
+    const bool is_pf = wave >= 2u;                 // wave-uniform
+    Lanes2Lds& L = L2[pair];
+    const uint32_t group = blockIdx.x * 2u + pair;
+    const uint32_t slot = group * 64u + (uint32_t)lane;
+    uint32_t f = 0xffffffffu;
+    if (slot < n_slots) f = slot_frame[slot];
+    clx_dev_frame fr;
+    fr.byte_off = 0; fr.out_off = 0; fr.limit_bits = 0; fr.first_slot = 0; fr.header_bytes = 0; fr.block_size = 0;
+    fr.n_channels = 0; fr.channel_assignment = 0; fr.bps = 1; fr.flags = 0;
+    if (f != 0xffffffffu) fr = frames[f];
+    const uint32_t ch = (f != 0xffffffffu) ? slot - fr.first_slot : 0u;
+    // both waves of a pair see the same 64 slots: nmax (the number of turns) is the same in both.  A row that turns out
+    // to be unreadable (the scan failed on an earlier channel) still takes part with garbage -- its frame is reported failed.
+    uint32_t nmax = (f != 0xffffffffu) ? fr.block_size : 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { const uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax; }
+    if (nmax == 0u) return;
+    const uint32_t nturn = (nmax + 15u) >> 4;
+
+    if (!is_pf) {
+        uint32_t bs = fr.block_size;
+        LaneReader r;
+        r.arena = arena;
+        r.origin = (uint32_t)(fr.byte_off & ~15ull);
+        const uint32_t o = 8u * (uint32_t)(fr.byte_off & 15ull);
+        r.limit = o + fr.limit_bits;
+        r.pos = o + 8u * (uint32_t)fr.header_bytes;
+        r.err = 0u;
+        bool active = (f != 0xffffffffu);
+        if (active && ch != 0u) {
+            const uint32_t sp = sf_start[slot];
+            if (sp == 0xffffffffu) active = false;           // an earlier channel failed (the scan reported it)
+            else r.pos = sp;
+        }
+        if (active && r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        if (!active) { bs = 0; r.err = 1u; }                 // idle lane: produces nothing, reports nothing
+        Ring g;
+        g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
+        g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
+        g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0;
+        SfHead h = { 1u, 0u, 0u, 1u };
+        if (active && !r.err) h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
+        uint32_t omax = (active && !r.err && h.kind >= 2u) ? h.order : 0u;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { const uint32_t b = __shfl_xor(omax, s, 64); omax = b > omax ? b : omax; }
+        LaneState<32> S;
+        S.r = r;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { S.c[j] = 0; S.hist[j] = 0; }
+        const uint32_t n = r.err ? 0u : bs;              // a lane that failed in its header produces nothing
+        S.phase = 3u; S.cval = 0; S.trans_at = 0xffffffffu; S.transitioned = false;
+        S.order = 0; S.shift = 0; S.lim = 0x7fffffff;
+        S.k = 0; S.k1 = 1; S.pcnt = 0; S.next_cnt = 0; S.per = 0; S.parts_left = 0; S.rice2 = 0;
+        if (n) {
+            if (h.kind == 0u) { S.cval = clx_lread_signed(S.r, h.sf_bps); S.phase = 2u; }              // decode_constant (subframe.rs:382-394)
+            else if (h.kind == 1u) S.phase = 0u;
+            else {
+                if (bs < h.order) S.r.err = CLX_LERR(CLX_FORMAT_ERROR, h.kind == 2u ? CLX_MSG_FIXED_ORDER_GT_BLOCK : CLX_MSG_LPC_ORDER_GT_BLOCK);
+                else { S.phase = 0u; S.trans_at = h.order; }
+            }
+        }
+        clx_l2_publish(&L.desc[lane], S, h, S.r.err ? 0u : n, false);
+        clx_wg_barrier();                                    // PF may read the rows' shapes
+        clx_rice_wave(S, g, L.ring[lane], L.tile, &L.desc[lane], h, bs, S.r.err ? 0u : n, nmax, omax, lane);
+        if (active) {
+            if (S.r.err) clx_report_error(errkey, f, ch, S.r.err);
+            else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(S.r.pos - o);
+        }
+    } else {
+        clx_wg_barrier();                                    // the rows' shapes are in L.desc
+        K2Slot S;
+        S.d = &L.desc[lane];
+        const bool valid = f != 0xffffffffu;
+        S.n = valid ? fr.block_size : 0u;
+        S.order = valid ? S.d->order : 0u; S.shift = 0; S.wasted = valid ? S.d->wasted : 0u;
+        S.decor = valid ? fr.channel_assignment : 0u; S.lim_log2 = 0;
+        S.row = out + (valid ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
+        if (S.n == 0u) { S.order = 0; S.wasted = 0; S.decor = 0; }
+        const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.n, 0xB1, 0xF, 0xF, false);
+        const uint32_t pd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.decor, 0xB1, 0xF, 0xF, false);
+        S.pair_ok = (S.decor != CLX_CH_INDEPENDENT) && pn == S.n && pd == S.decor && S.n != 0u;
+        uint32_t omax = S.order;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { const uint32_t b = __shfl_xor(omax, s, 64); omax = b > omax ? b : omax; }
+        int32_t* const dump = dump_all + (size_t)(group * 64u + (uint32_t)lane) * CLX_BLK;
+        const bool al = (S.n == 0u) || ((((uintptr_t)S.row) & 15u) == 0u && (S.n & 3u) == 0u);
+        if (__all(al)) {
+            if (omax <= 4u)       clx_pf_wave_mode<4, true>(L.tile, out, S, dump, nturn, lane);
+            else if (omax <= 8u)  clx_pf_wave_mode<8, true>(L.tile, out, S, dump, nturn, lane);
+            else if (omax <= 12u) clx_pf_wave_mode<12, true>(L.tile, out, S, dump, nturn, lane);
+            else                  clx_pf_wave_mode<32, true>(L.tile, out, S, dump, nturn, lane);
+        } else {
+            if (omax <= 4u)       clx_pf_wave_mode<4, false>(L.tile, out, S, dump, nturn, lane);
+            else if (omax <= 8u)  clx_pf_wave_mode<8, false>(L.tile, out, S, dump, nturn, lane);
+            else if (omax <= 12u) clx_pf_wave_mode<12, false>(L.tile, out, S, dump, nturn, lane);
+            else                  clx_pf_wave_mode<32, false>(L.tile, out, S, dump, nturn, lane);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // F: error keys -> clx_frame_result
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(256)
