@@ -173,6 +173,7 @@ struct Ring {
     uint32_t npend;           // granules requested at the last pump (0..2), stored in pend0 / pend1
     uint4 pend0, pend1;
     uint32_t fast_lim;        // a fast block may start at any bit position <= fast_lim (ring coverage and EOF margin)
+    uint32_t fast_lim16;      // the same for sixteen codes read through four register windows (D2's turn)
 };
 
 __device__ __forceinline__ uint4 clx_ring_fetch(const Ring& g, uint32_t dw) {
@@ -192,6 +193,10 @@ __device__ __forceinline__ void clx_ring_set_lim(Ring& g, uint32_t limit) {
     const uint32_t by_ring = g.fill >= 8u ? 32u * (g.fill - 8u) : 0u;
     const uint32_t by_eof = limit >= 160u ? limit - 160u : 0u;
     g.fast_lim = by_ring < by_eof ? by_ring : by_eof;
+    // 16 codes <= 512 bits; the last window load reaches 96 + 192 bits past the start of the fourth block
+    const uint32_t by_ring16 = g.fill >= 24u ? 32u * (g.fill - 24u) : 0u;
+    const uint32_t by_eof16 = limit >= 544u ? limit - 544u : 0u;
+    g.fast_lim16 = by_ring16 < by_eof16 ? by_ring16 : by_eof16;
 }
 // synchronous (re)fill starting at the granule that holds dword `dw` (start of a subframe, or after a jump)
 __device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t dw, uint32_t limit) {
@@ -286,7 +291,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     Ring g;
     g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
     g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0;
+    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0; g.fast_lim16 = 0;
     const uint32_t bs = fr.block_size;
     uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
     uint32_t nch_max = nch;
@@ -829,7 +834,7 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     Ring g;
     g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
     g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0;
+    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0; g.fast_lim16 = 0;
 
     SfHead h = { 1u, 0u, 0u, 1u };
     if (active && !r.err) h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
@@ -913,6 +918,44 @@ __device__ __forceinline__ void clx_rice_wave(LaneState<32>& S, Ring& g, uint32_
     bool ring_ready = false;
     for (uint32_t T = 0; T < nturn; ++T) {
         int4* const out4 = &tile[T & 1u][0][0];
+        // ---- lean turn: sixteen codes of one partition in every live lane (or sixteen repeats of a constant), four register
+        //      windows, ONE vote.  Anything else -- a partition edge, verbatim rows, a long code, the ring running low, the
+        //      prologue -- takes the turn through the four blocks below.
+        if (ring_ready) {
+            const uint32_t tb = 16u * T;
+            clx_ring_pump(g, ringrow, r.pos, r.limit);
+            const bool live = (n != 0u) && !r.err && tb < n;
+            const bool rice = S.phase == 1u;
+            const uint32_t rmask = rice ? 0xffffffffu : 0u;
+            const uint32_t kk = S.k & 31u;
+            uint32_t p = r.pos, mx = 0;
+            int32_t X[16];
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                Win w = clx_win_load64(ringrow, p);
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const uint32_t z = (uint32_t)__clz((int)w.a);
+                    const uint32_t nb = z + S.k1;
+                    const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);    // (q << k) | r, subframe.rs:337-341
+                    const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);      // rice_to_signed (subframe.rs:157-170)
+                    X[4 * b4 + ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
+                    const uint32_t nbm = nb & rmask;
+                    mx = nbm > mx ? nbm : mx;
+                    clx_win_skip(w, nb);
+                    p += nbm;
+                }
+            }
+            const bool ok16 = !live || ((rice ? (S.transitioned && S.pcnt >= 16u && r.pos <= g.fast_lim16 && mx <= 32u) : S.phase == 2u)
+                                        && tb + 16u <= n);
+            if (__all(ok16)) {
+                if (live) { r.pos = p; if (rice) S.pcnt -= 16u; }
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) out4[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
+                clx_wg_barrier();
+                continue;
+            }
+        }
         for (uint32_t q = 0; q < 4u; ++q) {
             const uint32_t t0 = 16u * T + 4u * q;
             int32_t xs[4] = { 0, 0, 0, 0 };
@@ -925,7 +968,7 @@ __device__ __forceinline__ void clx_rice_wave(LaneState<32>& S, Ring& g, uint32_
                 }
             } else {
                 if (!ring_ready) { clx_ring_reset(g, ringrow, r.pos >> 5, r.limit); ring_ready = true; }      // (wave-uniform: t0 is)
-                else if ((t0 & 12u) == 0u) clx_ring_pump(g, ringrow, r.pos, r.limit);
+                // (a turn that started with the ring in place was pumped by the lean attempt above)
                 const bool live = (n != 0u) && !r.err && t0 < n;
                 bool lean_done = false;
                 // lean block: see clx_lanes_body -- here without the predictor
@@ -1126,7 +1169,7 @@ void clx_k_lanes2(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         Ring g;
         g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
         g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-        g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0;
+        g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0; g.fast_lim16 = 0;
         SfHead h = { 1u, 0u, 0u, 1u };
         if (active && !r.err) h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
         uint32_t omax = (active && !r.err && h.kind >= 2u) ? h.order : 0u;
