@@ -334,11 +334,11 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     }
     for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
     // path: explicit flag, else by batch shape -- the lane-serial kernels need many independent subframes to fill
-    // the machine (their duration is one lane's serial chain: ~1.3 ms for 4096-sample subframes however few there
+    // the machine (their duration is one lane's serial chain: ~1.1 ms for 4096-sample subframes however few there
     // are, until every SIMD has a wave), the wave-per-frame kernels scale with the batch (0.53 ms per 10k stereo
     // frames).  Measured on MI355X: 32k subframes 0.74 ms (waves) vs 0.81 ms (lanes);
-    // 48k subframes 1.12 vs 1.28 ms; 56k 1.30 vs 1.29 ms; 80k 1.77 vs 1.55 ms; 128k 2.73 vs 1.82 ms.
-    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 55000);
+    // 48k subframes 1.17 vs 1.06 ms; 64k 1.5 (est.) vs 1.12 ms; 128k 2.73 vs 1.63 ms; 200k 2.62 ms (lanes).
+    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 48000);
     {   // where stores that fall outside a row go (K2 and D2 keep their store instructions unconditional)
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
@@ -410,11 +410,16 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         // the two-wave (latency) build while its workgroups get a CU each (0.50 ms against 1.00 ms at 20k subframes), the fused
         // single-wave (throughput) build beyond (1.28 against 1.34 ms at 48k subframes); CLX_LANES_BUILD=fused|split forces one
         static const int forced = [] { const char* e = std::getenv("CLX_LANES_BUILD"); return !e ? 0 : e[0] == 'f' ? 1 : e[0] == 's' ? 2 : 0; }();
-        const bool split = forced == 2 || (forced == 0 && b->n_slots <= 32768);
-        if (!split)
+        const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false
+                         : forced == 2 || (forced == 0 && b->n_slots <= 32768);
+        if (!split) {
             hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
                                (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits);
+                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits, b->d_dump);
+            hipLaunchKernelGGL(clx_k_lanes_hi, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits, b->d_dump);
+        }
         else
             hipLaunchKernelGGL(clx_k_lanes2, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_arena, alloc_len,
                                (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,

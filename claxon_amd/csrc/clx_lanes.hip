@@ -560,7 +560,7 @@ __device__ __forceinline__ int32_t clx_lfinish(int32_t s, const Finish& F) {
 template <int OMAX>
 __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint32_t* ringrow, int4* stage, const SfHead h, uint32_t bs, uint32_t n,
                                                uint32_t decor, bool pair_ok, int32_t* __restrict__ row, bool row_aligned,
-                                               uint32_t nmax, uint32_t omax, int lane) {
+                                               uint32_t nmax, uint32_t omax, int lane, int32_t* __restrict__ out, int32_t* __restrict__ dump) {
     LaneReader& r = S.r;
     const Finish F = clx_lfinish_setup(n, h.wasted, decor, pair_ok, lane);
 
@@ -583,9 +583,82 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     if (i0 < nmax) clx_ring_reset(g, ringrow, r.pos >> 5, r.limit);
     bool wide = false;                                   // sticky: i64 accumulate from now on (made wave-uniform where it is used)
     bool no_lean = false;                                // wave-uniform, sticky: the lean block cannot succeed any more
+    // rows that allow 16-byte accesses leave through the 64 B x 16 rows store shape (see K2 in clx_kernels.hip), a whole
+    // turn of 16 samples at a time
+    const bool al16 = __all(n == 0u || (row_aligned && (n & 3u) == 0u));
+    K2Slot ms; ms.d = nullptr; ms.row = row; ms.n = n; ms.order = 0; ms.shift = 0; ms.wasted = 0; ms.decor = 0; ms.lim_log2 = 0; ms.pair_ok = false;
+    K2Mover M; M.init(out, ms, lane);
+    int4* const tile = stage - 4 * lane;                 // the wave's 64 x 4 staging slots seen as one tile
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
     for (uint32_t t0 = i0; t0 < nmax; t0 += 4u) {
         if ((t0 & 12u) == 0u && t0 != i0) clx_ring_pump(g, ringrow, r.pos, r.limit);
         const bool live = (n != 0u) && !r.err && t0 < n;
+        // ---- lean turn: sixteen samples at once when every live lane is in the middle of a Rice partition (or repeats a
+        //      constant), nothing is near an edge and the 24-bit predictor holds: four register windows, ONE vote.
+        if ((t0 & 12u) == 0u && !no_lean && al16) {
+            const bool rice = S.phase == 1u;
+            const uint32_t rmask = rice ? 0xffffffffu : 0u;                    // constant lanes consume no bits
+            const uint32_t kk = S.k & 31u;
+            uint32_t p = r.pos, mx = 0;
+            int32_t Y[16];
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                Win w = clx_win_load64(ringrow, p);
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const uint32_t z = (uint32_t)__clz((int)w.a);
+                    const uint32_t nb = z + S.k1;
+                    const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);    // (q << k) | r, subframe.rs:337-341
+                    const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);      // rice_to_signed (subframe.rs:157-170)
+                    Y[4 * b4 + ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
+                    const uint32_t nbm = nb & rmask;
+                    mx = nbm > mx ? nbm : mx;
+                    clx_win_skip(w, nb);
+                    p += nbm;
+                }
+            }
+            int32_t hh[OMAX];
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) hh[j] = S.hist[j];
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) {
+                const int32_t pred = clx_lpredict<OMAX, false>(S.c, hh, S.shift);      // taps beyond the order are zero
+                const int32_t sm = (int32_t)((uint32_t)Y[ii] + (uint32_t)pred);
+#pragma unroll
+                for (int j = OMAX - 1; j > 0; --j) hh[j] = hh[j - 1];
+                hh[0] = sm;
+                Y[ii] = sm;
+            }
+            int32_t hi = Y[0], lo = Y[0];
+#pragma unroll
+            for (int ii = 1; ii + 1 < 16; ii += 2) { hi = clx_max3(hi, Y[ii], Y[ii + 1]); lo = clx_min3(lo, Y[ii], Y[ii + 1]); }
+            hi = Y[15] > hi ? Y[15] : hi; lo = Y[15] < lo ? Y[15] : lo;
+            const bool in_range = S.order == 0u || (hi < S.lim && lo >= -S.lim);
+            const bool ok16 = !live || ((rice ? (S.transitioned && S.pcnt >= 16u && r.pos <= g.fast_lim16 && mx <= 32u) : S.phase == 2u)
+                                        && t0 + 16u <= n && S.lim >= 0 && in_range);
+            if (__all(ok16)) {
+                if (live) {
+                    r.pos = p;
+                    if (rice) S.pcnt -= 16u;
+#pragma unroll
+                    for (int j = 0; j < OMAX; ++j) S.hist[j] = hh[j];
+                }
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) Y[ii] = clx_lfinish(Y[ii], F);
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) tile[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(Y[4 * q], Y[4 * q + 1], Y[4 * q + 2], Y[4 * q + 3]);
+                clx_wave_sync();
+                const uint32_t t = t0 + 4u * M.pc;
+                const int4 w0 = tile[lane], w1 = tile[64 + lane], w2 = tile[128 + lane], w3 = tile[192 + lane];
+                *reinterpret_cast<int4*>(t < M.rn[0] ? const_cast<int32_t*>(M.rp[0]) + t : dump + 0) = w0;
+                *reinterpret_cast<int4*>(t < M.rn[1] ? const_cast<int32_t*>(M.rp[1]) + t : dump + 4) = w1;
+                *reinterpret_cast<int4*>(t < M.rn[2] ? const_cast<int32_t*>(M.rp[2]) + t : dump + 8) = w2;
+                *reinterpret_cast<int4*>(t < M.rn[3] ? const_cast<int32_t*>(M.rp[3]) + t : dump + 12) = w3;
+                clx_wave_sync();
+                t0 += 12u;                                   // the whole turn is done
+                continue;
+            } else if (__any(live && S.lim < 0 && S.order != 0u)) no_lean = true;   // a lane needs the i64 predictor from now on
+        }
         int32_t y[4];
         bool lean_done = false;
         // ---- lean block: every live lane is in the middle of a Rice partition (or repeats a constant), nothing is near an
@@ -775,7 +848,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
 template <int OMAX>
 __device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* ringrow, int4* stage, const SfHead h, uint32_t bs, uint32_t decor, bool pair_ok,
                                               int32_t* __restrict__ row, bool row_aligned, uint32_t nmax, uint32_t omax, int lane,
-                                              uint32_t* end_pos, uint32_t* err_out) {
+                                              uint32_t* end_pos, uint32_t* err_out, int32_t* __restrict__ out, int32_t* __restrict__ dump) {
     LaneState<OMAX> S;
     S.r = r;
 #pragma unroll
@@ -792,17 +865,20 @@ __device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* r
             else { S.phase = 0u; S.trans_at = h.order; }
         }
     }
-    clx_lanes_body<OMAX>(S, g, ringrow, stage, h, bs, n, decor, pair_ok, row, row_aligned, nmax, omax, lane);
+    clx_lanes_body<OMAX>(S, g, ringrow, stage, h, bs, n, decor, pair_ok, row, row_aligned, nmax, omax, lane, out, dump);
     *end_pos = S.r.pos;
     *err_out = S.r.err;
 }
 
-extern "C" __global__ __launch_bounds__(64)
-void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
+// Two kernels: waves whose highest predictor order is <= 12, and the rest (the 32-tap predictor state would otherwise
+// cost every wave its occupancy: 256 VGPRs = one wave per SIMD).  Both are launched over all slots; a wave leaves at once
+// when its subframes belong to the other kernel.
+template <bool HI>
+__device__ __forceinline__ void clx_lanes_fused(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                  const clx_dev_frame* __restrict__ frames,
                  const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
                  const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits) {
+                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all) {
     __shared__ LanesLds L;
     CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
@@ -855,17 +931,31 @@ void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     int32_t* const row = out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
     const bool row_aligned = (((uintptr_t)row) & 15u) == 0u;
     uint32_t end_pos = r.pos, err = r.err;
+    int32_t* const dump = dump_all + (size_t)slot * 16u;                   // 64 bytes per lane for stores that fall outside a row
+    if ((omax > 12u) != HI) return;                          // the other kernel's wave (it reports this wave's lanes)
     if (nmax != 0u) {
-        if (omax <= 4u)       clx_lanes_run<4>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
-        else if (omax <= 8u)  clx_lanes_run<8>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
-        else if (omax <= 12u) clx_lanes_run<12>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
-        else                  clx_lanes_run<32>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err);
+        if (HI)               clx_lanes_run<32>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err, out, dump);
+        else if (omax <= 4u)  clx_lanes_run<4>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err, out, dump);
+        else if (omax <= 8u)  clx_lanes_run<8>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err, out, dump);
+        else                  clx_lanes_run<12>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err, out, dump);
     }
     if (active) {
         if (err) clx_report_error(errkey, f, ch, err);
         else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(end_pos - o);
     }
     CLX_TL_END(3, blockIdx.x);
+}
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
+                 const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
+                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all) {
+    clx_lanes_fused<false>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all);
+}
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_lanes_hi(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
+                    const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
+                    uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all) {
+    clx_lanes_fused<true>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -185,7 +185,11 @@ enum {
      *        needs arena_len < 4 GiB). */
     CLX_PATH_WAVES      = 1u << 3,
     CLX_PATH_LANES      = 1u << 4,
-    CLX_PCM_ON_DEVICE   = 1u << 5    /* clx_interleave: `pcm` is a device pointer (else host; copied D2H) */
+    CLX_PCM_ON_DEVICE   = 1u << 5,   /* clx_interleave: `pcm` is a device pointer (else host; copied D2H) */
+    /* Build of the lane path's decode kernel (with CLX_PATH_LANES; default: by batch size): the fused one-wave
+     * kernel (throughput), or the two-wave split kernel (latency). */
+    CLX_LANES_FUSED     = 1u << 6,
+    CLX_LANES_SPLIT     = 1u << 7
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32

@@ -15,7 +15,7 @@ def ctx():
     return cx.Context(0, wait_s=120)
 
 
-@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES], ids=["waves", "lanes"])
+@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED], ids=["waves", "lanes", "lanes-fused"])
 def gpu(ctx, request):
     """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip)."""
     return GpuBackend(ctx, request.param)

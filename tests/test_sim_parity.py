@@ -13,7 +13,7 @@ from parity_util import SimBackend
 import claxon_amd as cx
 
 
-@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES], ids=["waves", "lanes"])
+@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED], ids=["waves", "lanes", "lanes-fused"])
 def sim(request):
     """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip)."""
     import simlib

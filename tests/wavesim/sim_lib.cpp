@@ -21,10 +21,13 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         const size_t n_multi = clx_plan_lanes(dev.data(), n, n_slots, slot_frame.data(), multi.data());
         if (n_slots_out) *n_slots_out = n_slots;
         if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, arena, alloc_len + 16, dev.data(), multi.data(), (uint32_t)n_multi, sf_start.data(), errkey.data());
-        // both lane kernels are exercised: the two-wave one for even slot counts, the fused one for odd ones
-        if (n_slots & 1) {
+        // CLX_LANES_FUSED: the fused kernel; otherwise the two-wave one
+        if (flags & CLX_LANES_FUSED) {
+            std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
-                       errkey.data(), endbits.data());
+                       errkey.data(), endbits.data(), dump.data());
+            SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
+                       errkey.data(), endbits.data(), dump.data());
         } else {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
