@@ -112,7 +112,7 @@ def main():
     alg_bytes = w.algorithmic_bytes          # compressed bytes read once + 4 B per decoded sample written once
     peak = 8000.0                            # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = _pmc_traffic(dom_name)
+    traffic = _pmc_traffic(dom_name, args.frames)
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
@@ -193,12 +193,12 @@ def _cpu_baseline(w):
                       (w.n, w.total_samples / 1e6, ncpu)}
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary of this same command, if present."""
+def _pmc_traffic(kernel, frames):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary of this same workload size, if there is one."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(kernel)
+            return json.load(f).get("frames_%d" % frames, {}).get(kernel)
     except Exception:
         return None
 
