@@ -583,6 +583,16 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     if (i0 < nmax) clx_ring_reset(g, ringrow, r.pos >> 5, r.limit);
     bool wide = false;                                   // sticky: i64 accumulate from now on (made wave-uniform where it is used)
     bool no_lean = false;                                // wave-uniform, sticky: the lean block cannot succeed any more
+    // The prologue predicts in i64 and checks nothing: a corrupt stream may have left history values outside the range
+    // in which 24-bit factors are exact.  The blocks below only range-check their OUTPUTS (computed from the history), so
+    // the history they start from has to be vouched for here.
+    {
+        bool hist_in = S.lim >= 0;
+#pragma unroll
+        for (int j = 0; j < OMAX; ++j) hist_in = hist_in && S.hist[j] < S.lim && S.hist[j] >= -S.lim;
+        if (n != 0u && !r.err && S.order != 0u && !hist_in) wide = true;
+        if (__any(wide)) no_lean = true;
+    }
     // rows that allow 16-byte accesses leave through the 64 B x 16 rows store shape (see K2 in clx_kernels.hip), a whole
     // turn of 16 samples at a time
     const bool al16 = __all(n == 0u || (row_aligned && (n & 3u) == 0u));
@@ -807,6 +817,9 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     #pragma unroll
                     for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
                     S.hist[0] = s;
+                    // the careful steps predict in i64 and may leave the proven range: the 24-bit blocks that follow
+                    // range-check only their outputs, so a history value outside the range ends them for good
+                    if (n != 0u && S.order != 0u && !(s < S.lim && s >= -S.lim)) wide = true;
                     ys[ii] = clx_lfinish(s, F);
                 }
                 const int4 yv = stage[(t0 >> 2) & 3u];

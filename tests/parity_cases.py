@@ -146,3 +146,11 @@ def edge_workload():
                     fp.sf[c] = synth.sf(kind, order, int(rng.integers(2, 16)), 0, force_rice2=int(rng.integers(0, 2)))
                 ws.append(synth.encode_frames("e", pcm, channels, bs, bps, [fp]))
     return synth.concat("edges", ws)
+
+
+def check_regressions(oracle, backend):
+    """Frames that once decoded differently from the oracle on some kernel selection (found by tools/stress_gpu.py)."""
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "*.npy")))
+    assert files
+    for p in files:
+        assert_same_as_oracle(oracle, backend, np.load(p), False, os.path.basename(p))

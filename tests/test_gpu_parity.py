@@ -122,3 +122,7 @@ def test_gpu_flac_reader_streams(oracle, gpu):
         err = e
     si2, blocks2, st2, msg2 = oracle.decode_stream(cut)
     assert got == len(blocks2) and err is not None and (err.status, err.msg) == (st2, msg2)
+
+
+def test_gpu_regressions(oracle, gpu):
+    pc.check_regressions(oracle, gpu)

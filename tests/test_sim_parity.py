@@ -97,3 +97,7 @@ def test_sim_collectives_semantics():
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(here, "wavesim", "fake"), "-o", exe,
                                os.path.join(d, "t.cpp")])
         assert subprocess.run([exe]).returncode == 0
+
+
+def test_sim_regressions(oracle, sim):
+    pc.check_regressions(oracle, sim)
