@@ -10,6 +10,11 @@
 #ifndef CLX_DEVICE_H
 #define CLX_DEVICE_H
 
+// tier statistics: compiled in by the wave simulator only (tools/sim_tiers.py), nothing on the device
+#ifndef CLX_STAT
+#define CLX_STAT(i, n) do {} while (0)
+#endif
+
 #include <stdint.h>
 
 struct clx_dev_frame {

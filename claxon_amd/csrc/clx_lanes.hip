@@ -170,10 +170,9 @@ struct Ring {
     const uint32_t* src;      // arena + origin (16-byte aligned)
     uint32_t avail_dw;        // dwords readable from src
     uint32_t fill;            // stream dwords [fill-CLX_RING, fill) are in the ring; multiple of 4
-    uint32_t npend;           // granules requested at the last pump (0..2), stored in pend0 / pend1
-    uint4 pend0, pend1;
+    uint32_t npend;           // granules requested at the last pump (0..3), stored in pend0 / pend1 / pend2
+    uint4 pend0, pend1, pend2;
     uint32_t fast_lim;        // a fast block may start at any bit position <= fast_lim (ring coverage and EOF margin)
-    uint32_t fast_lim16;      // the same for sixteen codes read through four register windows (D2's turn)
 };
 
 __device__ __forceinline__ uint4 clx_ring_fetch(const Ring& g, uint32_t dw) {
@@ -193,10 +192,13 @@ __device__ __forceinline__ void clx_ring_set_lim(Ring& g, uint32_t limit) {
     const uint32_t by_ring = g.fill >= 8u ? 32u * (g.fill - 8u) : 0u;
     const uint32_t by_eof = limit >= 160u ? limit - 160u : 0u;
     g.fast_lim = by_ring < by_eof ? by_ring : by_eof;
-    // 16 codes <= 512 bits; the last window load reaches 96 + 192 bits past the start of the fourth block
-    const uint32_t by_ring16 = g.fill >= 24u ? 32u * (g.fill - 24u) : 0u;
-    const uint32_t by_eof16 = limit >= 544u ? limit - 544u : 0u;
-    g.fast_lim16 = by_ring16 < by_eof16 ? by_ring16 : by_eof16;
+}
+// The lean blocks decode first and ask afterwards: `pw` = where their last register window was loaded, `pend` = where
+// they stopped.  What they decoded is what the stream holds iff that window (6 dwords) was inside the ring's filled part
+// and no code reached past the end of the frame.  (Worst-case margins instead -- 16 codes <= 512 bits -- would demand
+// 24 of the ring's 32 dwords ahead of the position at every turn, which lanes above 8 bits per code cannot keep.)
+__device__ __forceinline__ bool clx_ring_covered(const Ring& g, uint32_t pw, uint32_t pend, uint32_t limit) {
+    return (pw >> 5) + 6u <= g.fill && pend <= limit;
 }
 // synchronous (re)fill starting at the granule that holds dword `dw` (start of a subframe, or after a jump)
 __device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t dw, uint32_t limit) {
@@ -215,12 +217,14 @@ __device__ __forceinline__ void clx_ring_pump(Ring& g, uint32_t* row, uint32_t p
     const uint32_t dw = pos >> 5;
     if (g.npend >= 1u) { clx_ring_put(row, g.fill, g.pend0); g.fill += 4u; }
     if (g.npend >= 2u) { clx_ring_put(row, g.fill, g.pend1); g.fill += 4u; }
+    if (g.npend >= 3u) { clx_ring_put(row, g.fill, g.pend2); g.fill += 4u; }
     g.npend = 0;
     if (dw + 8u > g.fill || dw + CLX_RING < g.fill) clx_ring_reset(g, row, dw, limit);       // ran dry, or the position jumped
     else {
         const uint32_t room = CLX_RING - (g.fill - dw);                                     // dwords that may be overwritten
         if (room >= 4u) { g.pend0 = clx_ring_fetch(g, g.fill); g.npend = 1u; }
         if (room >= 8u) { g.pend1 = clx_ring_fetch(g, g.fill + 4u); g.npend = 2u; }
+        if (room >= 12u) { g.pend2 = clx_ring_fetch(g, g.fill + 8u); g.npend = 3u; }        // 384 bits per 16 codes: 24 bits per code sustained
         clx_ring_set_lim(g, limit);
     }
 }
@@ -291,7 +295,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     Ring g;
     g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
     g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0; g.fast_lim16 = 0;
+    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.pend2 = g.pend0; g.fast_lim = 0;
     const uint32_t bs = fr.block_size;
     uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
     uint32_t nch_max = nch;
@@ -301,7 +305,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     for (uint32_t ch = 0; ch < nch_max; ++ch) {
         const bool on = ch < nch && !r.err;
         // ---- headers (per lane, generic reader)
-        uint32_t codes = 0, first = 0, per = 0, parts_left = 0, rice2 = 0;
+        uint32_t codes = 0, first = 0, per = 0, parts_left = 0, rice2 = 0, order = 0;
         if (on) {
             const SfHead h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
             if (!r.err) {
@@ -327,7 +331,7 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                     }
                     if (!r.err) {
                         const ResHead rh = clx_lparse_residual_header(r, bs, h.order);
-                        if (!r.err) { codes = bs - h.order; first = rh.per - h.order; per = rh.per; parts_left = rh.n_part; rice2 = rh.rice2; }
+                        if (!r.err) { codes = bs - h.order; first = rh.per - h.order; per = rh.per; parts_left = rh.n_part; rice2 = rh.rice2; order = h.order; }
                     }
                 }
             }
@@ -335,6 +339,33 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         // ---- all Rice codes of this subframe: only their lengths matter here
         uint32_t left = r.err ? 0u : codes;                 // codes still to skip
         uint32_t pcnt = 0, next_cnt = first, k = 0, k1 = 1;
+        // one careful step (rolled where it is used): empty partitions, escape codes, long runs, EOF
+        auto careful_step = [&]() {
+            while (!r.err && pcnt == 0u && parts_left != 0u) {
+                k = clx_lread_rice_param(r, rice2); k1 = k + 1u; parts_left -= 1u; pcnt = next_cnt; next_cnt = per;
+            }
+            if (!r.err) {
+                const uint32_t v = clx_lpeek32(r, r.pos);
+                const uint32_t nb = (uint32_t)__clz((int)v) + k1;
+                if (v != 0u && nb <= 32u) {
+                    r.pos += nb;
+                    if (r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                } else (void)clx_lrice_slow(r, k);
+                pcnt -= 1u; left -= 1u;
+            }
+        };
+        // Partitions end at multiples of their length in SAMPLES: the first (-order & 3) codes go one by one, so that the
+        // blocks of four below start on multiples of 4 samples and meet partition edges only at their start -- in every
+        // lane, whatever the orders of the subframes the lanes scan.
+        {
+            uint32_t pre = (0u - order) & 3u;
+            pre = pre < left ? pre : left;
+#pragma unroll 1
+            for (; __any(pre != 0u); ) {
+                if (pre != 0u) { careful_step(); pre = r.err ? 0u : pre - 1u; }
+            }
+            if (r.err) left = 0u;
+        }
         uint32_t lmax = left;
 #pragma unroll
         for (int sx = 32; sx >= 1; sx >>= 1) { const uint32_t a = __shfl_xor(lmax, sx, 64); lmax = a > lmax ? a : lmax; }
@@ -345,21 +376,37 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
             // lean block: 4 codes of ONE partition (the common case: lanes that decode subframes of the same shape meet
             // their partition boundaries in the same block) -- count zeros, add, shift the window, nothing else; one vote
             {
-                Win w = clx_win_load64(row, r.pos);
-                uint32_t p = r.pos, mx = 0;
+                uint32_t p = r.pos, mx = 0, kq = k, k1q = k1, pc = pcnt, nx = next_cnt, pl = parts_left;
+                bool bad = false;
+                const bool at = busy && pcnt == 0u;             // a partition starts here: its parameter comes first
+                if (__any(at)) {
+                    const uint32_t pv = clx_ring_peek32(row, r.pos);
+                    if (at) {
+                        const uint32_t pb = rice2 ? 5u : 4u;
+                        kq = pv >> (32u - pb);
+                        bad = kq == (rice2 ? 31u : 15u) || pl == 0u || nx == 0u;
+                        k1q = kq + 1u; p += pb; pl -= 1u; pc = nx; nx = per;
+                    }
+                }
+                const uint32_t pw = p;
+                Win w = clx_win_load64(row, p);
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    const uint32_t nb = (uint32_t)__clz((int)w.a) + k1;        // 32 + k1 when the window is all zeros
+                    const uint32_t nb = (uint32_t)__clz((int)w.a) + k1q;       // 32 + k1 when the window is all zeros
                     mx = nb > mx ? nb : mx;
                     clx_win_skip(w, nb);
                     p += nb;
                 }
                 // (a lane with 1..3 codes left sends the wave to the general block, which finishes tails)
-                const bool lean_ok = busy ? (pcnt >= 4u && r.pos <= g.fast_lim && mx <= 32u) : (left == 0u || r.err != 0u);
+                const bool lean_ok = busy ? (!bad && pc >= 4u && clx_ring_covered(g, pw, p, r.limit) && mx <= 32u) : (left == 0u || r.err != 0u);
                 if (__all(lean_ok)) {
-                    if (busy) { r.pos = p; pcnt -= 4u; left -= 4u; }
+                    if (busy) { r.pos = p; k = kq; k1 = k1q; pcnt = pc - 4u; next_cnt = nx; parts_left = pl; left -= 4u; }
+                    CLX_STAT(0, 1);
                     continue;
                 }
+                CLX_STAT(1, 1);
+                CLX_STAT(2, busy && bad); CLX_STAT(3, busy && pc < 4u); CLX_STAT(4, busy && !clx_ring_covered(g, pw, p, r.limit)); CLX_STAT(5, busy && mx > 32u);
+                CLX_STAT(6, !busy && !(left == 0u || r.err != 0u));
             }
             // general block: 4 codes from a register window with partition parameters in between, no EOF possible, every
             // code <= 32 bits; committed only if every lane stayed on the common path
@@ -385,26 +432,14 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                 }
             }
             const bool all_ok = __all(ok || !busy);
+            CLX_STAT(7, all_ok);
             if (all_ok && busy) { r.pos = pos2; pcnt = pcnt2; k = k_2; k1 = k1_2; parts_left = parts2; next_cnt = next2; left -= 4u; }
             const bool tail = !r.err && left != 0u && left < 4u;
             if (!all_ok || __any(tail)) {
                 // careful steps (rolled): empty partitions, escape codes, long runs, EOF, tails
 #pragma unroll 1
                 for (int ii = 0; ii < 4; ++ii) {
-                    if (!r.err && left != 0u && (!all_ok || left < 4u)) {
-                        while (!r.err && pcnt == 0u && parts_left != 0u) {
-                            k = clx_lread_rice_param(r, rice2); k1 = k + 1u; parts_left -= 1u; pcnt = next_cnt; next_cnt = per;
-                        }
-                        if (!r.err) {
-                            const uint32_t v = clx_lpeek32(r, r.pos);
-                            const uint32_t nb = (uint32_t)__clz((int)v) + k1;
-                            if (v != 0u && nb <= 32u) {
-                                r.pos += nb;
-                                if (r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-                            } else (void)clx_lrice_slow(r, k);
-                            pcnt -= 1u; left -= 1u;
-                        }
-                    }
+                    if (!r.err && left != 0u && (!all_ok || left < 4u)) careful_step();
                 }
             }
         }
@@ -557,6 +592,76 @@ __device__ __forceinline__ int32_t clx_lfinish(int32_t s, const Finish& F) {
     return mine;
 }
 
+// ---- the lean blocks' common parts ------------------------------------------------------------------------------------
+// What a lane is doing while the lean blocks run (fixed once the prologue is over): Rice codes, verbatim fields, or a
+// constant.  Lanes of all three kinds run the same straight-line code; masks pick what applies.
+struct LeanKind {
+    bool rice, verb;
+    uint32_t bitmask;        // all ones where the lane consumes bits (Rice, verbatim), 0 for a constant
+    uint32_t ricemask;       // all ones for Rice lanes: only their code lengths can exceed the window
+    uint32_t cor;            // the constant, OR-ed in for constant lanes
+    uint32_t vbits, vsh;     // verbatim field width and the shift that sign-extends it
+};
+template <int OMAX>
+__device__ __forceinline__ LeanKind clx_lean_kind(const LaneState<OMAX>& S, const SfHead& h) {
+    LeanKind K;
+    K.rice = S.phase == 1u; K.verb = S.phase == 0u;
+    K.bitmask = S.phase == 2u ? 0u : 0xffffffffu;
+    K.ricemask = K.rice ? 0xffffffffu : 0u;
+    K.cor = S.phase == 2u ? (uint32_t)S.cval : 0u;
+    K.vbits = h.sf_bps; K.vsh = (32u - h.sf_bps) & 31u;
+    return K;
+}
+// The cursor a lean block works on (committed only if the wave's vote passes).
+struct LeanCur { uint32_t p, k, k1, pcnt, next, parts; bool bad; };
+// A partition that starts exactly where the block starts: its parameter is read first (subframe.rs:314-319 / 362-367).
+// Partitions are a multiple of 4 (16) samples long in every stream whose block size allows it, and the prologue leaves
+// every lane on a multiple of 16 -- so this is where partition boundaries fall, also when the lanes of a wave decode
+// subframes of different shapes.  `any_at` (a wave vote by the caller) keeps the LDS read off the common path.
+template <int OMAX>
+__device__ __forceinline__ LeanCur clx_lean_begin(const LaneState<OMAX>& S, const uint32_t* ringrow, bool live, const LeanKind& K) {
+    LeanCur c = { S.r.pos, S.k, S.k1, S.pcnt, S.next_cnt, S.parts_left, false };
+    const bool at = live && K.rice && S.pcnt == 0u;
+    if (__any(at)) {
+        const uint32_t pv = clx_ring_peek32(ringrow, S.r.pos);
+        if (at) {
+            const uint32_t pb = S.rice2 ? 5u : 4u;
+            c.k = pv >> (32u - pb);
+            c.bad = c.k == (S.rice2 ? 31u : 15u) || c.parts == 0u || c.next == 0u;
+            c.k1 = c.k + 1u; c.p += pb; c.parts -= 1u; c.pcnt = c.next; c.next = S.per;
+        }
+    }
+    return c;
+}
+// N (a multiple of 4) values from register windows of 4; VERB (wave-uniform): some lane reads verbatim fields
+template <int N, bool VERB>
+__device__ __forceinline__ void clx_lean_codes(const uint32_t* ringrow, const LeanKind& K, uint32_t k, uint32_t k1, uint32_t& p, uint32_t& mx,
+                                               uint32_t& pw, int32_t (&X)[N]) {
+    const uint32_t kk = k & 31u;
+#pragma unroll
+    for (int b4 = 0; b4 < N / 4; ++b4) {
+        pw = p;
+        Win w = clx_win_load64(ringrow, p);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t z = (uint32_t)__clz((int)w.a);                  // 32 when the window is all zeros
+            const uint32_t nbr = z + k1;
+            const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nbr, k);     // (q << k) | r, subframe.rs:337-341
+            int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);            // rice_to_signed (subframe.rs:157-170)
+            uint32_t nb = nbr;
+            if (VERB) {                                                    // verbatim rows ride along (subframe.rs:397-415)
+                x = K.verb ? ((int32_t)w.a >> K.vsh) : x;
+                nb = K.verb ? K.vbits : nbr;
+            }
+            X[4 * b4 + ii] = (int32_t)(((uint32_t)x & K.bitmask) | K.cor);
+            const uint32_t nbx = nbr & K.ricemask;
+            mx = nbx > mx ? nbx : mx;
+            clx_win_skip(w, nb);
+            p += nb & K.bitmask;
+        }
+    }
+}
+
 template <int OMAX>
 __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint32_t* ringrow, int4* stage, const SfHead h, uint32_t bs, uint32_t n,
                                                uint32_t decor, bool pair_ok, int32_t* __restrict__ row, bool row_aligned,
@@ -600,33 +705,19 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     K2Mover M; M.init(out, ms, lane);
     int4* const tile = stage - 4 * lane;                 // the wave's 64 x 4 staging slots seen as one tile
     const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+    const LeanKind K = clx_lean_kind<OMAX>(S, h);         // (the prologue is over: no lane changes its kind any more)
+    const bool any_verb = __any(n != 0u && !r.err && K.verb);
     for (uint32_t t0 = i0; t0 < nmax; t0 += 4u) {
         if ((t0 & 12u) == 0u && t0 != i0) clx_ring_pump(g, ringrow, r.pos, r.limit);
         const bool live = (n != 0u) && !r.err && t0 < n;
         // ---- lean turn: sixteen samples at once when every live lane is in the middle of a Rice partition (or repeats a
         //      constant), nothing is near an edge and the 24-bit predictor holds: four register windows, ONE vote.
         if ((t0 & 12u) == 0u && !no_lean && al16) {
-            const bool rice = S.phase == 1u;
-            const uint32_t rmask = rice ? 0xffffffffu : 0u;                    // constant lanes consume no bits
-            const uint32_t kk = S.k & 31u;
-            uint32_t p = r.pos, mx = 0;
+            LeanCur c = clx_lean_begin<OMAX>(S, ringrow, live, K);
+            uint32_t mx = 0, pw = 0;
             int32_t Y[16];
-#pragma unroll
-            for (int b4 = 0; b4 < 4; ++b4) {
-                Win w = clx_win_load64(ringrow, p);
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const uint32_t z = (uint32_t)__clz((int)w.a);
-                    const uint32_t nb = z + S.k1;
-                    const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);    // (q << k) | r, subframe.rs:337-341
-                    const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);      // rice_to_signed (subframe.rs:157-170)
-                    Y[4 * b4 + ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
-                    const uint32_t nbm = nb & rmask;
-                    mx = nbm > mx ? nbm : mx;
-                    clx_win_skip(w, nb);
-                    p += nbm;
-                }
-            }
+            if (any_verb) clx_lean_codes<16, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, Y);
+            else          clx_lean_codes<16, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, Y);
             int32_t hh[OMAX];
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) hh[j] = S.hist[j];
@@ -644,12 +735,19 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
             for (int ii = 1; ii + 1 < 16; ii += 2) { hi = clx_max3(hi, Y[ii], Y[ii + 1]); lo = clx_min3(lo, Y[ii], Y[ii + 1]); }
             hi = Y[15] > hi ? Y[15] : hi; lo = Y[15] < lo ? Y[15] : lo;
             const bool in_range = S.order == 0u || (hi < S.lim && lo >= -S.lim);
-            const bool ok16 = !live || ((rice ? (S.transitioned && S.pcnt >= 16u && r.pos <= g.fast_lim16 && mx <= 32u) : S.phase == 2u)
-                                        && t0 + 16u <= n && S.lim >= 0 && in_range);
+            const bool ok16 = !live || ((K.rice ? (S.transitioned && !c.bad && c.pcnt >= 16u && mx <= 32u)
+                                                : K.verb ? true : S.phase == 2u)
+                                        && (S.phase == 2u || clx_ring_covered(g, pw, c.p, r.limit)) && t0 + 16u <= n && S.lim >= 0 && in_range);
+            if (!__all(ok16)) {
+                CLX_STAT(17, 1);
+                CLX_STAT(18, live && K.rice && !S.transitioned); CLX_STAT(19, live && K.rice && c.bad); CLX_STAT(20, live && K.rice && c.pcnt < 16u);
+                CLX_STAT(21, live && !(S.phase == 2u) && !clx_ring_covered(g, pw, c.p, r.limit)); CLX_STAT(22, live && mx > 32u); CLX_STAT(23, live && t0 + 16u > n);
+                CLX_STAT(24, live && S.lim < 0); CLX_STAT(25, live && !in_range); CLX_STAT(26, live && S.phase == 3u);
+            }
             if (__all(ok16)) {
                 if (live) {
-                    r.pos = p;
-                    if (rice) S.pcnt -= 16u;
+                    r.pos = c.p;
+                    if (K.rice) { S.k = c.k; S.k1 = c.k1; S.pcnt = c.pcnt - 16u; S.next_cnt = c.next; S.parts_left = c.parts; }
 #pragma unroll
                     for (int j = 0; j < OMAX; ++j) S.hist[j] = hh[j];
                 }
@@ -666,6 +764,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                 *reinterpret_cast<int4*>(t < M.rn[3] ? const_cast<int32_t*>(M.rp[3]) + t : dump + 12) = w3;
                 clx_wave_sync();
                 t0 += 12u;                                   // the whole turn is done
+                CLX_STAT(16, 1);
                 continue;
             } else if (__any(live && S.lim < 0 && S.order != 0u)) no_lean = true;   // a lane needs the i64 predictor from now on
         }
@@ -675,24 +774,11 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
         //      edge, the 24-bit predictor holds: four codes, four predictor steps, ONE vote.  Lanes that decode subframes
         //      of the same shape meet their partition boundaries in the same block, so this is the common case by far.
         if (!no_lean) {
-            const bool rice = S.phase == 1u;
-            const uint32_t rmask = rice ? 0xffffffffu : 0u;                    // constant lanes consume no bits
-            Win w = clx_win_load64(ringrow, r.pos);
-            uint32_t p = r.pos, mx = 0;
+            LeanCur c = clx_lean_begin<OMAX>(S, ringrow, live, K);
+            uint32_t mx = 0, pw = 0;
             int32_t xs[4];
-            const uint32_t kk = S.k & 31u;
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const uint32_t z = (uint32_t)__clz((int)w.a);                  // 32 when the window is all zeros
-                const uint32_t nb = z + S.k1;
-                const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);    // (q << k) | r, subframe.rs:337-341
-                const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);      // rice_to_signed (subframe.rs:157-170)
-                xs[ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
-                const uint32_t nbm = nb & rmask;
-                mx = nbm > mx ? nbm : mx;
-                clx_win_skip(w, nb);
-                p += nbm;
-            }
+            if (any_verb) clx_lean_codes<4, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
+            else          clx_lean_codes<4, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
             int32_t hh[OMAX];
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) hh[j] = S.hist[j];
@@ -708,21 +794,29 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
             int32_t hi = clx_max3(y[0], y[1], y[2]), lo = clx_min3(y[0], y[1], y[2]);
             hi = y[3] > hi ? y[3] : hi; lo = y[3] < lo ? y[3] : lo;
             const bool in_range = S.order == 0u || (hi < S.lim && lo >= -S.lim);
-            const bool lean_ok = !live || ((rice ? (S.transitioned && S.pcnt >= 4u && r.pos <= g.fast_lim && mx <= 32u) : S.phase == 2u)
-                                           && t0 + 4u <= n && S.lim >= 0 && in_range);
+            const bool lean_ok = !live || ((K.rice ? (S.transitioned && !c.bad && c.pcnt >= 4u && mx <= 32u)
+                                                   : K.verb ? true : S.phase == 2u)
+                                           && (S.phase == 2u || clx_ring_covered(g, pw, c.p, r.limit)) && t0 + 4u <= n && S.lim >= 0 && in_range);
             if (__all(lean_ok)) {
                 if (live) {
-                    r.pos = p;
-                    if (rice) S.pcnt -= 4u;
+                    r.pos = c.p;
+                    if (K.rice) { S.k = c.k; S.k1 = c.k1; S.pcnt = c.pcnt - 4u; S.next_cnt = c.next; S.parts_left = c.parts; }
 #pragma unroll
                     for (int j = 0; j < OMAX; ++j) S.hist[j] = hh[j];
                 }
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], F);
                 lean_done = true;
-            } else if (__any(live && S.lim < 0 && S.order != 0u)) no_lean = true;   // a lane needs the i64 predictor from now on
+                CLX_STAT(32, 1);
+            } else {
+                CLX_STAT(40, live && K.rice && !S.transitioned); CLX_STAT(41, live && K.rice && c.bad); CLX_STAT(42, live && K.rice && c.pcnt < 4u);
+                CLX_STAT(43, live && !(S.phase == 2u) && !clx_ring_covered(g, pw, c.p, r.limit)); CLX_STAT(44, live && mx > 32u); CLX_STAT(45, live && t0 + 4u > n);
+                CLX_STAT(46, live && S.lim < 0); CLX_STAT(47, live && !in_range); CLX_STAT(48, live && S.phase == 3u);
+            }
+            if (lean_done) {} else if (__any(live && S.lim < 0 && S.order != 0u)) no_lean = true;   // a lane needs the i64 predictor from now on
         }
         if (!lean_done) {
+            CLX_STAT(33, 1); CLX_STAT(34, no_lean);
             const bool rice_on = live && S.phase == 1u;
             const bool verb_on = live && S.phase == 0u;
             bool can = true;
@@ -767,6 +861,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                 }
             }
             const bool all_ok = __all(ok);
+            CLX_STAT(35, all_ok); CLX_STAT(36, all_ok && __any(wide));
             if (all_ok) {
                 if (live) { r.pos = pos2; S.pcnt = pcnt2; S.k = k_2; S.k1 = k1_2; S.parts_left = parts2; S.next_cnt = next2; }
                 // predictor over the block: 24-bit evaluation, range-checked; exact i64 re-run when outside the proven range
@@ -923,7 +1018,7 @@ __device__ __forceinline__ void clx_lanes_fused(const uint8_t* __restrict__ aren
     Ring g;
     g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
     g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0; g.fast_lim16 = 0;
+    g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.pend2 = g.pend0; g.fast_lim = 0;
 
     SfHead h = { 1u, 0u, 0u, 1u };
     if (active && !r.err) h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
@@ -1028,31 +1123,21 @@ __device__ __forceinline__ void clx_rice_wave(LaneState<32>& S, Ring& g, uint32_
             const uint32_t tb = 16u * T;
             clx_ring_pump(g, ringrow, r.pos, r.limit);
             const bool live = (n != 0u) && !r.err && tb < n;
-            const bool rice = S.phase == 1u;
-            const uint32_t rmask = rice ? 0xffffffffu : 0u;
-            const uint32_t kk = S.k & 31u;
-            uint32_t p = r.pos, mx = 0;
+            const LeanKind K = clx_lean_kind<32>(S, h);
+            const bool any_verb = __any(live && K.verb);
+            LeanCur c = clx_lean_begin<32>(S, ringrow, live, K);
+            uint32_t mx = 0, pw = 0;
             int32_t X[16];
-#pragma unroll
-            for (int b4 = 0; b4 < 4; ++b4) {
-                Win w = clx_win_load64(ringrow, p);
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const uint32_t z = (uint32_t)__clz((int)w.a);
-                    const uint32_t nb = z + S.k1;
-                    const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);    // (q << k) | r, subframe.rs:337-341
-                    const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);      // rice_to_signed (subframe.rs:157-170)
-                    X[4 * b4 + ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
-                    const uint32_t nbm = nb & rmask;
-                    mx = nbm > mx ? nbm : mx;
-                    clx_win_skip(w, nb);
-                    p += nbm;
-                }
-            }
-            const bool ok16 = !live || ((rice ? (S.transitioned && S.pcnt >= 16u && r.pos <= g.fast_lim16 && mx <= 32u) : S.phase == 2u)
-                                        && tb + 16u <= n);
+            if (any_verb) clx_lean_codes<16, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, X);
+            else          clx_lean_codes<16, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, X);
+            const bool ok16 = !live || ((K.rice ? (S.transitioned && !c.bad && c.pcnt >= 16u && mx <= 32u)
+                                                : K.verb ? true : S.phase == 2u)
+                                        && (S.phase == 2u || clx_ring_covered(g, pw, c.p, r.limit)) && tb + 16u <= n);
             if (__all(ok16)) {
-                if (live) { r.pos = p; if (rice) S.pcnt -= 16u; }
+                if (live) {
+                    r.pos = c.p;
+                    if (K.rice) { S.k = c.k; S.k1 = c.k1; S.pcnt = c.pcnt - 16u; S.next_cnt = c.next; S.parts_left = c.parts; }
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < 4u; ++q) out4[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
                 clx_wg_barrier();
@@ -1076,27 +1161,20 @@ __device__ __forceinline__ void clx_rice_wave(LaneState<32>& S, Ring& g, uint32_
                 bool lean_done = false;
                 // lean block: see clx_lanes_body -- here without the predictor
                 {
-                    const bool rice = S.phase == 1u;
-                    const uint32_t rmask = rice ? 0xffffffffu : 0u;
-                    Win w = clx_win_load64(ringrow, r.pos);
-                    uint32_t p = r.pos, mx = 0;
-                    const uint32_t kk = S.k & 31u;
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const uint32_t z = (uint32_t)__clz((int)w.a);
-                        const uint32_t nb = z + S.k1;
-                        const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nb, S.k);
-                        const int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
-                        xs[ii] = (int32_t)(((uint32_t)x & rmask) | (uint32_t)(rice ? 0 : S.cval));
-                        const uint32_t nbm = nb & rmask;
-                        mx = nbm > mx ? nbm : mx;
-                        clx_win_skip(w, nb);
-                        p += nbm;
-                    }
-                    const bool lean_ok = !live || ((rice ? (S.transitioned && S.pcnt >= 4u && r.pos <= g.fast_lim && mx <= 32u) : S.phase == 2u)
-                                                   && t0 + 4u <= n);
+                    const LeanKind K = clx_lean_kind<32>(S, h);
+                    const bool any_verb = __any(live && K.verb);
+                    LeanCur c = clx_lean_begin<32>(S, ringrow, live, K);
+                    uint32_t mx = 0, pw = 0;
+                    if (any_verb) clx_lean_codes<4, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
+                    else          clx_lean_codes<4, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
+                    const bool lean_ok = !live || ((K.rice ? (S.transitioned && !c.bad && c.pcnt >= 4u && mx <= 32u)
+                                                           : K.verb ? true : S.phase == 2u)
+                                                   && (S.phase == 2u || clx_ring_covered(g, pw, c.p, r.limit)) && t0 + 4u <= n);
                     if (__all(lean_ok)) {
-                        if (live) { r.pos = p; if (rice) S.pcnt -= 4u; }
+                        if (live) {
+                            r.pos = c.p;
+                            if (K.rice) { S.k = c.k; S.k1 = c.k1; S.pcnt = c.pcnt - 4u; S.next_cnt = c.next; S.parts_left = c.parts; }
+                        }
                         lean_done = true;
                     }
                 }
@@ -1272,7 +1350,7 @@ void clx_k_lanes2(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         Ring g;
         g.src = reinterpret_cast<const uint32_t*>(arena + r.origin);
         g.avail_dw = (uint32_t)((arena_alloc_len > r.origin ? arena_alloc_len - r.origin : 0ull) >> 2);
-        g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.fast_lim = 0; g.fast_lim16 = 0;
+        g.fill = 0; g.npend = 0; g.pend0 = make_uint4(0u, 0u, 0u, 0u); g.pend1 = g.pend0; g.pend2 = g.pend0; g.fast_lim = 0;
         SfHead h = { 1u, 0u, 0u, 1u };
         if (active && !r.err) h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
         uint32_t omax = (active && !r.err && h.kind >= 2u) ? h.order : 0u;

@@ -1,5 +1,8 @@
 // TEST INFRASTRUCTURE: runs the production kernel source under the wave simulator.
 #include <vector>
+#include <cstdint>
+extern "C" { uint64_t sim_stats[64]; }
+#define CLX_STAT(i, n) (sim_stats[i] += (uint64_t)(n))
 #include "clx_kernels.hip"
 #include "clx_lanes.hip"
 #include "clx_plan.h"

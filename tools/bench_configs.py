@@ -19,7 +19,7 @@ for name, make in makers:
     d_arena = torch.from_numpy(w.arena).cuda()
     d_out = torch.zeros(w.pcm.size, dtype=torch.int32, device="cuda")
     ref = torch.from_numpy(w.pcm).cuda()
-    for pname, path in (("waves", cx.PATH_WAVES), ("lanes", cx.PATH_LANES)):
+    for pname, path in (("waves", cx.PATH_WAVES), ("lanes-split", cx.PATH_LANES | cx.LANES_SPLIT), ("lanes-fused", cx.PATH_LANES | cx.LANES_FUSED)):
         batch = ctx.plan(descs, w.out_offs, path=path)
         for _ in range(3):
             batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr())
@@ -32,5 +32,5 @@ for name, make in makers:
         ms = (time.perf_counter() - t) * 100
         batch.set_profiling(True); batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr()); torch.cuda.synchronize()
         km = {k: round(v, 3) for k, v in batch.kernel_times().items()}
-        print(f"{name:52s} {pname}: {ms:7.3f} ms  {w.pcm.size / ms / 1e6:7.1f} Gsamples/s  bit_exact={ok}  {km}", flush=True)
+        print(f"{name:52s} {pname:11s}: {ms:7.3f} ms  {w.pcm.size / ms / 1e6:7.1f} Gsamples/s  bit_exact={ok}  {km}", flush=True)
         batch.close()
