@@ -23,6 +23,7 @@
 #include <clx_intrin.h>
 
 #include "../../include/claxon_hip.h"
+#include <type_traits>
 #include "clx_device.h"
 
 #define CLX_LERR(status, msg) (((uint32_t)(status) << 16) | (uint32_t)(msg))
@@ -373,41 +374,51 @@ void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
         for (uint32_t i0 = 0; i0 < lmax; i0 += 4u) {
             if ((i0 & 12u) == 0u && i0 != 0u) clx_ring_pump(g, row, r.pos, r.limit);
             const bool busy = left >= 4u;
-            // lean block: 4 codes of ONE partition (the common case: lanes that decode subframes of the same shape meet
-            // their partition boundaries in the same block) -- count zeros, add, shift the window, nothing else; one vote
-            {
-                uint32_t p = r.pos, mx = 0, kq = k, k1q = k1, pc = pcnt, nx = next_cnt, pl = parts_left;
+            // lean blocks: NB x 4 codes, each four inside ONE partition (blocks start on multiples of 4 samples, partitions on
+            // multiples of their length: a partition may START with a four, its parameter is read then) -- count zeros, add,
+            // shift the window, nothing else; one vote.  Sixteen codes at a time where the pump's cadence allows, else four.
+            auto lean = [&](auto nb_tag) -> bool {
+                constexpr uint32_t NC = 4u * (uint32_t)decltype(nb_tag)::value;
+                const bool go = left >= NC;
+                uint32_t p = r.pos, mx = 0, kq = k, k1q = k1, pc = pcnt, nx = next_cnt, pl = parts_left, pw = 0;
                 bool bad = false;
-                const bool at = busy && pcnt == 0u;             // a partition starts here: its parameter comes first
-                if (__any(at)) {
-                    const uint32_t pv = clx_ring_peek32(row, r.pos);
-                    if (at) {
-                        const uint32_t pb = rice2 ? 5u : 4u;
-                        kq = pv >> (32u - pb);
-                        bad = kq == (rice2 ? 31u : 15u) || pl == 0u || nx == 0u;
-                        k1q = kq + 1u; p += pb; pl -= 1u; pc = nx; nx = per;
+#pragma unroll
+                for (uint32_t b4 = 0; b4 < NC / 4u; ++b4) {
+                    const bool at = go && pc == 0u;             // a partition starts here: its parameter comes first
+                    if (__any(at)) {
+                        const uint32_t pv = clx_ring_peek32(row, p);
+                        if (at) {
+                            const uint32_t pb = rice2 ? 5u : 4u;
+                            kq = pv >> (32u - pb);
+                            bad = bad || kq == (rice2 ? 31u : 15u) || pl == 0u || nx == 0u;
+                            k1q = kq + 1u; p += pb; pl -= 1u; pc = nx; nx = per;
+                        }
+                    }
+                    bad = bad || pc < 4u;                       // (a partition edge inside the four codes: the general block's)
+                    pc -= 4u;
+                    pw = p;
+                    Win w = clx_win_load64(row, p);
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const uint32_t nb = (uint32_t)__clz((int)w.a) + k1q;   // 32 + k1 when the window is all zeros
+                        mx = nb > mx ? nb : mx;
+                        clx_win_skip(w, nb);
+                        p += nb;
                     }
                 }
-                const uint32_t pw = p;
-                Win w = clx_win_load64(row, p);
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const uint32_t nb = (uint32_t)__clz((int)w.a) + k1q;       // 32 + k1 when the window is all zeros
-                    mx = nb > mx ? nb : mx;
-                    clx_win_skip(w, nb);
-                    p += nb;
+                // (a lane with fewer codes left sends the wave on to the smaller blocks; the general block finishes tails)
+                const bool lean_ok = go ? (!bad && clx_ring_covered(g, pw, p, r.limit) && mx <= 32u) : (left == 0u || r.err != 0u);
+                const bool all = __all(lean_ok);
+                if (all && go) { r.pos = p; k = kq; k1 = k1q; pcnt = pc; next_cnt = nx; parts_left = pl; left -= NC; }
+                if (NC == 4u && !all) {
+                    CLX_STAT(2, go && bad); CLX_STAT(4, go && !clx_ring_covered(g, pw, p, r.limit)); CLX_STAT(5, go && mx > 32u);
+                    CLX_STAT(6, !go && !(left == 0u || r.err != 0u));
                 }
-                // (a lane with 1..3 codes left sends the wave to the general block, which finishes tails)
-                const bool lean_ok = busy ? (!bad && pc >= 4u && clx_ring_covered(g, pw, p, r.limit) && mx <= 32u) : (left == 0u || r.err != 0u);
-                if (__all(lean_ok)) {
-                    if (busy) { r.pos = p; k = kq; k1 = k1q; pcnt = pc - 4u; next_cnt = nx; parts_left = pl; left -= 4u; }
-                    CLX_STAT(0, 1);
-                    continue;
-                }
-                CLX_STAT(1, 1);
-                CLX_STAT(2, busy && bad); CLX_STAT(3, busy && pc < 4u); CLX_STAT(4, busy && !clx_ring_covered(g, pw, p, r.limit)); CLX_STAT(5, busy && mx > 32u);
-                CLX_STAT(6, !busy && !(left == 0u || r.err != 0u));
-            }
+                return all;
+            };
+            if ((i0 & 12u) == 0u && lean(std::integral_constant<int, 4>())) { CLX_STAT(8, 1); i0 += 12u; continue; }
+            if (lean(std::integral_constant<int, 1>())) { CLX_STAT(0, 1); continue; }
+            CLX_STAT(1, 1);
             // general block: 4 codes from a register window with partition parameters in between, no EOF possible, every
             // code <= 32 bits; committed only if every lane stayed on the common path
             uint32_t pos2 = r.pos, pcnt2 = pcnt, k_2 = k, k1_2 = k1, parts2 = parts_left, next2 = next_cnt;

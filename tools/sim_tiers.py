@@ -8,7 +8,7 @@ import claxon_amd as cx, synth, simlib
 from parity_cases import workload_descs
 
 NAMES = {0: "scan lean ok", 1: "scan lean failed", 2: " .. bad param", 3: " .. partition edge inside", 4: " .. ring/eof margin", 5: " .. code > 32 bits",
-         6: " .. tail lane", 7: "scan general ok",
+         6: " .. tail lane", 7: "scan general ok", 8: "scan lean16 ok",
          16: "D lean16 ok", 17: "D lean16 failed", 18: " .. not transitioned", 19: " .. bad param", 20: " .. partition edge inside",
          21: " .. ring/eof margin", 22: " .. code > 32 bits", 23: " .. row end", 24: " .. needs i64", 25: " .. out of range", 26: " .. idle",
          32: "D lean4 ok", 33: "D general entered", 34: " .. with no_lean", 35: "D general ok", 36: " .. wide",
