@@ -495,8 +495,8 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
             const uint32_t slot = fr.first_slot + ch;
             clx_sf_desc* d = &sfd[slot];
             if ((uint32_t)lane < 32u) d->coef[lane] = (int16_t)((uint32_t)lane < order ? my_coef : 0);
-            // sum|c| over the taps: K2 may evaluate the recurrence in 32 bits with 24-bit factors when
-            // sum|c| * 2^(sf_bps-1) < 2^31 and sf_bps <= 24 (exact for every in-range history; K2 re-checks the range)
+            // sum|c| over the taps: K2 may evaluate the recurrence in 32 bits with 24-bit factors while the history stays
+            // inside [-lim, lim), lim <= 2^23 and sum|c| * lim < 2^31 (exact for every in-range history; K2 checks the data)
             uint32_t cabs = (uint32_t)(my_coef < 0 ? -my_coef : my_coef);
             if ((uint32_t)lane >= order || kind < 2u) cabs = 0;
 #pragma unroll
@@ -507,7 +507,11 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                 d->shift = (uint8_t)qshift;
                 d->wasted = (uint8_t)wasted;
                 d->decor = (uint8_t)ca;
-                d->lim_log2 = (uint8_t)((sf_bps <= 24u && ((uint64_t)cabs << (sf_bps - 1u)) < (1ull << 31)) ? (sf_bps - 1u) : 0xffu);
+                {   // the largest power of two that keeps sum|c| * lim < 2^31 (and 24-bit factors): K2 checks the data against it
+                    const uint32_t by_sum = cabs != 0u ? 0x7fffffffu / cabs : 0x7fffffffu;
+                    const uint32_t ll = 31u - (uint32_t)__clz((int)(by_sum | 1u));
+                    d->lim_log2 = (uint8_t)(ll < 23u ? ll : 23u);
+                }
                 d->reserved = 0;
                 d->n = (uint16_t)bs;
             }

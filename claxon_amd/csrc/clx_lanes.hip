@@ -522,7 +522,14 @@ __device__ __forceinline__ void clx_ltransition(LaneState<OMAX>& S, const SfHead
         cabs = o == 1u ? 1u : o == 2u ? 3u : o == 3u ? 7u : o == 4u ? 15u : 0u;
     }
     S.order = h.order;
-    S.lim = (h.sf_bps <= 24u && ((uint64_t)cabs << (h.sf_bps - 1u)) < (1ull << 31)) ? (int32_t)(1u << (h.sf_bps - 1u)) : -1;
+    // 24-bit evaluation (v_mad_i32_i24 chains, i32 accumulate) == the reference's i64 evaluation (subframe.rs:464-505) while
+    // every history value s has |s| <= lim <= 2^23 with sum|c| * lim < 2^31: the factors fit 24 bits and no partial sum
+    // wraps.  Which samples are inside is checked on the data, not assumed from the bit depth: streams whose sum|c| * 2^(bps-1)
+    // reaches 2^31 (high precision, loud side channels) still run in 24 bits wherever the signal allows.
+    {
+        const uint32_t by_sum = cabs != 0u ? 0x7fffffffu / cabs : 0x7fffffffu;
+        S.lim = (int32_t)(by_sum < (1u << 23) ? by_sum : (1u << 23));
+    }
     const ResHead rh = clx_lparse_residual_header(r, bs, h.order);
     S.rice2 = rh.rice2; S.per = rh.per; S.parts_left = rh.n_part;
     S.pcnt = 0; S.next_cnt = rh.per - h.order;     // the first partition holds per - order codes (subframe.rs:283)
@@ -697,18 +704,20 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     }
     // ---- steady state: blocks of 4 samples through the LDS ring, rolled back to careful steps when anything is unusual
     if (i0 < nmax) clx_ring_reset(g, ringrow, r.pos >> 5, r.limit);
-    bool wide = false;                                   // sticky: i64 accumulate from now on (made wave-uniform where it is used)
-    bool no_lean = false;                                // wave-uniform, sticky: the lean block cannot succeed any more
-    // The prologue predicts in i64 and checks nothing: a corrupt stream may have left history values outside the range
-    // in which 24-bit factors are exact.  The blocks below only range-check their OUTPUTS (computed from the history), so
-    // the history they start from has to be vouched for here.
+    // The 24-bit predictor is exact while the history it reads lies inside [-lim, lim) (see clx_lsetup_predictor).  The
+    // blocks below range-check their OUTPUTS, which become the history of the next block; `good` counts how many of the most
+    // recent samples were inside (saturating), so `good >= order` vouches for a block's starting history.  Blocks that
+    // evaluated in 24 bits and were accepted keep it true; the i64 evaluations (prologue, wide blocks, careful steps) check
+    // nothing, so `good` is recounted after them -- and the 24-bit blocks resume once the signal is back inside the range.
+    uint32_t good;
     {
         bool hist_in = S.lim >= 0;
 #pragma unroll
         for (int j = 0; j < OMAX; ++j) hist_in = hist_in && S.hist[j] < S.lim && S.hist[j] >= -S.lim;
-        if (n != 0u && !r.err && S.order != 0u && !hist_in) wide = true;
-        if (__any(wide)) no_lean = true;
+        good = hist_in ? 64u : 0u;
     }
+    bool wide = n != 0u && !r.err && S.order != 0u && good < S.order;    // this lane needs the i64 predictor for its next block
+    bool no_lean = __any(wide);                          // wave-uniform: the lean blocks (24-bit only) cannot run now
     // rows that allow 16-byte accesses leave through the 64 B x 16 rows store shape (see K2 in clx_kernels.hip), a whole
     // turn of 16 samples at a time
     const bool al16 = __all(n == 0u || (row_aligned && (n & 3u) == 0u));
@@ -777,7 +786,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                 t0 += 12u;                                   // the whole turn is done
                 CLX_STAT(16, 1);
                 continue;
-            } else if (__any(live && S.lim < 0 && S.order != 0u)) no_lean = true;   // a lane needs the i64 predictor from now on
+            }
         }
         int32_t y[4];
         bool lean_done = false;
@@ -824,7 +833,6 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                 CLX_STAT(43, live && !(S.phase == 2u) && !clx_ring_covered(g, pw, c.p, r.limit)); CLX_STAT(44, live && mx > 32u); CLX_STAT(45, live && t0 + 4u > n);
                 CLX_STAT(46, live && S.lim < 0); CLX_STAT(47, live && !in_range); CLX_STAT(48, live && S.phase == 3u);
             }
-            if (lean_done) {} else if (__any(live && S.lim < 0 && S.order != 0u)) no_lean = true;   // a lane needs the i64 predictor from now on
         }
         if (!lean_done) {
             CLX_STAT(33, 1); CLX_STAT(34, no_lean);
@@ -836,7 +844,6 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                 if (S.phase != 2u) can = can && r.pos <= g.fast_lim;
                 if (S.phase == 1u) can = can && S.transitioned;
             }
-            if (S.lim < 0 && live && S.order != 0u) wide = true;
             uint32_t pos2 = r.pos, pcnt2 = S.pcnt, k_2 = S.k, k1_2 = S.k1, parts2 = S.parts_left, next2 = S.next_cnt;
             int32_t xs[4];
             bool ok = can;
@@ -876,12 +883,12 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
             if (all_ok) {
                 if (live) { r.pos = pos2; S.pcnt = pcnt2; S.k = k_2; S.k1 = k1_2; S.parts_left = parts2; S.next_cnt = next2; }
                 // predictor over the block: 24-bit evaluation, range-checked; exact i64 re-run when outside the proven range
-                wide = __any(wide);
-                bool redo = wide;
+                const bool wv = __any(wide);
+                bool redo = wv;
                 int32_t h0[OMAX];
     #pragma unroll
                 for (int j = 0; j < OMAX; ++j) h0[j] = S.hist[j];
-                if (!wide) {
+                if (!wv) {
     #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         const int32_t pred = clx_lpredict<OMAX, false>(S.c, S.hist, S.shift);
@@ -894,7 +901,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                     int32_t mx = clx_max3(y[0], y[1], y[2]), mn = clx_min3(y[0], y[1], y[2]);
                     mx = y[3] > mx ? y[3] : mx; mn = y[3] < mn ? y[3] : mn;
                     const bool in_range = !live || S.order == 0u || (mx < S.lim && mn >= -S.lim);
-                    if (!__all(in_range)) { redo = true; wide = true; }
+                    if (!__all(in_range)) redo = true;
                 }
                 if (redo) {
     #pragma unroll
@@ -908,6 +915,12 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                         S.hist[0] = s;
                         y[ii] = s;
                     }
+                    // nobody checked these four: recount (conservatively -- one sample outside restarts the count)
+                    int32_t mx = clx_max3(y[0], y[1], y[2]), mn = clx_min3(y[0], y[1], y[2]);
+                    mx = y[3] > mx ? y[3] : mx; mn = y[3] < mn ? y[3] : mn;
+                    const uint32_t g4 = good + 4u;
+                    good = (mx < S.lim && mn >= -S.lim) ? (g4 < 64u ? g4 : 64u) : 0u;
+                    wide = live && S.order != 0u && good < S.order;
                 }
     #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) y[ii] = clx_lfinish(y[ii], F);
@@ -923,17 +936,17 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     #pragma unroll
                     for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
                     S.hist[0] = s;
-                    // the careful steps predict in i64 and may leave the proven range: the 24-bit blocks that follow
-                    // range-check only their outputs, so a history value outside the range ends them for good
-                    if (n != 0u && S.order != 0u && !(s < S.lim && s >= -S.lim)) wide = true;
+                    // the careful steps predict in i64 and check nothing: recount
+                    good = (s < S.lim && s >= -S.lim) ? (good < 64u ? good + 1u : 64u) : 0u;
                     ys[ii] = clx_lfinish(s, F);
                 }
+                wide = n != 0u && !r.err && S.order != 0u && good < S.order;
                 const int4 yv = stage[(t0 >> 2) & 3u];
                 y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
             }
-            // once a lane has left the proven range its history may hold values the 24-bit predictor cannot take:
-            // from here on only the general block (which then accumulates in i64) may run
-            if (__any(wide)) no_lean = true;
+            // while a lane's history holds values the 24-bit predictor cannot take, only the general block (which then
+            // accumulates in i64) may run
+            no_lean = __any(wide);
         }
         // ---- output: stage 16 bytes per block, write the row one full 64-byte segment at a time (scattered 16-byte
         //      stores issued microseconds apart reach HBM as partial-line writes: 2.8x write traffic when measured)

@@ -148,6 +148,34 @@ def edge_workload():
     return synth.concat("edges", ws)
 
 
+def range_hop_workload(n=72, bs=1024):
+    """Signals that wander in and out of the range in which the kernels may evaluate the predictor with 24-bit factors
+    (sum|c| * |s| < 2^31; the limit comes from the coefficients, the check is on the data): a loud burst in a quiet
+    signal, staggered from frame to frame so that the lanes of a wave cross the limit at different samples; 24-bit and
+    16-bit, high-precision order-12 / order-32 predictors, all channel assignments."""
+    rng = np.random.default_rng(4242)
+    ws = []
+    t = np.arange(bs)
+    for i in range(n):
+        bps = 24 if i % 3 else 16
+        full = 1 << (bps - 1)
+        loud, quiet = (0.7 * full, 900.0) if bps == 24 else (0.95 * full, 40.0)
+        start = 256 + (5 * i) % 64 + (512 if i % 2 else 0) * (i % 5 == 0)
+        env = np.where((t >= start) & (t < start + 96 + i % 40), loud, quiet)       # one loud burst, elsewhere quiet
+        if i % 9 == 8:
+            env = np.full(bs, quiet)                       # some lanes never leave the range
+        base = env * np.sin(2 * np.pi * (200 + 13 * i) * t / 44100.0) + rng.normal(0, 6.0, bs)
+        chans = [np.clip(np.rint(base * g), -full, full - 1).astype(np.int32) for g in (1.0, 0.55)]
+        ca = (0, 3, 1, 2)[i % 4]
+        channels = 1 if ca == 0 and i % 8 == 0 else 2
+        pcm = np.stack(chans[:channels])[None]
+        fp = synth.FrameParams(ca if channels == 2 else 0, 0, i)
+        for c in range(channels):
+            fp.sf[c] = synth.sf(synth.SF_LPC, 32 if i % 7 == 3 else 12, 15, int(rng.integers(0, 5)))
+        ws.append(synth.encode_frames("h", pcm, channels, bs, bps, [fp]))
+    return synth.concat("range hops", ws)
+
+
 def check_regressions(oracle, backend):
     """Frames that once decoded differently from the oracle on some kernel selection (found by tools/stress_gpu.py)."""
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "*.npy")))

@@ -33,6 +33,10 @@ def test_sim_edges(oracle, sim):
     pc.check_workload(oracle, sim, pc.edge_workload())
 
 
+def test_sim_range_hops(oracle, sim):
+    pc.check_workload(oracle, sim, pc.range_hop_workload())
+
+
 def test_sim_truncations(oracle, sim):
     pc.check_truncations(oracle, sim, n_frames=6, cuts_per_frame=16)
 
@@ -101,3 +105,17 @@ def test_sim_collectives_semantics():
 
 def test_sim_regressions(oracle, sim):
     pc.check_regressions(oracle, sim)
+
+
+def test_sim_range_hops_take_both_predictors(oracle):
+    """The range-hop workload must really cross the limit in the fused lane kernel: 24-bit lean turns before and after the burst,
+    i64 blocks inside it (tier counters compiled into the simulator build only)."""
+    import ctypes as C
+    import simlib
+    w = pc.range_hop_workload()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for i in range(64):
+        stats[i] = 0
+    pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=False)
+    lean, wide = stats[16] + stats[32], stats[36]
+    assert lean > 1000 and wide > 1000, (lean, wide)
