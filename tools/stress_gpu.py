@@ -43,6 +43,42 @@ for si in range(n_seeds):
                         if n_bad >= 8:
                             print("too many mismatches"); sys.exit(1)
     print("seed", seed, "done:", n_all, "decodes,", n_bad, "mismatches", flush=True)
+# whole batches of 4096-sample frames with a quarter of the frames corrupted: the sixteen-sample tiers of the lane kernels,
+# the lanes of a wave leaving them at different samples
+def batch_flips(w, tag, trials):
+    global n_bad, n_all
+    descs = pc.workload_descs(w)
+    heads = [cx.parse_frame_header(w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])])[2].header_bytes for i in range(w.n)]
+    for trial in range(trials):
+        rng = np.random.default_rng(seed0 + 77 * trial)
+        a = w.arena.copy()
+        for i in rng.choice(w.n, size=max(1, w.n // 4), replace=False):
+            for _ in range(int(rng.integers(1, 4))):
+                lo = int(w.offs[i]) * 8 + heads[i] * 8
+                pos = int(rng.integers(lo, (int(w.offs[i]) + int(w.lens[i])) * 8))
+                a[pos >> 3] ^= 0x80 >> (pos & 7)
+        ref = np.zeros(w.pcm.size, dtype=np.int32)
+        r = oracle.decode_batch(a[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, check_crc=False)
+        for name, path in paths:
+            out, res = GpuBackend(ctx, path).decode(a, w.arena_len, descs, w.out_offs, False, fill=0x13131313)
+            n_all += w.n
+            for i in range(w.n):
+                lo = int(w.out_offs[i]); hi = lo + int(descs["n_channels"][i]) * int(descs["block_size"][i])
+                same = (int(res["status"][i]), int(res["msg"][i])) == (int(r["statuses"][i]), int(r["msgs"][i])) and \
+                       (res["status"][i] != 0 or (res["end_bit"][i] == r["end_bits"][i] and np.array_equal(out[lo:hi], ref[lo:hi])))
+                if not same:
+                    n_bad += 1
+                    print("MISMATCH (batch)", tag, name, "trial", trial, "frame", i, "oracle", r["statuses"][i], r["msgs"][i], "product", res["status"][i], res["msg"][i], flush=True)
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.save("gpurun_out/badbatch_%s_%s_%d_%d.npy" % (tag, name, trial, i), a[int(w.offs[i]):int(w.offs[i] + w.lens[i])])
+                    if n_bad >= 8:
+                        print("too many mismatches"); sys.exit(1)
+    print("batch flips", tag, "done:", n_all, "decodes,", n_bad, "mismatches", flush=True)
+
+
+batch_flips(synth.config5_unique(160), "config5", 6)
+batch_flips(synth.config4(96), "config4", 4)
+batch_flips(pc.range_hop_workload(), "hops", 6)
 for n in (257, 1000):
     w = synth.config5_unique(n)
     for name, path in paths:
