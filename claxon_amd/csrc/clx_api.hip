@@ -428,7 +428,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
                                (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits, b->d_dump);
         if (!mark("clx_k_finalize")) return CLX_API_ERROR;
         hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
-                           (const uint32_t*)b->d_errkey, (const uint64_t*)b->d_endbits, (uint32_t)b->n, b->d_results);
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_errkey, (const uint64_t*)b->d_endbits, (uint32_t)b->n, b->d_results);
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
         if (!mark("clx_k_residual")) return CLX_API_ERROR;

@@ -517,6 +517,9 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
             }
         }
     }
+    // the footer is read whether or not it is compared (frame.rs:754; under cfg(fuzzing) only the comparison goes away)
+    if (!h.err && !(fr.flags & 1u) && (uint64_t)(((h.pos - o) + 7u) & ~7u) + 16u > (uint64_t)fr.limit_bits)
+        h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
     if (lane == 0) {
         clx_frame_result r;
         r.status = (int32_t)(h.err >> 16);

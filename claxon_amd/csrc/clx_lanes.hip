@@ -1439,13 +1439,19 @@ void clx_k_lanes2(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 // F: error keys -> clx_frame_result
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(256)
-void clx_k_finalize(const uint32_t* __restrict__ errkey, const uint64_t* __restrict__ end_bits, uint32_t n_frames,
-                    clx_frame_result* __restrict__ results) {
+void clx_k_finalize(const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ errkey, const uint64_t* __restrict__ end_bits,
+                    uint32_t n_frames, clx_frame_result* __restrict__ results) {
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
     if (f >= n_frames) return;
     const uint32_t key = errkey[f];
     clx_frame_result r;
-    if (key == 0xffffffffu) { r.status = CLX_OK; r.msg = CLX_MSG_NONE; r.end_bit = end_bits[f]; }
+    if (key == 0xffffffffu) {
+        r.status = CLX_OK; r.msg = CLX_MSG_NONE; r.end_bit = end_bits[f];
+        // the footer is read whether or not it is compared (frame.rs:754; under cfg(fuzzing) only the comparison goes away)
+        if (!(frames[f].flags & 1u) && ((r.end_bit + 7ull) & ~7ull) + 16ull > (uint64_t)frames[f].limit_bits) {
+            r.status = CLX_IO_ERROR; r.msg = CLX_MSG_UNEXPECTED_EOF;
+        }
+    }
     else { r.status = (int32_t)((key >> 16) & 0xffu); r.msg = key & 0xffffu; r.end_bit = 0; }
     results[f] = r;
 }

@@ -178,7 +178,10 @@ enum {
     CLX_ARENA_ON_DEVICE = 1u << 0,   /* arena is a device pointer (else host; copied H2D) */
     CLX_OUT_ON_DEVICE   = 1u << 1,   /* out is a device pointer (else host; copied D2H)   */
     CLX_VERIFY_CRC16    = 1u << 2,   /* also verify each frame's CRC-16 footer on device
-                                        (frame.rs:752-763); mismatch -> CLX_MSG_FRAME_CRC_MISMATCH */
+                                        (frame.rs:752-763); mismatch -> CLX_MSG_FRAME_CRC_MISMATCH.
+                                        Without it the footer is still read, as the reference does
+                                        under cfg(fuzzing) (frame.rs:754): a frame whose two footer
+                                        bytes lie beyond max_bytes fails with CLX_MSG_UNEXPECTED_EOF */
     /* Kernel path.  Default (neither bit): chosen from the batch shape.
      * WAVES: one wavefront per frame, wave-parallel Rice decode (lowest latency for a few frames).
      * LANES: one lane per subframe, lane-serial fused decode (highest throughput for many frames;

@@ -182,3 +182,23 @@ def check_regressions(oracle, backend):
     assert files
     for p in files:
         assert_same_as_oracle(oracle, backend, np.load(p), False, os.path.basename(p))
+
+
+def check_footer_read_in_batch(oracle, backend):
+    """A corrupted frame whose subframes end inside its last two bytes: the footer read fails (frame.rs:754) even when the
+    CRC is not compared and even though, in a batch, the bytes that follow belong to the next frame and are readable."""
+    bad = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "flip_ends_inside_footer.npy"))
+    good = synth.config3(2)
+    arena = np.concatenate([bad, good.arena])
+    offs = np.concatenate([[0], good.offs + np.uint64(len(bad))]).astype(np.uint64)
+    lens = np.concatenate([[len(bad)], good.lens]).astype(np.uint32)
+    alen = len(bad) + good.arena_len
+    descs, _ = cx.descs_from_offsets(arena[:alen], offs, lens, check_crc=False)
+    out_offs = np.concatenate([[0], good.out_offs + np.uint64(2 * 4096)]).astype(np.uint64)
+    for crc in (False, True):
+        out, res = backend.decode(arena, alen, descs, out_offs, crc, fill=0x21212121)
+        r = oracle.decode_batch(arena[:alen], offs, lens, out=np.zeros(out.size, dtype=np.int32), out_offs=out_offs, check_crc=crc)
+        assert (int(r["statuses"][0]), int(r["msgs"][0])) == (cx.IO_ERROR, MSG["CLX_MSG_UNEXPECTED_EOF"])
+        assert [int(x) for x in res["status"]] == [int(x) for x in r["statuses"]]
+        assert [int(x) for x in res["msg"]] == [int(x) for x in r["msgs"]]
+        assert np.array_equal(out[2 * 4096:2 * 4096 + good.pcm.size], good.pcm)

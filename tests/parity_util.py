@@ -66,10 +66,6 @@ def product_frame_decode(backend, data, check_crc=True, fill=0):
     r = res[0]
     if r["status"] != cx.OK:
         return int(r["status"]), int(r["msg"]), int(r["end_bit"]), None, h
-    if not check_crc:
-        # cfg(fuzzing): the footer is still *read* (frame.rs:754), only not compared
-        if (int(r["end_bit"]) + 7) // 8 + 2 > n:
-            return cx.IO_ERROR, MSG["CLX_MSG_UNEXPECTED_EOF"], int(r["end_bit"]), None, h
     return cx.OK, 0, int(r["end_bit"]), out[:h.block_size * h.n_channels], h
 
 

@@ -37,6 +37,10 @@ def test_gpu_range_hops(oracle, gpu):
     pc.check_workload(oracle, gpu, pc.range_hop_workload())
 
 
+def test_gpu_footer_read_in_batch(oracle, gpu):
+    pc.check_footer_read_in_batch(oracle, gpu)
+
+
 def test_gpu_truncations(oracle, gpu):
     pc.check_truncations(oracle, gpu, n_frames=10, cuts_per_frame=24)
 

@@ -37,6 +37,10 @@ def test_sim_range_hops(oracle, sim):
     pc.check_workload(oracle, sim, pc.range_hop_workload())
 
 
+def test_sim_footer_read_in_batch(oracle, sim):
+    pc.check_footer_read_in_batch(oracle, sim)
+
+
 def test_sim_truncations(oracle, sim):
     pc.check_truncations(oracle, sim, n_frames=6, cuts_per_frame=16)
 

@@ -36,7 +36,7 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
                        errkey.data(), endbits.data(), dump.data());
         }
-        SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, errkey.data(), endbits.data(), (uint32_t)n, results);
+        SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, dev.data(), errkey.data(), endbits.data(), (uint32_t)n, results);
         if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
         return CLX_OK;
     }
