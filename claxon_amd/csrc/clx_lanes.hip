@@ -651,10 +651,12 @@ __device__ __forceinline__ LeanCur clx_lean_begin(const LaneState<OMAX>& S, cons
     }
     return c;
 }
-// N (a multiple of 4) values from register windows of 4; VERB (wave-uniform): some lane reads verbatim fields
-template <int N, bool VERB>
-__device__ __forceinline__ void clx_lean_codes(const uint32_t* ringrow, const LeanKind& K, uint32_t k, uint32_t k1, uint32_t& p, uint32_t& mx,
-                                               uint32_t& pw, int32_t (&X)[N]) {
+// N (a multiple of 4) values from register windows of 4.  MODE (wave-uniform): 0 every live lane reads Rice codes, 1 some
+// repeat a constant, 2 some read verbatim fields -- the masks that let the kinds share one instruction stream cost four
+// instructions per code, which waves of Rice lanes only (nearly all of them) need not pay.
+template <int N, int MODE>
+__device__ __forceinline__ void clx_lean_codes_m(const uint32_t* ringrow, const LeanKind& K, uint32_t k, uint32_t k1, uint32_t& p, uint32_t& mx,
+                                                 uint32_t& pw, int32_t (&X)[N]) {
     const uint32_t kk = k & 31u;
 #pragma unroll
     for (int b4 = 0; b4 < N / 4; ++b4) {
@@ -667,17 +669,35 @@ __device__ __forceinline__ void clx_lean_codes(const uint32_t* ringrow, const Le
             const uint32_t u = (z << kk) | clx_bfe(w.a, 32u - nbr, k);     // (q << k) | r, subframe.rs:337-341
             int32_t x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);            // rice_to_signed (subframe.rs:157-170)
             uint32_t nb = nbr;
-            if (VERB) {                                                    // verbatim rows ride along (subframe.rs:397-415)
+            if (MODE == 2) {                                               // verbatim rows ride along (subframe.rs:397-415)
                 x = K.verb ? ((int32_t)w.a >> K.vsh) : x;
                 nb = K.verb ? K.vbits : nbr;
             }
-            X[4 * b4 + ii] = (int32_t)(((uint32_t)x & K.bitmask) | K.cor);
-            const uint32_t nbx = nbr & K.ricemask;
-            mx = nbx > mx ? nbx : mx;
-            clx_win_skip(w, nb);
-            p += nb & K.bitmask;
+            if (MODE == 0) {
+                X[4 * b4 + ii] = x;
+                mx = nbr > mx ? nbr : mx;
+                clx_win_skip(w, nb);
+                p += nb;
+            } else {
+                X[4 * b4 + ii] = (int32_t)(((uint32_t)x & K.bitmask) | K.cor);
+                const uint32_t nbx = nbr & K.ricemask;
+                mx = nbx > mx ? nbx : mx;
+                clx_win_skip(w, nb);
+                p += nb & K.bitmask;
+            }
         }
     }
+}
+template <int N>
+__device__ __forceinline__ void clx_lean_codes(int mode, const uint32_t* ringrow, const LeanKind& K, uint32_t k, uint32_t k1, uint32_t& p,
+                                               uint32_t& mx, uint32_t& pw, int32_t (&X)[N]) {
+    if (mode == 0)      clx_lean_codes_m<N, 0>(ringrow, K, k, k1, p, mx, pw, X);
+    else if (mode == 1) clx_lean_codes_m<N, 1>(ringrow, K, k, k1, p, mx, pw, X);
+    else                clx_lean_codes_m<N, 2>(ringrow, K, k, k1, p, mx, pw, X);
+}
+// which of them a wave needs (wave-uniform)
+__device__ __forceinline__ int clx_lean_mode(bool on, const LeanKind& K, uint32_t phase) {
+    return __any(on && K.verb) ? 2 : __any(on && phase == 2u) ? 1 : 0;
 }
 
 template <int OMAX>
@@ -726,7 +746,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     int4* const tile = stage - 4 * lane;                 // the wave's 64 x 4 staging slots seen as one tile
     const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
     const LeanKind K = clx_lean_kind<OMAX>(S, h);         // (the prologue is over: no lane changes its kind any more)
-    const bool any_verb = __any(n != 0u && !r.err && K.verb);
+    const int lean_mode = clx_lean_mode(n != 0u && !r.err, K, S.phase);
     for (uint32_t t0 = i0; t0 < nmax; t0 += 4u) {
         if ((t0 & 12u) == 0u && t0 != i0) clx_ring_pump(g, ringrow, r.pos, r.limit);
         const bool live = (n != 0u) && !r.err && t0 < n;
@@ -736,8 +756,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
             LeanCur c = clx_lean_begin<OMAX>(S, ringrow, live, K);
             uint32_t mx = 0, pw = 0;
             int32_t Y[16];
-            if (any_verb) clx_lean_codes<16, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, Y);
-            else          clx_lean_codes<16, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, Y);
+            clx_lean_codes<16>(lean_mode, ringrow, K, c.k, c.k1, c.p, mx, pw, Y);
             int32_t hh[OMAX];
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) hh[j] = S.hist[j];
@@ -797,8 +816,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
             LeanCur c = clx_lean_begin<OMAX>(S, ringrow, live, K);
             uint32_t mx = 0, pw = 0;
             int32_t xs[4];
-            if (any_verb) clx_lean_codes<4, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
-            else          clx_lean_codes<4, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
+            clx_lean_codes<4>(lean_mode, ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
             int32_t hh[OMAX];
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) hh[j] = S.hist[j];
@@ -1148,12 +1166,11 @@ __device__ __forceinline__ void clx_rice_wave(LaneState<32>& S, Ring& g, uint32_
             clx_ring_pump(g, ringrow, r.pos, r.limit);
             const bool live = (n != 0u) && !r.err && tb < n;
             const LeanKind K = clx_lean_kind<32>(S, h);
-            const bool any_verb = __any(live && K.verb);
+            const int lean_mode = clx_lean_mode(live, K, S.phase);
             LeanCur c = clx_lean_begin<32>(S, ringrow, live, K);
             uint32_t mx = 0, pw = 0;
             int32_t X[16];
-            if (any_verb) clx_lean_codes<16, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, X);
-            else          clx_lean_codes<16, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, X);
+            clx_lean_codes<16>(lean_mode, ringrow, K, c.k, c.k1, c.p, mx, pw, X);
             const bool ok16 = !live || ((K.rice ? (S.transitioned && !c.bad && c.pcnt >= 16u && mx <= 32u)
                                                 : K.verb ? true : S.phase == 2u)
                                         && (S.phase == 2u || clx_ring_covered(g, pw, c.p, r.limit)) && tb + 16u <= n);
@@ -1186,11 +1203,10 @@ __device__ __forceinline__ void clx_rice_wave(LaneState<32>& S, Ring& g, uint32_
                 // lean block: see clx_lanes_body -- here without the predictor
                 {
                     const LeanKind K = clx_lean_kind<32>(S, h);
-                    const bool any_verb = __any(live && K.verb);
+                    const int lean_mode = clx_lean_mode(live, K, S.phase);
                     LeanCur c = clx_lean_begin<32>(S, ringrow, live, K);
                     uint32_t mx = 0, pw = 0;
-                    if (any_verb) clx_lean_codes<4, true>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
-                    else          clx_lean_codes<4, false>(ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
+                    clx_lean_codes<4>(lean_mode, ringrow, K, c.k, c.k1, c.p, mx, pw, xs);
                     const bool lean_ok = !live || ((K.rice ? (S.transitioned && !c.bad && c.pcnt >= 4u && mx <= 32u)
                                                            : K.verb ? true : S.phase == 2u)
                                                    && (S.phase == 2u || clx_ring_covered(g, pw, c.p, r.limit)) && t0 + 4u <= n);
