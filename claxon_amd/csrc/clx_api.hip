@@ -1104,19 +1104,21 @@ FlacReader::FlacReader() : impl_(new Impl()) {}
 FlacReader::FlacReader(FlacReader&& o) noexcept : impl_(o.impl_) { o.impl_ = nullptr; }
 FlacReader::~FlacReader() { delete impl_; }
 
-Result<FlacReader> FlacReader::create(clx_ctx* ctx, const uint8_t* data, size_t len) {
+Result<FlacReader> FlacReader::create_ext(clx_ctx* ctx, const uint8_t* data, size_t len, FlacReaderOptions opts) {
     Result<FlacReader> r;
     clx_streaminfo si; size_t off = 0; uint32_t msg = 0;
     clx_tags* tags = nullptr;
-    int st = clx_read_stream_header_ext(data, len, 0, &si, &off, &tags, &msg);
+    const uint32_t o = (opts.metadata_only ? (uint32_t)CLX_OPT_METADATA_ONLY : 0u) | (opts.read_vorbis_comment ? 0u : (uint32_t)CLX_OPT_NO_VORBIS_COMMENT);
+    int st = clx_read_stream_header_ext(data, len, o, &si, &off, &tags, &msg);
     if (st != CLX_OK) { r.is_err = true; r.error = Error::from(st, msg); return r; }
     r.value.impl_->info = si;
     r.value.impl_->tags = tags;
-    r.value.impl_->frames = new FrameReader(ctx, data + off, len - off);
+    if (!opts.metadata_only) r.value.impl_->frames = new FrameReader(ctx, data + off, len - off);
     return r;
 }
+Result<FlacReader> FlacReader::create(clx_ctx* ctx, const uint8_t* data, size_t len) { return create_ext(ctx, data, len, FlacReaderOptions()); }
 
-Result<FlacReader> FlacReader::open(clx_ctx* ctx, const char* path) {
+Result<FlacReader> FlacReader::open_ext(clx_ctx* ctx, const char* path, FlacReaderOptions opts) {
     Result<FlacReader> r;
     FILE* f = std::fopen(path, "rb");
     if (!f) { r.is_err = true; r.error = Error::from(CLX_IO_ERROR, CLX_MSG_NONE); r.error.text = "cannot open file"; return r; }
@@ -1125,8 +1127,9 @@ Result<FlacReader> FlacReader::open(clx_ctx* ctx, const char* path) {
     size_t got;
     while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + got);
     std::fclose(f);
-    return create(ctx, data.data(), data.size());
+    return create_ext(ctx, data.data(), data.size(), opts);
 }
+Result<FlacReader> FlacReader::open(clx_ctx* ctx, const char* path) { return open_ext(ctx, path, FlacReaderOptions()); }
 
 const clx_streaminfo& FlacReader::streaminfo() const { return impl_->info; }
 const clx_tags* FlacReader::raw_tags() const { return impl_->tags; }
@@ -1154,7 +1157,11 @@ std::vector<std::string> FlacReader::get_tag(const char* name) const {
     }
     return out;
 }
-FrameReader& FlacReader::blocks() { return *impl_->frames; }
+FrameReader& FlacReader::blocks() {
+    // lib.rs:367-373 panics with this message
+    if (!impl_->frames) throw std::logic_error("FlacReaderOptions::metadata_only must be false to be able to use blocks()");
+    return *impl_->frames;
+}
 
 }  // namespace claxon
 

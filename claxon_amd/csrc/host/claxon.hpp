@@ -144,6 +144,12 @@ private:
     bool has_failed_ = false;
 };
 
+// Controls what FlacReader reads when it is constructed (lib.rs:100-140).
+struct FlacReaderOptions {
+    bool metadata_only = false;        // stop after the metadata blocks; blocks() / samples() are unavailable (lib.rs:113)
+    bool read_vorbis_comment = true;   // parse the VORBIS_COMMENT block (lib.rs:125)
+};
+
 // A FLAC decoder over a stream held in memory (lib.rs:93-97).
 class FlacReader {
 public:
@@ -153,13 +159,16 @@ public:
     ~FlacReader();
     static Result<FlacReader> open(clx_ctx* ctx, const char* path);                      // lib.rs:455
     static Result<FlacReader> create(clx_ctx* ctx, const uint8_t* data, size_t len);     // FlacReader::new, lib.rs:217
+    static Result<FlacReader> open_ext(clx_ctx* ctx, const char* path, FlacReaderOptions opts);                       // lib.rs:462
+    static Result<FlacReader> create_ext(clx_ctx* ctx, const uint8_t* data, size_t len, FlacReaderOptions opts);      // FlacReader::new_ext, lib.rs:227
     const clx_streaminfo& streaminfo() const;                                            // lib.rs:312
     bool vendor(std::string* out) const;                                                 // lib.rs:321 (false: no Vorbis comment block)
     std::vector<std::pair<std::string, std::string>> tags() const;                       // lib.rs:335 (name, value) in stream order
     std::vector<std::string> get_tag(const char* name) const;                            // lib.rs:356 ASCII-case-insensitive, all matches
     const clx_tags* raw_tags() const;
-    FrameReader& blocks();                                                               // lib.rs:367
-    FlacSamples samples() { return FlacSamples(blocks()); }                              // lib.rs:396
+    // lib.rs:367 / 396; both throw std::logic_error where the reference panics: the reader was made with metadata_only
+    FrameReader& blocks();
+    FlacSamples samples() { return FlacSamples(blocks()); }
     FlacReader();
 private:
     friend struct Result<FlacReader>;
