@@ -4,16 +4,19 @@
 //                    no output) to find the bit at which each later subframe starts -- subframe c+1
 //                    begins where subframe c ends, there is no length field (frame.rs:705-742).
 //   D  clx_k_lanes   one lane per subframe: subframe header, warm-up, LPC coefficients, Rice/Rice2
-//                    residual decode, fixed/LPC synthesis, wasted-bits shift and stereo decorrelation
-//                    (partner channel in lane^1, exchanged with DPP) fused in one pass; each lane streams
-//                    its own output row with 16-byte stores.  No intermediate residual buffer in HBM.
-//   F  clx_k_finalize  folds the per-frame error keys into clx_frame_result.
+//      (_hi: orders   residual decode, fixed/LPC synthesis, wasted-bits shift and stereo decorrelation
+//       above 12)     (partner channel in lane^1, exchanged with DPP) fused in one pass; sixteen samples per
+//                    turn leave as 64-byte row segments.  No intermediate residual buffer in HBM.
+//   D2 clx_k_lanes2  the same work split over a Rice wave and a predictor/finisher wave per 64 subframes
+//                    (tiles handed over through LDS): half the serial chain per wave, for batches that
+//                    leave most SIMDs without a wave.
+//   F  clx_k_finalize  folds the per-frame error keys into clx_frame_result (and performs the footer read).
 //
-// Why two paths: a wavefront issues at most one instruction every ~4 cycles, and the wave-parallel
-// decoder (clx_kernels.hip) spends ~10 wave-instructions per code to resolve code boundaries
-// speculatively; decoding serially in each lane costs ~0.7 wave-instructions per code.  With
-// thousands of frames in flight the lane-serial form wins by a wide margin; with a handful of
-// frames the wave-parallel form has the lower latency.  clx_batch_run picks by batch shape.
+// Why two paths: a lone wavefront issues one instruction every ~6 cycles, and the wave-parallel
+// decoder (clx_kernels.hip) spends ~3.4 wave-instructions per code to resolve code boundaries
+// speculatively; decoding serially in each lane costs ~0.6 wave-instructions per code.  With
+// tens of thousands of subframes in flight the lane-serial form wins by a wide margin; with fewer
+// the wave-parallel form has the lower latency.  clx_batch_run picks by batch shape.
 //
 // Both kernels mirror the reference's call sequence read for read (subframe.rs:29-91, 184-228,
 // 236-415, 492-516, 651-721), so the first error in stream order is the one reported.
