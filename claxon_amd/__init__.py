@@ -16,7 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libclaxon_hip.so")
+# CLAXON_HIP_LIB selects another build of the same library (e.g. one compiled with -DCLX_TIMELINE for tools/timeline.py)
+LIB_PATH = os.environ.get("CLAXON_HIP_LIB") or os.path.join(_HERE, "libclaxon_hip.so")
 
 OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
 CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)

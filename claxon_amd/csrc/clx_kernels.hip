@@ -34,6 +34,7 @@
 // frame's first byte, so every global access is a naturally aligned dword / dwordx4.
 // ------------------------------------------------------------------------------------------------
 struct K1Lds {
+    uint32_t Wfront[4];        // never written: lets the extraction read the dword in front of W[0] (its bits are masked off)
     uint32_t W[CLX_NW + 4];
     // The two phases of a span never overlap: first the exit-state tables resolve where every lane's chunk is entered,
     // then the positions of the codes are listed.  4.4 KiB per wave in all = 8 waves per SIMD.
@@ -47,6 +48,11 @@ struct K1Lds {
         } t;
         uint16_t P[CLX_NPOS];      // P[i]: bit position (relative to the span) where code i of the span starts
     } u;
+    // lut[s * 16 + nib]: what four stream bits `nib` (MSB first) do to a walk that meets them in state s, for the Rice
+    // parameter of the partition being decoded (k <= 14: at most 16 states; rebuilt when k changes).  High nibble: the
+    // state behind the four bits; low nibble: which of the four positions are code starts (bit i = the i-th bit).
+    // Any byte is a valid entry at all times, so a chain of look-ups never leaves the table.
+    uint8_t lut[256];
 };
 
 struct BitSrc {
@@ -173,18 +179,41 @@ __device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint3
 // output indices; (4) each lane extracts its codes (clz for the unary part, shift for the remainder)
 // into LDS, from where they are written to HBM coalesced.
 __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32_t k, uint32_t count,
-                                       int32_t* dst, uint32_t limit, uint32_t* err, int lane CLX_TL_PH_PARAM) {
+                                       int32_t* dst, uint32_t limit, uint32_t* err, uint32_t& lut_k, int lane CLX_TL_PH_PARAM) {
     // the cursor and the partition's shape are the same in every lane: keep them (and all that follows from them: chunk
     // width, window tests, loop control) on the scalar unit -- this kernel is bound by VALU issue slots
     pos = clx_uniform(pos); k = clx_uniform(k); count = clx_uniform(count); limit = clx_uniform(limit);
     const uint32_t SC = k + 1u, ns = k + 2u;
     CLX_TL_PHASE(5);                       // everything outside the residual decode: headers, warm-up, descriptors
+    // Transition table of the code's bit automaton, four bits at a time: a state m in [1,k] just counts a remainder
+    // bit down; at a code start (0) or inside a run (SC) a one ends the run and leaves k remainder bits, a zero
+    // continues it.  With it the exit state of a chunk for one entry state is B/4 dependent LDS look-ups instead of a
+    // walk of shift / count-leading-zeros / add steps per code -- this kernel is bound by VALU issue slots.
+    const bool use_lut = k <= 14u;                           // wave-uniform; Rice2 parameters above 14 keep the walks
+    if (use_lut && lut_k != k) {
+        const uint32_t nent = ns << 4;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+        for (uint32_t e = (uint32_t)lane; e < nent; e += 64u) {
+            uint32_t st = e >> 4, starts = 0;
+            const uint32_t nib = e & 15u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (st == 0u) starts |= 1u << i;
+                const bool rem = (st - 1u) < k;              // 1 <= st <= k
+                st = rem ? st - 1u : (((nib >> (3 - i)) & 1u) ? k : SC);
+            }
+            L.lut[e] = (uint8_t)((st << 4) | starts);
+        }
+        lut_k = k;
+        __syncthreads();
+    }
     uint32_t done = 0;
     while (done < count) {
         const uint32_t remaining = count - done;
         // chunk width: sized so that one span of 64 chunks usually covers the whole partition (a code with an
         // optimal parameter averages ~k+2.2 bits; k+3 leaves headroom) and every lane has work
         uint32_t B = (remaining * (k + 3u) + 63u) >> 6;
+        B = (B + 3u) & ~3u;                                 // whole nibbles (the transition table's step)
         B = B < 4u ? 4u : B > 32u ? 32u : B;
         if (k == 0u && B > 16u) B = 16u;                    // at most 1024 <= CLX_NPOS codes per span
         clx_window_ensure(L, b, pos, 64u * B + 64u, lane);
@@ -206,6 +235,33 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         // (1) exit-state tables
         const bool sent = B < 32u;                           // wave-uniform
         const uint32_t cs = sent ? (c | (0x80000000u >> B)) : c;
+        if (use_lut) {
+            const uint32_t nb = B >> 2;
+            uint32_t ex0 = 0;
+            for (uint32_t g = 0; 4u * g < ns; ++g) {
+                // four entry states at a time, each held as a table entry (state in the high nibble); states above k are
+                // not walked: SC takes state 0's result, the rest are never read
+                uint32_t s0 = (4u * g) << 4, s1 = s0 + 16u, s2 = s0 + 32u, s3 = s0 + 48u;
+                const bool a1 = 4u * g + 1u <= k, a2 = 4u * g + 2u <= k, a3 = 4u * g + 3u <= k;       // wave-uniform
+                if (4u * g <= k) {
+#pragma unroll 1
+                    for (uint32_t j = 0; j < nb; ++j) {
+                        const uint32_t nib = (c >> (28u - 4u * j)) & 15u;
+                        s0 = L.lut[(s0 & 0xf0u) | nib];
+                        if (a1) s1 = L.lut[(s1 & 0xf0u) | nib];
+                        if (a2) s2 = L.lut[(s2 & 0xf0u) | nib];
+                        if (a3) s3 = L.lut[(s3 & 0xf0u) | nib];
+                    }
+                }
+                if (g == 0u) ex0 = s0;
+                // entering inside a run (SC) walks exactly like entering at a code start (state 0)
+                if (4u * g == SC) s0 = ex0;
+                if (4u * g + 1u == SC) s1 = ex0;
+                if (4u * g + 2u == SC) s2 = ex0;
+                if (4u * g + 3u == SC) s3 = ex0;
+                *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4u * g]) = ((s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) >> 4) & 0x0f0f0f0fu;
+            }
+        } else {
         const uint32_t ex0 = sent ? clx_chunk_exit<true>(cs, B, k, 0u) : clx_chunk_exit<false>(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
             uint32_t packed = 0;
@@ -218,6 +274,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                 packed |= ex << (8u * j);
             }
             *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4u * g]) = packed;     // states 4g .. 4g+3 (little endian)
+        }
         }
         __syncthreads();
         CLX_TL_PHASE(1);                   // exit tables
@@ -253,7 +310,16 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         CLX_TL_PHASE(2);                   // three-level walk
         // (3) starts in my chunk
         uint32_t S = 0;
-        {
+        if (use_lut) {
+            // the same table, walked once from the true entry state: every step hands over the four start flags of its bits
+            uint32_t v = my_entry << 4;
+#pragma unroll 1
+            for (uint32_t j = 0; j < (B >> 2); ++j) {
+                v = L.lut[(v & 0xf0u) | ((c >> (28u - 4u * j)) & 15u)];
+                S = clx_alignbit(v, S, 4u);                  // (S >> 4) | (flags << 28)
+            }
+            S >>= (32u - B) & 31u;
+        } else {
             uint32_t p = (my_entry == SC) ? 0u : my_entry;
             if (sent) {
                 const uint32_t k1 = k + 1u;
@@ -311,6 +377,22 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         // q = start(i+1) - start(i) - 1 - k zeros and its k remainder bits end where code i+1 starts
         const uint32_t end_rel = newpos - pos;
         const bool far = end_rel > 64u * B + 32u;            // the span's last code runs past what the window is known to hold
+        if (!far) {
+            // every remainder lies inside the window: its k bits are the low bits of the 64-bit pair (dword in front of the
+            // one holding its last bit, that dword) shifted right until that last bit is bit 0 -- one v_alignbit, one v_bfe
+            const uint32_t bias = pos - 1u - 32u * b.win_dw;                                   // wave-uniform
+            for (uint32_t i = (uint32_t)lane; i < ntake; i += 64u) {
+                const uint32_t s = L.u.P[i];
+                const uint32_t nx = L.u.P[i + 1u];           // (one past the list for the last code: any value, not used)
+                const uint32_t e = (i + 1u < ntake) ? nx : end_rel;
+                const uint32_t q = e - s - 1u - k;
+                const uint32_t last = e + bias;              // window-relative position of the code's last bit
+                const uint32_t* w = &L.W[last >> 5];
+                const uint32_t r = clx_bfe(clx_alignbit(w[-1], w[0], ~last), 0u, k);         // k = 0: no bits, r = 0
+                const uint32_t u = (q << k) | r;             // u32 wrapping shift, subframe.rs:340
+                dst[done + i] = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                       // rice_to_signed, subframe.rs:157-170
+            }
+        } else
         for (uint32_t i = (uint32_t)lane; i < ntake; i += 64u) {
             const uint32_t s = L.u.P[i];
             const uint32_t e = (i + 1u < ntake) ? (uint32_t)L.u.P[i + 1u] : end_rel;
@@ -318,7 +400,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             uint32_t r = 0;
             if (k != 0u) {
                 const uint32_t at = pos + e - k;
-                const uint32_t v = (far && i + 1u == ntake) ? clx_peek32(L, b, at) : clx_peek32_win(L, b, at);
+                const uint32_t v = (i + 1u == ntake) ? clx_peek32(L, b, at) : clx_peek32_win(L, b, at);
                 r = v >> (32u - k);
             }
             const uint32_t u = (q << k) | r;                 // u32 wrapping shift, subframe.rs:340
@@ -346,7 +428,7 @@ __device__ __forceinline__ bool clx_hdr_bits(const K1Lds& L, const BitSrc& b, Hd
     return true;
 }
 
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8)))
 void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                     const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
                     int32_t* __restrict__ out, clx_sf_desc* __restrict__ sfd,
@@ -372,6 +454,8 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     h.pos = o + 8u * (uint32_t)fr.header_bytes;
     h.err = CLX_ERR_NONE;
     if (h.pos > h.limit) h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    reinterpret_cast<uint32_t*>(L.lut)[lane] = 0u;                     // every byte of the table is a valid state from the start
+    uint32_t lut_k = 0xffffffffu;                                      // the Rice parameter the table is built for: none yet
     clx_window_load(L, b, h.pos < h.limit ? h.pos : o, lane);
 
     const uint32_t bs = fr.block_size;
@@ -483,7 +567,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                 if (!clx_hdr_bits(L, b, h, rice2 ? 5u : 4u, &v)) break;
                 if (v == (rice2 ? 31u : 15u)) { h.err = CLX_MKERR(CLX_UNSUPPORTED, CLX_MSG_UNENCODED_BINARY); break; }
                 uint32_t perr = CLX_ERR_NONE;
-                h.pos = clx_rice_partition(L, b, h.pos, v, len, chan + start, h.limit, &perr, lane CLX_TL_PH_ARG);
+                h.pos = clx_rice_partition(L, b, h.pos, v, len, chan + start, h.limit, &perr, lut_k, lane CLX_TL_PH_ARG);
                 if (perr != CLX_ERR_NONE) { h.err = perr; break; }
                 start += len;
                 len = per;
