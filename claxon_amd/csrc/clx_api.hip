@@ -432,7 +432,8 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
         if (!mark("clx_k_residual")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), 0, stream,
+        static const unsigned k1_pad = [] { const char* e = std::getenv("CLX_K1_LDS_PAD"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
+        hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), k1_pad, stream,
                            d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
         // K2: the two-wave (latency) build while the groups of 64 rows are few, the one-wave (throughput) build beyond
         const unsigned groups = (unsigned)((b->n_slots + 63) / 64);

@@ -53,6 +53,8 @@ struct K1Lds {
     // state behind the four bits; low nibble: which of the four positions are code starts (bit i = the i-th bit).
     // Any byte is a valid entry at all times, so a chain of look-ups never leaves the table.
     uint8_t lut[256];
+    uint8_t gent[8];           // entry state of each group of 8 chunks / of each chunk: every lane writes the entries of the
+    uint8_t ent[64];           // chains it walks (lanes of a group walk the same chain) and reads back its own
 };
 
 struct BitSrc {
@@ -235,32 +237,50 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         // (1) exit-state tables
         const bool sent = B < 32u;                           // wave-uniform
         const uint32_t cs = sent ? (c | (0x80000000u >> B)) : c;
+        uint32_t my_entry;
         if (use_lut) {
             const uint32_t nb = B >> 2;
-            uint32_t ex0 = 0;
-            for (uint32_t g = 0; 4u * g < ns; ++g) {
-                // four entry states at a time, each held as a table entry (state in the high nibble); states above k are
-                // not walked: SC takes state 0's result, the rest are never read
+            // The chunk's exit states stay in registers, a nibble per entry state (xlo: states 0-7, xhi: 8-15), as the
+            // difference from state 0's exit: nibbles of states that are not walked (SC, unused) then read as state 0's.
+            uint32_t xlo = 0, xhi = 0, pat = 0, differs = 0;
+            for (uint32_t g = 0; 4u * g <= k; ++g) {
+                // four entry states at a time, each held as a table entry (state in the high nibble).  The last group may
+                // reach past state k: those rows hold stale but valid entries, their results are masked off below.
                 uint32_t s0 = (4u * g) << 4, s1 = s0 + 16u, s2 = s0 + 32u, s3 = s0 + 48u;
-                const bool a1 = 4u * g + 1u <= k, a2 = 4u * g + 2u <= k, a3 = 4u * g + 3u <= k;       // wave-uniform
-                if (4u * g <= k) {
 #pragma unroll 1
-                    for (uint32_t j = 0; j < nb; ++j) {
-                        const uint32_t nib = (c >> (28u - 4u * j)) & 15u;
-                        s0 = L.lut[(s0 & 0xf0u) | nib];
-                        if (a1) s1 = L.lut[(s1 & 0xf0u) | nib];
-                        if (a2) s2 = L.lut[(s2 & 0xf0u) | nib];
-                        if (a3) s3 = L.lut[(s3 & 0xf0u) | nib];
-                    }
+                for (uint32_t j = 0; j < nb; ++j) {
+                    const uint32_t nib = (c >> (28u - 4u * j)) & 15u;
+                    s0 = L.lut[(s0 & 0xf0u) | nib];
+                    s1 = L.lut[(s1 & 0xf0u) | nib];
+                    s2 = L.lut[(s2 & 0xf0u) | nib];
+                    s3 = L.lut[(s3 & 0xf0u) | nib];
                 }
-                if (g == 0u) ex0 = s0;
-                // entering inside a run (SC) walks exactly like entering at a code start (state 0)
-                if (4u * g == SC) s0 = ex0;
-                if (4u * g + 1u == SC) s1 = ex0;
-                if (4u * g + 2u == SC) s2 = ex0;
-                if (4u * g + 3u == SC) s3 = ex0;
-                *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4u * g]) = ((s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) >> 4) & 0x0f0f0f0fu;
+                if (g == 0u) { pat = (s0 >> 4) * 0x11111111u; xlo = xhi = pat; }
+                // the four exit states, squeezed from the high nibbles of four bytes into four adjacent nibbles
+                uint32_t q = ((s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) >> 4) & 0x0f0f0f0fu;
+                q = (q | (q >> 4)) & 0x00ff00ffu;
+                q = (q | (q >> 8)) & 0xffffu;
+                const uint32_t nvalid = k + 1u - 4u * g;                                    // states 4g .. k (wave-uniform)
+                const uint32_t vmask = nvalid >= 4u ? 0xffffu : (0xffffu >> (16u - 4u * nvalid));
+                const uint32_t d = ((q ^ pat) & vmask) << ((16u * g) & 31u);                // nibble of state 4g in xlo / xhi
+                if (g < 2u) xlo ^= d; else xhi ^= d;
+                differs |= d;
             }
+            CLX_TL_PHASE(1);               // exit tables
+            // (2) entry states.  Rice codes resynchronise within a few codes, so for most chunks every entry state leads to
+            // the same exit state: such a chunk tells its successor where it starts without knowing its own entry state.
+            // What is known is handed to the next lane (DPP wave shift) until every lane knows its entry state: one round
+            // plus one per chunk of the longest run of chunks whose exit does depend on their entry -- no LDS traffic.
+            uint32_t ent = (lane == 0) ? 0u : 0xffu;         // a span always begins at a code start; 0xff: not known yet
+            uint32_t outv = (differs == 0u) ? (pat & 15u) : 0xffu;
+            for (;;) {
+                const uint32_t cand = (uint32_t)(((((uint64_t)xhi) << 32) | xlo) >> ((ent & 15u) << 2)) & 15u;
+                if (outv == 0xffu && ent != 0xffu) outv = cand;
+                const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)outv, 0x138, 0xF, 0xF, true);   // wave_shr:1
+                if (ent == 0xffu) ent = pv;                  // (lane 0 never takes this)
+                if (__all(ent != 0xffu)) break;
+            }
+            my_entry = ent;
         } else {
         const uint32_t ex0 = sent ? clx_chunk_exit<true>(cs, B, k, 0u) : clx_chunk_exit<false>(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
@@ -274,7 +294,6 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                 packed |= ex << (8u * j);
             }
             *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4u * g]) = packed;     // states 4g .. 4g+3 (little endian)
-        }
         }
         __syncthreads();
         CLX_TL_PHASE(1);                   // exit tables
@@ -291,23 +310,23 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         __syncthreads();
         // (2b) across groups (on the scalar unit: the eight group entry states are packed into two registers, every
         // lane picks its group's byte), (2c) inside each group
-        uint32_t my_entry = 0;
+        // Both walks are chains of LDS look-ups whose address is the previous result; the state in front of every step is
+        // dropped into LDS (no VALU work) and each lane picks up the one that is its own afterwards.
         {
-            uint32_t m = 0, lo = 0, hi = 0;                  // a span always begins at a code start
+            uint32_t m = 0;                                  // a span always begins at a code start
 #pragma unroll
-            for (uint32_t g = 0; g < 8; ++g) {
-                if (g < 4u) lo |= m << (8u * g); else hi |= m << (8u * (g - 4u));
-                m = clx_uniform((uint32_t)L.u.t.gtab[g][m]);
-            }
+            for (uint32_t g = 0; g < 8; ++g) { L.gent[g] = (uint8_t)m; m = L.u.t.gtab[g][m]; }
             const uint32_t g8 = (uint32_t)lane >> 3;
-            m = (((g8 & 4u) ? hi : lo) >> (8u * (g8 & 3u))) & 0xffu;
+            m = L.gent[g8];
 #pragma unroll
             for (uint32_t i = 0; i < 8; ++i) {
-                if (((uint32_t)lane & 7u) == i) my_entry = m;
-                m = L.u.t.tab[g8 * 8u + i][m];
+                L.ent[g8 * 8u + i] = (uint8_t)m;
+                if (i < 7u) m = L.u.t.tab[g8 * 8u + i][m];
             }
+            my_entry = L.ent[lane];
         }
-        CLX_TL_PHASE(2);                   // three-level walk
+        }
+        CLX_TL_PHASE(2);                   // entry states
         // (3) starts in my chunk
         uint32_t S = 0;
         if (use_lut) {
@@ -377,14 +396,16 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         // q = start(i+1) - start(i) - 1 - k zeros and its k remainder bits end where code i+1 starts
         const uint32_t end_rel = newpos - pos;
         const bool far = end_rel > 64u * B + 32u;            // the span's last code runs past what the window is known to hold
+        // the list ends with the end of the last taken code (already there when codes were left over: the first of those
+        // starts at it); every lane writes the same value and reads only after its own write
+        if (total <= remaining) L.u.P[ntake] = (uint16_t)end_rel;
         if (!far) {
             // every remainder lies inside the window: its k bits are the low bits of the 64-bit pair (dword in front of the
             // one holding its last bit, that dword) shifted right until that last bit is bit 0 -- one v_alignbit, one v_bfe
             const uint32_t bias = pos - 1u - 32u * b.win_dw;                                   // wave-uniform
             for (uint32_t i = (uint32_t)lane; i < ntake; i += 64u) {
                 const uint32_t s = L.u.P[i];
-                const uint32_t nx = L.u.P[i + 1u];           // (one past the list for the last code: any value, not used)
-                const uint32_t e = (i + 1u < ntake) ? nx : end_rel;
+                const uint32_t e = L.u.P[i + 1u];
                 const uint32_t q = e - s - 1u - k;
                 const uint32_t last = e + bias;              // window-relative position of the code's last bit
                 const uint32_t* w = &L.W[last >> 5];

@@ -207,6 +207,7 @@ static int update_dpp_(int line, int old, int src, int dpp_ctrl, int row_mask, i
     int from = -1;                                       // source lane, -1: none
     if (dpp_ctrl >= 0 && dpp_ctrl <= 0xff) from = (lane & ~3) | ((dpp_ctrl >> (2 * (lane & 3))) & 3);
     else if (dpp_ctrl >= 0x111 && dpp_ctrl <= 0x11f) { const int n = dpp_ctrl - 0x110; from = (lane & 15) >= n ? lane - n : -1; }
+    else if (dpp_ctrl == 0x138) from = lane - 1;                                    // wave_shr:1 (GFX9)
     else if (dpp_ctrl == 0x142) from = (lane >= 16) ? ((lane & ~15) - 1) : -1;
     else if (dpp_ctrl == 0x143) from = (lane >= 32) ? 31 : -1;
     else die("this DPP control is not simulated");
