@@ -334,13 +334,14 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     }
     for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
     // path: explicit flag, else by batch shape -- the lane-serial kernels need many independent subframes to fill
-    // the machine (their duration is one lane's serial chain: ~0.72 ms for 4096-sample subframes however few there
-    // are, until every SIMD has a wave), the wave-per-frame kernels scale with the batch (0.53 ms per 10k stereo
+    // the machine (their duration is one lane's serial chain: ~0.7-0.9 ms for 4096-sample subframes however few there
+    // are, until every SIMD has a wave), the wave-per-frame kernels scale with the batch (0.44 ms per 10k stereo
     // frames).  Measured on MI355X, BASELINE configs[2] frames (tools/sweep_paths.py), ms for
-    // waves / lanes two-wave build / lanes fused build: 20k subframes 0.54 / 0.72 / 0.90; 32k 0.71 / 0.72 / 0.90;
-    // 48k 1.08 / 1.20 / 0.96; 64k 1.45 / 1.22 / 1.01; 128k 2.58 / 2.16 / 1.34.  On frames of mixed shapes and higher
-    // bit rates (synth.config5) the lane kernels are ahead already at 32k subframes: 1.44 / 1.17 / 0.99.
-    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 32000);
+    // waves / lanes two-wave build / lanes fused build: 32k subframes 0.58 / 0.71 / 0.87; 40k 0.77 / 1.17 / 0.92;
+    // 48k 0.85 / 1.17 / 0.93; 64k 1.08 / 1.18 / 0.97 -- the curves cross near 54k subframes.  Frames of mixed shapes and
+    // higher bit rates (synth.config5) cost the wave path more per frame than the lane path, so the switch sits a
+    // little below that.
+    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 48000);
     {   // where stores that fall outside a row go (K2 and D2 keep their store instructions unconditional)
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }

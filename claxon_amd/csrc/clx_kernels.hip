@@ -57,6 +57,29 @@ struct K1Lds {
     uint8_t ent[64];           // chains it walks (lanes of a group walk the same chain) and reads back its own
 };
 
+// The transition tables of K1Lds::lut for the Rice parameters that use them (k <= CLX_LUT_KMAX), generated at compile time
+// and kept in constant memory: switching the LDS copy to another parameter is one 4-byte load + store in 28 lanes.
+#define CLX_LUT_KMAX 5u
+struct K1LutRom { uint32_t w[CLX_LUT_KMAX + 1u][32]; };
+constexpr K1LutRom clx_make_lut_rom() {
+    K1LutRom r{};
+    for (uint32_t k = 0; k <= CLX_LUT_KMAX; ++k) {
+        const uint32_t SC = k + 1u;
+        for (uint32_t e = 0; e < (k + 2u) * 16u; ++e) {
+            uint32_t st = e >> 4, starts = 0;
+            const uint32_t nib = e & 15u;
+            for (uint32_t i = 0; i < 4u; ++i) {
+                if (st == 0u) starts |= 1u << i;                                   // a code starts at this bit
+                const bool rem = st >= 1u && st <= k;                              // a remainder bit: count it down
+                st = rem ? st - 1u : (((nib >> (3u - i)) & 1u) ? k : SC);          // a one ends the run, a zero continues it
+            }
+            r.w[k][e >> 2] |= ((st << 4) | starts) << (8u * (e & 3u));
+        }
+    }
+    return r;
+}
+__constant__ K1LutRom clx_lut_rom = clx_make_lut_rom();
+
 struct BitSrc {
     const uint32_t* origin;    // arena + (byte_off & ~15)
     uint32_t avail_dw;         // dwords readable from origin (arena allocation is padded to 16 B)
@@ -191,21 +214,9 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
     // bit down; at a code start (0) or inside a run (SC) a one ends the run and leaves k remainder bits, a zero
     // continues it.  With it the exit state of a chunk for one entry state is B/4 dependent LDS look-ups instead of a
     // walk of shift / count-leading-zeros / add steps per code -- this kernel is bound by VALU issue slots.
-    const bool use_lut = k <= 14u;                           // wave-uniform; Rice2 parameters above 14 keep the walks
+    const bool use_lut = k <= CLX_LUT_KMAX;                  // wave-uniform.  Longer codes: few per chunk, the walks are short
     if (use_lut && lut_k != k) {
-        const uint32_t nent = ns << 4;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-        for (uint32_t e = (uint32_t)lane; e < nent; e += 64u) {
-            uint32_t st = e >> 4, starts = 0;
-            const uint32_t nib = e & 15u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (st == 0u) starts |= 1u << i;
-                const bool rem = (st - 1u) < k;              // 1 <= st <= k
-                st = rem ? st - 1u : (((nib >> (3 - i)) & 1u) ? k : SC);
-            }
-            L.lut[e] = (uint8_t)((st << 4) | starts);
-        }
+        if ((uint32_t)lane < 4u * ns) reinterpret_cast<uint32_t*>(L.lut)[lane] = clx_lut_rom.w[k][lane];
         lut_k = k;
         __syncthreads();
     }
@@ -215,7 +226,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         // chunk width: sized so that one span of 64 chunks usually covers the whole partition (a code with an
         // optimal parameter averages ~k+2.2 bits; k+3 leaves headroom) and every lane has work
         uint32_t B = (remaining * (k + 3u) + 63u) >> 6;
-        B = (B + 3u) & ~3u;                                 // whole nibbles (the transition table's step)
+        if (use_lut) B = (B + 3u) & ~3u;                    // whole nibbles (the transition table's step)
         B = B < 4u ? 4u : B > 32u ? 32u : B;
         if (k == 0u && B > 16u) B = 16u;                    // at most 1024 <= CLX_NPOS codes per span
         clx_window_ensure(L, b, pos, 64u * B + 64u, lane);
@@ -240,9 +251,10 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         uint32_t my_entry;
         if (use_lut) {
             const uint32_t nb = B >> 2;
-            // The chunk's exit states stay in registers, a nibble per entry state (xlo: states 0-7, xhi: 8-15), as the
-            // difference from state 0's exit: nibbles of states that are not walked (SC, unused) then read as state 0's.
-            uint32_t xlo = 0, xhi = 0, pat = 0, differs = 0;
+            // The chunk's exit states stay in a register, a nibble per entry state, as the difference from state 0's
+            // exit: nibbles of states that are not walked (SC, unused) then read as state 0's.
+            static_assert(CLX_LUT_KMAX <= 6u, "the exit states of a chunk are kept in one register: eight nibbles");
+            uint32_t xlo = 0, pat = 0, differs = 0;
             for (uint32_t g = 0; 4u * g <= k; ++g) {
                 // four entry states at a time, each held as a table entry (state in the high nibble).  The last group may
                 // reach past state k: those rows hold stale but valid entries, their results are masked off below.
@@ -255,15 +267,15 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
                     s2 = L.lut[(s2 & 0xf0u) | nib];
                     s3 = L.lut[(s3 & 0xf0u) | nib];
                 }
-                if (g == 0u) { pat = (s0 >> 4) * 0x11111111u; xlo = xhi = pat; }
+                if (g == 0u) { pat = (s0 >> 4) * 0x11111111u; xlo = pat; }
                 // the four exit states, squeezed from the high nibbles of four bytes into four adjacent nibbles
                 uint32_t q = ((s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) >> 4) & 0x0f0f0f0fu;
                 q = (q | (q >> 4)) & 0x00ff00ffu;
                 q = (q | (q >> 8)) & 0xffffu;
                 const uint32_t nvalid = k + 1u - 4u * g;                                    // states 4g .. k (wave-uniform)
                 const uint32_t vmask = nvalid >= 4u ? 0xffffu : (0xffffu >> (16u - 4u * nvalid));
-                const uint32_t d = ((q ^ pat) & vmask) << ((16u * g) & 31u);                // nibble of state 4g in xlo / xhi
-                if (g < 2u) xlo ^= d; else xhi ^= d;
+                const uint32_t d = ((q ^ pat) & vmask) << (16u * g);                        // nibble of state 4g
+                xlo ^= d;
                 differs |= d;
             }
             CLX_TL_PHASE(1);               // exit tables
@@ -274,7 +286,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             uint32_t ent = (lane == 0) ? 0u : 0xffu;         // a span always begins at a code start; 0xff: not known yet
             uint32_t outv = (differs == 0u) ? (pat & 15u) : 0xffu;
             for (;;) {
-                const uint32_t cand = (uint32_t)(((((uint64_t)xhi) << 32) | xlo) >> ((ent & 15u) << 2)) & 15u;
+                const uint32_t cand = (xlo >> ((ent & 7u) << 2)) & 15u;
                 if (outv == 0xffu && ent != 0xffu) outv = cand;
                 const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)outv, 0x138, 0xF, 0xF, true);   // wave_shr:1
                 if (ent == 0xffu) ent = pv;                  // (lane 0 never takes this)

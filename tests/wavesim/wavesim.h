@@ -20,6 +20,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
+#define __constant__ static const
 #define __launch_bounds__(...)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
