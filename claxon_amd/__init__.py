@@ -56,6 +56,15 @@ class StreamInfo(C.Structure):
                 ("samples", C.c_uint64), ("md5sum", C.c_uint8 * 16)]
 
 
+class MetadataBlock(C.Structure):
+    """clx_metadata_block (metadata::MetadataBlock, metadata.rs:104-131)"""
+    _fields_ = [("kind", C.c_uint32), ("length", C.c_uint32), ("streaminfo", StreamInfo), ("application_id", C.c_uint32),
+                ("application_data", C.c_void_p), ("application_len", C.c_size_t), ("tags", C.c_void_p)]
+
+
+BLOCK_STREAMINFO, BLOCK_PADDING, BLOCK_APPLICATION, BLOCK_VORBIS_COMMENT, BLOCK_RESERVED = 0, 1, 2, 4, 126
+
+
 class BlockInfo(C.Structure):
     _fields_ = [("time", C.c_uint64), ("block_size", C.c_uint32), ("channels", C.c_uint32)]
 
@@ -78,6 +87,7 @@ EXPORTS = [
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
     "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
     "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames", "clx_index_frames_device",
+    "clx_read_metadata_block", "clx_read_metadata_block_with_header", "clx_describe_packets",
 ]
 
 
@@ -169,6 +179,9 @@ def lib():
     L.clx_reader_close.argtypes = [vp]
     L.clx_reader_close.restype = None
     L.clx_index_frames.argtypes = [vp, sz, sz, vp, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.clx_read_metadata_block.argtypes = [vp, sz, C.c_uint8, C.c_uint32, C.POINTER(MetadataBlock), C.POINTER(sz), u32p]
+    L.clx_read_metadata_block_with_header.argtypes = [vp, sz, C.POINTER(MetadataBlock), C.POINTER(C.c_int), C.POINTER(sz), u32p]
+    L.clx_describe_packets.argtypes = [vp, sz, vp, vp, sz, C.c_int, vp, vp, vp]
     _lib = L
     return L
 
@@ -257,6 +270,50 @@ def read_stream_header_ext(data, metadata_only=False, read_vorbis_comment=True):
     if t.value:
         lib().clx_tags_free(t)
     return st, int(m.value), si, int(off.value), vendor, tags
+
+
+def read_metadata_block(data, block_type=None, length=None):
+    """metadata::read_metadata_block (metadata.rs:261) when block_type / length are given, else
+    read_metadata_block_with_header (metadata.rs:244).  Same dict as oracle.read_metadata_block."""
+    a = _u8(data)
+    blk = MetadataBlock()
+    used, m = C.c_size_t(0), C.c_uint32(0)
+    out = {}
+    if block_type is None:
+        last = C.c_int(0)
+        st = lib().clx_read_metadata_block_with_header(_np_ptr(a), a.size, C.byref(blk), C.byref(last), C.byref(used), C.byref(m))
+        out["is_last"] = bool(last.value)
+    else:
+        st = lib().clx_read_metadata_block(_np_ptr(a), a.size, int(block_type), int(length), C.byref(blk), C.byref(used), C.byref(m))
+    out.update(status=st, msg=int(m.value))
+    if st != OK:
+        return out
+    out.update(kind=int(blk.kind), length=int(blk.length), consumed=int(used.value))
+    if blk.kind == BLOCK_STREAMINFO:
+        out["streaminfo"] = blk.streaminfo
+    elif blk.kind == BLOCK_APPLICATION:
+        out["app_id"] = int(blk.application_id)
+        out["app_data"] = C.string_at(blk.application_data, blk.application_len) if blk.application_len else b""
+    elif blk.kind == BLOCK_VORBIS_COMMENT:
+        out["vendor"], out["tags"] = _tags_to_py(blk.tags)
+        lib().clx_tags_free(blk.tags)
+    return out
+
+
+def describe_packets(arena, offs, lens, check_crc=True):
+    """Container packets -> frame descriptors (clx_describe_packets): returns (descs, headers, results)."""
+    a = _u8(arena)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n = offs.size
+    descs = np.zeros(n, dtype=FRAME_DESC_DTYPE)
+    hdrs = np.zeros(n, dtype=FRAME_HEADER_DTYPE)
+    res = np.zeros(n, dtype=FRAME_RESULT_DTYPE)
+    st = lib().clx_describe_packets(_np_ptr(a), a.size, _np_ptr(offs), _np_ptr(lens), n, 1 if check_crc else 0,
+                                    _np_ptr(descs), _np_ptr(hdrs), _np_ptr(res))
+    if st == API_ERROR:
+        raise ClaxonError(API_ERROR, 0, "clx_describe_packets: a packet lies outside the arena")
+    return descs, hdrs, res
 
 
 def index_frames(data, start=0, cap=1 << 20):

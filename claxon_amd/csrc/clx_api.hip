@@ -681,6 +681,129 @@ int read_vorbis_comment(ByteCursor& c, uint32_t length, clx_tags& out, uint32_t*
 }
 }  // namespace
 
+namespace {
+// read_streaminfo_block (metadata.rs:321-400): the 34 bytes behind the block header, then the reference's sanity checks
+int read_streaminfo_body(ByteCursor& c, clx_streaminfo* out, uint32_t* msg) {
+    auto be = [&](int nbytes, uint64_t* v) { uint64_t r = 0; for (int i = 0; i < nbytes; ++i) { uint32_t b; if (!c.u8(&b)) return false; r = (r << 8) | b; } *v = r; return true; };
+    clx_streaminfo s; std::memset(&s, 0, sizeof s);
+    uint64_t v, sr_msb, sr_lsb, bps_ns, ns_lsb;
+    if (!be(2, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    s.min_block_size = (uint16_t)v;
+    if (!be(2, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    s.max_block_size = (uint16_t)v;
+    if (!be(3, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    s.min_frame_size = (uint32_t)v;
+    if (!be(3, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    s.max_frame_size = (uint32_t)v;
+    if (!be(2, &sr_msb) || !be(1, &sr_lsb) || !be(1, &bps_ns) || !be(4, &ns_lsb)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    s.sample_rate = (uint32_t)((sr_msb << 4) | (sr_lsb >> 4));
+    s.channels = (uint32_t)(((sr_lsb >> 1) & 7) + 1);
+    s.bits_per_sample = (uint32_t)((((sr_lsb & 1) << 4) | (bps_ns >> 4)) + 1);
+    s.samples = ((bps_ns & 15) << 32) | ns_lsb;
+    if (c.pos + 16 > c.n) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+    std::memcpy(s.md5sum, c.p + c.pos, 16); c.pos += 16;
+    if (s.min_block_size > s.max_block_size) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_MIN_BLOCK_GT_MAX_BLOCK);
+    if (s.min_block_size < 16) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_BLOCK_SIZE_LT_16);
+    if (s.min_frame_size > s.max_frame_size && s.max_frame_size != 0) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_MIN_FRAME_GT_MAX_FRAME);
+    if (s.sample_rate == 0 || s.sample_rate > 655350) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_SAMPLE_RATE);
+    *out = s;
+    return CLX_OK;
+}
+}  // namespace
+
+extern "C" int clx_read_metadata_block(const uint8_t* d, size_t len, uint8_t block_type, uint32_t length,
+                                       clx_metadata_block* out, size_t* consumed, uint32_t* msg) {
+    if (msg) *msg = CLX_MSG_NONE;
+    if (consumed) *consumed = 0;
+    if (!out || (!d && len)) return CLX_API_ERROR;
+    std::memset(out, 0, sizeof *out);
+    out->length = length;
+    ByteCursor c{ d, len, 0 };
+    auto skip = [&](uint32_t n) { if (n > c.n - c.pos) return false; c.pos += n; return true; };     // ReadBytes::skip, input.rs:269-277
+    int st = CLX_OK;
+    switch (block_type) {
+    case 0:                                                                                    // metadata.rs:266-274
+        if (length != 34) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_STREAMINFO_LENGTH);
+        out->kind = CLX_BLOCK_STREAMINFO;
+        st = read_streaminfo_body(c, &out->streaminfo, msg);
+        break;
+    case 2: {                                                                                  // read_application_block, metadata.rs:525-551
+        if (length < 4) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_APPLICATION_BLOCK_TOO_SHORT);
+        if (length > 10u * 1024 * 1024) return fail(msg, CLX_UNSUPPORTED, CLX_MSG_APPLICATION_BLOCK_TOO_LARGE);
+        uint32_t id = 0;
+        for (int i = 0; i < 4; ++i) { uint32_t b; if (!c.u8(&b)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF); id = (id << 8) | b; }
+        out->kind = CLX_BLOCK_APPLICATION;
+        out->application_id = id;
+        out->application_data = d + c.pos;
+        out->application_len = length - 4u;
+        if (!skip(length - 4u)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        break;
+    }
+    case 4: {                                                                                  // metadata.rs:291-294
+        std::unique_ptr<clx_tags> t(new clx_tags());
+        st = read_vorbis_comment(c, length, *t, msg);
+        if (st == CLX_OK) { out->kind = CLX_BLOCK_VORBIS_COMMENT; out->tags = t.release(); }
+        break;
+    }
+    case 127:                                                                                  // metadata.rs:303-306
+        return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_METADATA_BLOCK_TYPE);
+    case 1: case 3: case 5: case 6:                                                            // padding; seek table, cue sheet, picture: "pretend it is padding"
+        out->kind = CLX_BLOCK_PADDING;
+        if (!skip(length)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        break;
+    default:                                                                                   // metadata.rs:307-316
+        out->kind = CLX_BLOCK_RESERVED;
+        if (!skip(length)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        break;
+    }
+    if (st != CLX_OK) return st;
+    if (consumed) *consumed = c.pos;
+    return CLX_OK;
+}
+
+extern "C" int clx_read_metadata_block_with_header(const uint8_t* d, size_t len, clx_metadata_block* out, int* is_last,
+                                                   size_t* consumed, uint32_t* msg) {
+    if (msg) *msg = CLX_MSG_NONE;
+    if (consumed) *consumed = 0;
+    if (is_last) *is_last = 0;
+    if (!out || (!d && len)) return CLX_API_ERROR;
+    if (len < 4) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);                       // read_metadata_block_header, metadata.rs:214-231
+    const uint32_t length = ((uint32_t)d[1] << 16) | ((uint32_t)d[2] << 8) | d[3];
+    size_t used = 0;
+    const int st = clx_read_metadata_block(d + 4, len - 4, (uint8_t)(d[0] & 0x7fu), length, out, &used, msg);
+    if (st != CLX_OK) return st;
+    if (is_last) *is_last = (d[0] >> 7) & 1;
+    if (consumed) *consumed = used + 4;
+    return CLX_OK;
+}
+
+extern "C" int clx_describe_packets(const uint8_t* arena, size_t arena_len, const uint64_t* offs, const uint32_t* lens, size_t n,
+                                    int check_crc, clx_frame_desc* descs, clx_frame_header* headers, clx_frame_result* results) {
+    if (n == 0) return CLX_OK;
+    if (!arena || !offs || !lens) return CLX_API_ERROR;
+    int first_bad = CLX_OK;
+    for (size_t i = 0; i < n; ++i) {
+        if (offs[i] > arena_len || lens[i] > arena_len - offs[i]) return CLX_API_ERROR;
+        clx_frame_header h;
+        uint32_t m = CLX_MSG_NONE;
+        const int st = clx_parse_frame_header(arena + offs[i], lens[i], check_crc, &h, &m);
+        if (results) { results[i].status = st; results[i].msg = m; results[i].end_bit = 0; }
+        if (headers) headers[i] = h;
+        if (descs) {
+            clx_frame_desc& d = descs[i];
+            std::memset(&d, 0, sizeof d);
+            d.byte_off = offs[i];
+            d.max_bytes = lens[i];
+            if (st == CLX_OK) {
+                d.header_bytes = h.header_bytes; d.block_size = h.block_size; d.n_channels = h.n_channels;
+                d.channel_assignment = h.channel_assignment; d.bps = h.bps;
+            }
+        }
+        if (st != CLX_OK && first_bad == CLX_OK) first_bad = st;
+    }
+    return first_bad;
+}
+
 extern "C" int clx_read_stream_header_ext(const uint8_t* d, size_t len, uint32_t options, clx_streaminfo* info,
                                           size_t* audio_offset, clx_tags** tags_out, uint32_t* msg) {
     if (msg) *msg = CLX_MSG_NONE;
@@ -703,27 +826,9 @@ extern "C" int clx_read_stream_header_ext(const uint8_t* d, size_t len, uint32_t
         const uint32_t type = hb & 0x7fu;
         if (type == 0) {
             if (length != 34) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_STREAMINFO_LENGTH);
-            clx_streaminfo s; std::memset(&s, 0, sizeof s);
-            uint64_t v, sr_msb, sr_lsb, bps_ns, ns_lsb;
-            if (!be(2, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-            s.min_block_size = (uint16_t)v;
-            if (!be(2, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-            s.max_block_size = (uint16_t)v;
-            if (!be(3, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-            s.min_frame_size = (uint32_t)v;
-            if (!be(3, &v)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-            s.max_frame_size = (uint32_t)v;
-            if (!be(2, &sr_msb) || !be(1, &sr_lsb) || !be(1, &bps_ns) || !be(4, &ns_lsb)) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-            s.sample_rate = (uint32_t)((sr_msb << 4) | (sr_lsb >> 4));
-            s.channels = (uint32_t)(((sr_lsb >> 1) & 7) + 1);
-            s.bits_per_sample = (uint32_t)((((sr_lsb & 1) << 4) | (bps_ns >> 4)) + 1);
-            s.samples = ((bps_ns & 15) << 32) | ns_lsb;
-            if (c.pos + 16 > len) return fail(msg, CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-            std::memcpy(s.md5sum, d + c.pos, 16); c.pos += 16;
-            if (s.min_block_size > s.max_block_size) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_MIN_BLOCK_GT_MAX_BLOCK);
-            if (s.min_block_size < 16) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_BLOCK_SIZE_LT_16);
-            if (s.min_frame_size > s.max_frame_size && s.max_frame_size != 0) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_MIN_FRAME_GT_MAX_FRAME);
-            if (s.sample_rate == 0 || s.sample_rate > 655350) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_INVALID_SAMPLE_RATE);
+            clx_streaminfo s;
+            const int sst = read_streaminfo_body(c, &s, msg);
+            if (sst != CLX_OK) return sst;
             if (!first) return fail(msg, CLX_FORMAT_ERROR, CLX_MSG_SECOND_STREAMINFO);
             *info = s;
         } else if (type == 4) {

@@ -3,7 +3,8 @@
 //   claxon::Block               <- frame.rs:402-529
 //   claxon::FrameReader         <- frame.rs:603-609, 650-785
 //   claxon::FlacReader          <- lib.rs:93-97, 207-471
-//   claxon::FlacSamples         <- lib.rs:169-178, 473-520
+//   claxon::FlacSamples         <- lib.rs:169-178, 473-520   (FlacIntoSamples <- lib.rs:181-184, 417, 522-560)
+//   claxon::MetadataBlock, read_metadata_block[_with_header], MetadataBlockReader <- metadata.rs:104-131, 244-319, 553-603
 // Same names, argument meaning and error behaviour; decoding itself happens on the GPU through
 // the C ABI in include/claxon_hip.h (frames are indexed on the host and decoded in batches).
 #ifndef CLAXON_HPP
@@ -144,6 +145,85 @@ private:
     bool has_failed_ = false;
 };
 
+// A metadata block of the stream (metadata.rs:104-131).  CueSheet / Picture / SeekTable are never produced: the reference
+// reads those blocks as Padding (its TODOs at metadata.rs:287-305).
+struct MetadataBlock {
+    enum class Kind { StreamInfo, Padding, Application, SeekTable, VorbisComment, CueSheet, Picture, Reserved };
+    Kind kind = Kind::Reserved;
+    clx_streaminfo streaminfo{};                                     // StreamInfo(..)
+    uint32_t length = 0;                                             // Padding { length }
+    uint32_t id = 0;                                                 // Application { id, data }
+    std::vector<uint8_t> data;
+    std::string vendor;                                              // VorbisComment { vendor, comments }: "NAME=value" split at '='
+    std::vector<std::pair<std::string, std::string>> comments;
+};
+
+namespace detail {
+inline Result<MetadataBlock> metadata_block_result(int st, uint32_t msg, clx_metadata_block& b) {
+    Result<MetadataBlock> r;
+    if (st != CLX_OK) { r.is_err = true; r.error = Error::from(st, msg); return r; }
+    MetadataBlock& m = r.value;
+    m.length = b.length;
+    switch (b.kind) {
+    case CLX_BLOCK_STREAMINFO: m.kind = MetadataBlock::Kind::StreamInfo; m.streaminfo = b.streaminfo; break;
+    case CLX_BLOCK_PADDING: m.kind = MetadataBlock::Kind::Padding; break;
+    case CLX_BLOCK_APPLICATION:
+        m.kind = MetadataBlock::Kind::Application; m.id = b.application_id;
+        m.data.assign(b.application_data, b.application_data + b.application_len);
+        break;
+    case CLX_BLOCK_VORBIS_COMMENT: {
+        m.kind = MetadataBlock::Kind::VorbisComment;
+        size_t n = 0;
+        const char* v = clx_tags_vendor(b.tags, &n);
+        m.vendor.assign(v ? v : "", n);
+        for (size_t i = 0; i < clx_tags_count(b.tags); ++i) {
+            const char *name, *value; size_t ln, lv;
+            if (clx_tags_get(b.tags, i, &name, &ln, &value, &lv) == CLX_OK) m.comments.emplace_back(std::string(name, ln), std::string(value, lv));
+        }
+        clx_tags_free(b.tags);
+        break;
+    }
+    default: m.kind = MetadataBlock::Kind::Reserved; break;
+    }
+    return r;
+}
+}  // namespace detail
+
+// Read a single metadata block of the given type and length from `data` (metadata.rs:261): for streams embedded in a
+// container, e.g. the MP4 "FLAC specific box".  *consumed (may be null) receives the bytes read.
+inline Result<MetadataBlock> read_metadata_block(const uint8_t* data, size_t len, uint8_t block_type, uint32_t length, size_t* consumed = nullptr) {
+    clx_metadata_block b; uint32_t msg = 0; size_t used = 0;
+    const int st = clx_read_metadata_block(data, len, block_type, length, &b, &used, &msg);
+    if (consumed) *consumed = used;
+    return detail::metadata_block_result(st, msg, b);
+}
+// Read a single metadata block header and body (metadata.rs:244): e.g. an Ogg packet of the FLAC mapping.
+inline Result<MetadataBlock> read_metadata_block_with_header(const uint8_t* data, size_t len, size_t* consumed = nullptr, bool* is_last = nullptr) {
+    clx_metadata_block b; uint32_t msg = 0; size_t used = 0; int last = 0;
+    const int st = clx_read_metadata_block_with_header(data, len, &b, &last, &used, &msg);
+    if (consumed) *consumed = used;
+    if (is_last) *is_last = last != 0;
+    return detail::metadata_block_result(st, msg, b);
+}
+
+// Reads metadata blocks from a stream positioned at a block header and yields them one by one (metadata.rs:553-603):
+// at least one element; after the block flagged as last, or after an error, next() returns false.
+class MetadataBlockReader {
+public:
+    MetadataBlockReader(const uint8_t* data, size_t len) : data_(data), len_(len) {}                 // metadata.rs:567
+    bool next(Result<MetadataBlock>* out) {                                                        // metadata.rs:582-597
+        if (done_) return false;
+        size_t used = 0; bool last = false;
+        *out = read_metadata_block_with_header(data_ + pos_, len_ - pos_, &used, &last);
+        pos_ += used;
+        done_ = out->is_err || last;
+        return true;
+    }
+    size_t position() const { return pos_; }
+private:
+    const uint8_t* data_; size_t len_, pos_ = 0; bool done_ = false;
+};
+
 // Controls what FlacReader reads when it is constructed (lib.rs:100-140).
 struct FlacReaderOptions {
     bool metadata_only = false;        // stop after the metadata blocks; blocks() / samples() are unavailable (lib.rs:113)
@@ -170,10 +250,25 @@ public:
     FrameReader& blocks();
     FlacSamples samples() { return FlacSamples(blocks()); }
     FlacReader();
+    friend class FlacIntoSamples;
 private:
     friend struct Result<FlacReader>;
     Impl* impl_;
 };
+
+// An iterator that yields samples and owns its reader (FlacReader::into_samples, lib.rs:181-184, 417-433): for
+// callers that want to hand the iterator on without keeping the reader alive themselves.
+class FlacIntoSamples {
+public:
+    explicit FlacIntoSamples(FlacReader&& reader) : reader_(std::move(reader)), samples_(reader_.blocks()) {}
+    FlacIntoSamples(const FlacIntoSamples&) = delete;
+    bool next(int32_t* sample, Error* err, bool* failed) { return samples_.next(sample, err, failed); }
+    FlacReader& reader() { return reader_; }
+private:
+    FlacReader reader_;
+    FlacSamples samples_;
+};
+inline FlacIntoSamples into_samples(FlacReader&& reader) { return FlacIntoSamples(std::move(reader)); }
 
 }  // namespace claxon
 

@@ -292,6 +292,38 @@ void        clx_tags_free(clx_tags* t);
 /* tags of an open reader (NULL if the stream has none); owned by the reader */
 const clx_tags* clx_reader_tags(const clx_reader* r);
 
+/* One metadata block, as `metadata::read_metadata_block` (metadata.rs:261-319) returns it: for streams embedded in a
+ * container (examples/decode_ogg.rs:32-41, 85-103: Ogg packets hold metadata blocks with their header;
+ * examples/decode_mp4.rs: the "FLAC specific box" holds type and raw data).  `kind` is the variant of the reference's
+ * `MetadataBlock` enum (metadata.rs:104-131): seek tables, cue sheets and pictures are read as Padding (the reference's
+ * TODOs at metadata.rs:287, 296, 301), unknown types as Reserved. */
+enum { CLX_BLOCK_STREAMINFO = 0, CLX_BLOCK_PADDING = 1, CLX_BLOCK_APPLICATION = 2, CLX_BLOCK_VORBIS_COMMENT = 4, CLX_BLOCK_RESERVED = 126 };
+typedef struct clx_metadata_block {
+    uint32_t kind;                       /* CLX_BLOCK_* */
+    uint32_t length;                     /* Padding { length } (metadata.rs:108-111); the block's length for every kind */
+    clx_streaminfo streaminfo;           /* StreamInfo(..) */
+    uint32_t application_id;             /* Application { id, data } (metadata.rs:113-118) */
+    const uint8_t* application_data;     /* points into the caller's buffer */
+    size_t application_len;
+    clx_tags* tags;                      /* VorbisComment(..); owned by the caller: clx_tags_free */
+} clx_metadata_block;
+/* read_metadata_block (metadata.rs:261): `data[0..len)` stands right behind the block header, whose fields the caller
+ * passes.  *consumed = bytes read on success.  Errors and messages as the reference (too short a buffer: CLX_IO_ERROR). */
+int clx_read_metadata_block(const uint8_t* data, size_t len, uint8_t block_type, uint32_t length,
+                            clx_metadata_block* out, size_t* consumed, uint32_t* msg);
+/* read_metadata_block_with_header (metadata.rs:244): header (last-block flag + type, 24-bit length; metadata.rs:214-231)
+ * and body.  *is_last receives the header's flag (MetadataBlockReader stops after it, metadata.rs:573-578). */
+int clx_read_metadata_block_with_header(const uint8_t* data, size_t len, clx_metadata_block* out, int* is_last,
+                                        size_t* consumed, uint32_t* msg);
+/* Container packets -> frame descriptors.  What the reference's container examples do per packet -- FrameReader::new over
+ * the packet's bytes, then read_next_or_eof (examples/decode_ogg.rs:105-114, decode_mp4.rs:143-152) -- for n packets at
+ * once: packet i = arena[offs[i] .. offs[i] + lens[i]) holds one frame; its header is parsed (clx_parse_frame_header) into
+ * descs[i] / headers[i] (either may be NULL) with max_bytes = lens[i].  results[i] (may be NULL) receives the header's
+ * status and message; packets shorter than two bytes give CLX_END_OF_STREAM (frame.rs:140-143; the examples skip empty
+ * packets).  Returns CLX_OK when every packet has a valid header, else the first failing packet's status. */
+int clx_describe_packets(const uint8_t* arena, size_t arena_len, const uint64_t* offs, const uint32_t* lens, size_t n,
+                         int check_crc, clx_frame_desc* descs, clx_frame_header* headers, clx_frame_result* results);
+
 int  clx_reader_open(clx_ctx* ctx, const char* path, clx_reader** out, uint32_t* msg);       /* lib.rs:455 */
 int  clx_reader_new(clx_ctx* ctx, const uint8_t* data, size_t len, clx_reader** out, uint32_t* msg); /* lib.rs:217 */
 int  clx_reader_streaminfo(const clx_reader* r, clx_streaminfo* out);                        /* lib.rs:312 */

@@ -222,6 +222,60 @@ def stream_open_ext(data, metadata_only=False, read_vorbis_comment=True):
     return st, int(msg.value), si, int(off.value), vendor, tags
 
 
+def _parse_tags_record(raw):
+    import struct
+    (vl,) = struct.unpack_from("=I", raw, 0)
+    vendor = raw[4:4 + vl]
+    (n,) = struct.unpack_from("=I", raw, 4 + vl)
+    p, tags = 8 + vl, []
+    for _ in range(n):
+        ln, sep = struct.unpack_from("=II", raw, p)
+        c = raw[p + 8:p + 8 + ln]
+        tags.append((c[:sep], c[sep + 1:]))
+        p += 8 + ln
+    return vendor, tags
+
+
+def read_metadata_block(data, block_type=None, length=None):
+    """metadata::read_metadata_block (metadata.rs:261) when block_type / length are given, else
+    read_metadata_block_with_header (metadata.rs:244).  Returns a dict: status, msg, and on success kind, length, consumed,
+    is_last (with header), streaminfo | (app_id, app_data) | (vendor, tags)."""
+    a = _bytes_arr(data)
+    L = lib()
+    si = StreamInfo()
+    app = (C.c_uint64 * 3)()
+    cap = a.size + 64
+    buf = np.zeros(cap, dtype=np.uint8)
+    tl, used, msg, kind = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0), C.c_uint32(0)
+    out = {}
+    if block_type is None:
+        ln, last = C.c_uint32(0), C.c_int(0)
+        L.clxo_read_metadata_block_with_header.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int),
+                                                           C.POINTER(StreamInfo), C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                                           C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+        st = L.clxo_read_metadata_block_with_header(_ptr(a), a.size, C.byref(kind), C.byref(ln), C.byref(last), C.byref(si), app,
+                                                    buf.ctypes.data, cap, C.byref(tl), C.byref(used), C.byref(msg))
+        out["is_last"] = bool(last.value)
+        length = int(ln.value)
+    else:
+        L.clxo_read_metadata_block.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(StreamInfo),
+                                               C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+        st = L.clxo_read_metadata_block(_ptr(a), a.size, int(block_type), int(length), C.byref(kind), C.byref(si), app,
+                                        buf.ctypes.data, cap, C.byref(tl), C.byref(used), C.byref(msg))
+    out.update(status=st, msg=int(msg.value))
+    if st != STATUS_OK:
+        return out
+    out.update(kind=int(kind.value), length=int(length), consumed=int(used.value))
+    if kind.value == 0:
+        out["streaminfo"] = si
+    elif kind.value == 2:
+        out["app_id"] = int(app[0])
+        out["app_data"] = a[int(app[1]):int(app[1]) + int(app[2])].tobytes()
+    elif kind.value == 4:
+        out["vendor"], out["tags"] = _parse_tags_record(buf[:tl.value].tobytes())
+    return out
+
+
 def decode_stream(data, check_crc=True):
     """FlacReader::new + blocks() loop.  Returns (streaminfo, [(FrameInfo, samples)], final_status, final_msg)."""
     a = _bytes_arr(data)

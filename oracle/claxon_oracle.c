@@ -903,6 +903,89 @@ eof:
     return CLX_IO_ERROR;
 }
 
+/* read_metadata_block (metadata.rs:261-319) on Cursor(d[0..len)) positioned behind the block header, and
+ * read_metadata_block_with_header (metadata.rs:244-248; header per 214-231).  kind: 0 StreamInfo, 1 Padding,
+ * 2 Application, 4 VorbisComment, 126 Reserved (seek table / cue sheet / picture are read as Padding, 287-305).
+ * app[0] = id, app[1] = offset of the data in d, app[2] = its length; tags as in clxo_stream_open_ext. */
+int clxo_read_metadata_block(const uint8_t* d, size_t len, uint32_t block_type, uint32_t length, uint32_t* kind,
+                             clx_streaminfo* si, uint64_t* app, uint8_t* tags_out, size_t tags_cap, size_t* tags_len,
+                             size_t* consumed, uint32_t* msg) {
+    size_t pos = 0;
+    *msg = CLX_MSG_NONE; *tags_len = 0; *consumed = 0; *kind = 0;
+    if (block_type == 0) {                                                                            /* 266-274 */
+        if (length != 34) { *msg = CLX_MSG_STREAMINFO_LENGTH; return CLX_FORMAT_ERROR; }
+        /* read_streaminfo_block, metadata.rs:321-400 */
+        uint64_t v, sr_msb, sr_lsb, bps_ns, ns_lsb;
+        clx_streaminfo s;
+        memset(&s, 0, sizeof s);
+        if (!cur_be(d, len, &pos, 2, &v)) goto eof;
+        s.min_block_size = (uint16_t)v;
+        if (!cur_be(d, len, &pos, 2, &v)) goto eof;
+        s.max_block_size = (uint16_t)v;
+        if (!cur_be(d, len, &pos, 3, &v)) goto eof;
+        s.min_frame_size = (uint32_t)v;
+        if (!cur_be(d, len, &pos, 3, &v)) goto eof;
+        s.max_frame_size = (uint32_t)v;
+        if (!cur_be(d, len, &pos, 2, &sr_msb)) goto eof;
+        if (!cur_be(d, len, &pos, 1, &sr_lsb)) goto eof;
+        if (!cur_be(d, len, &pos, 1, &bps_ns)) goto eof;
+        if (!cur_be(d, len, &pos, 4, &ns_lsb)) goto eof;
+        s.sample_rate = (uint32_t)((sr_msb << 4) | (sr_lsb >> 4));
+        s.channels = (uint32_t)(((sr_lsb >> 1) & 7) + 1);
+        s.bits_per_sample = (uint32_t)((((sr_lsb & 1) << 4) | (bps_ns >> 4)) + 1);
+        s.samples = ((bps_ns & 0x0f) << 32) | ns_lsb;
+        if (pos + 16 > len) goto eof;
+        memcpy(s.md5sum, d + pos, 16); pos += 16;
+        if (s.min_block_size > s.max_block_size) { *msg = CLX_MSG_MIN_BLOCK_GT_MAX_BLOCK; return CLX_FORMAT_ERROR; }
+        if (s.min_block_size < 16) { *msg = CLX_MSG_BLOCK_SIZE_LT_16; return CLX_FORMAT_ERROR; }
+        if (s.min_frame_size > s.max_frame_size && s.max_frame_size != 0) { *msg = CLX_MSG_MIN_FRAME_GT_MAX_FRAME; return CLX_FORMAT_ERROR; }
+        if (s.sample_rate == 0 || s.sample_rate > 655350) { *msg = CLX_MSG_INVALID_SAMPLE_RATE; return CLX_FORMAT_ERROR; }
+        *si = s; *kind = 0;
+    } else if (block_type == 2) {                                                                     /* read_application_block, 525-551 */
+        uint64_t id;
+        if (length < 4) { *msg = CLX_MSG_APPLICATION_BLOCK_TOO_SHORT; return CLX_FORMAT_ERROR; }
+        if (length > 10u * 1024 * 1024) { *msg = CLX_MSG_APPLICATION_BLOCK_TOO_LARGE; return CLX_UNSUPPORTED; }
+        if (!cur_be(d, len, &pos, 4, &id)) goto eof;
+        if ((size_t)(length - 4) > len - pos) goto eof;                                               /* read_into */
+        app[0] = id; app[1] = pos; app[2] = length - 4;
+        pos += length - 4;
+        *kind = 2;
+    } else if (block_type == 4) {                                                                     /* 291-294 */
+        size_t w = 0;
+        int st = read_vorbis_comment_block(d, len, &pos, length, tags_out, tags_cap, &w, msg);
+        if (st != CLX_OK) return st;
+        *tags_len = w; *kind = 4;
+    } else if (block_type == 127) {                                                                   /* 303-306 */
+        *msg = CLX_MSG_INVALID_METADATA_BLOCK_TYPE; return CLX_FORMAT_ERROR;
+    } else {                                                                                          /* 1, 3, 5, 6: padding; the rest reserved: skip(length) */
+        if ((size_t)length > len - pos) goto eof;
+        pos += length;
+        *kind = (block_type == 1 || block_type == 3 || block_type == 5 || block_type == 6) ? 1 : 126;
+    }
+    *consumed = pos;
+    return CLX_OK;
+eof:
+    *msg = CLX_MSG_UNEXPECTED_EOF;
+    return CLX_IO_ERROR;
+}
+int clxo_read_metadata_block_with_header(const uint8_t* d, size_t len, uint32_t* kind, uint32_t* length, int* is_last,
+                                         clx_streaminfo* si, uint64_t* app, uint8_t* tags_out, size_t tags_cap, size_t* tags_len,
+                                         size_t* consumed, uint32_t* msg) {
+    size_t pos = 0;
+    uint32_t b;
+    uint64_t l24;
+    *msg = CLX_MSG_NONE; *consumed = 0; *tags_len = 0; *kind = 0; *length = 0; *is_last = 0;
+    if (!cur_u8(d, len, &pos, &b) || !cur_be(d, len, &pos, 3, &l24)) { *msg = CLX_MSG_UNEXPECTED_EOF; return CLX_IO_ERROR; }   /* 214-231 */
+    *length = (uint32_t)l24;
+    size_t used = 0;
+    int st = clxo_read_metadata_block(d + pos, len - pos, b & 0x7f, (uint32_t)l24, kind, si, app, tags_out, tags_cap, tags_len, &used, msg);
+    if (st != CLX_OK) return st;
+    if (*kind == 2) app[1] += pos;
+    *is_last = (b >> 7) == 1;
+    *consumed = pos + used;
+    return CLX_OK;
+}
+
 /* ------------------------------------------------------------- test hooks for the reference's unit vectors */
 
 uint8_t  clxo_crc8(const uint8_t* p, size_t n)  { pthread_once(&g_crc_once, crc_tables_init); uint8_t s = 0;  for (size_t i = 0; i < n; i++) s = g_crc8_table[s ^ p[i]]; return s; }

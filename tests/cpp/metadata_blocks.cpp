@@ -1,0 +1,47 @@
+// The metadata side of the C++ mirror (claxon.hpp: MetadataBlock, read_metadata_block_with_header, MetadataBlockReader)
+// on the streams handed over as arguments: prints one line per block; tests/test_metadata_blocks.py compares the lines
+// with what the C ABI and the oracle say.  Needs no GPU (metadata is parsed on the host).
+//   usage: metadata_blocks <file.flac>...
+#include <cinttypes>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../claxon_amd/csrc/host/claxon.hpp"
+
+static const char* kind_name(claxon::MetadataBlock::Kind k) {
+    using K = claxon::MetadataBlock::Kind;
+    switch (k) {
+    case K::StreamInfo: return "StreamInfo"; case K::Padding: return "Padding"; case K::Application: return "Application";
+    case K::VorbisComment: return "VorbisComment"; case K::Reserved: return "Reserved"; default: return "Other";
+    }
+}
+
+int main(int argc, char** argv) {
+    for (int a = 1; a < argc; ++a) {
+        std::FILE* f = std::fopen(argv[a], "rb");
+        if (!f) { std::printf("%s: cannot open\n", argv[a]); return 2; }
+        std::vector<uint8_t> d;
+        uint8_t buf[65536]; size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+        std::fclose(f);
+        if (d.size() < 4) { std::printf("%s: too short\n", argv[a]); continue; }
+        claxon::MetadataBlockReader reader(d.data() + 4, d.size() - 4);          // behind the `fLaC` marker (lib.rs:186-205)
+        claxon::Result<claxon::MetadataBlock> r;
+        int i = 0;
+        while (reader.next(&r)) {
+            if (r.is_err) { std::printf("%s block=%d error status=%d text=%s\n", argv[a], i, r.error.status, r.error.text.c_str()); break; }
+            const claxon::MetadataBlock& m = r.value;
+            std::printf("%s block=%d kind=%s length=%" PRIu32, argv[a], i, kind_name(m.kind), m.length);
+            if (m.kind == claxon::MetadataBlock::Kind::StreamInfo)
+                std::printf(" sample_rate=%" PRIu32 " channels=%" PRIu32 " bits_per_sample=%" PRIu32 " samples=%" PRIu64,
+                            m.streaminfo.sample_rate, m.streaminfo.channels, m.streaminfo.bits_per_sample, (uint64_t)m.streaminfo.samples);
+            if (m.kind == claxon::MetadataBlock::Kind::Application) std::printf(" id=%08" PRIx32 " data_len=%zu", m.id, m.data.size());
+            if (m.kind == claxon::MetadataBlock::Kind::VorbisComment) std::printf(" comments=%zu vendor_len=%zu", m.comments.size(), m.vendor.size());
+            std::printf("\n");
+            ++i;
+        }
+        std::printf("%s end=%zu\n", argv[a], reader.position() + 4);
+    }
+    return 0;
+}
