@@ -37,7 +37,7 @@ struct K1Lds {
     uint32_t Wfront[4];        // never written: lets the extraction read the dword in front of W[0] (its bits are masked off)
     uint32_t W[CLX_NW + 4];
     // The two phases of a span never overlap: first the exit-state tables resolve where every lane's chunk is entered,
-    // then the positions of the codes are listed.  4.4 KiB per wave in all = 8 waves per SIMD.
+    // then the positions of the codes are listed.  4.9 KiB per wave in all = 8 waves per SIMD.
     union {
         struct {
             // tab[lane][s]: exit state of that lane's chunk for entry state s, one byte each, so that a step of the walk
@@ -198,11 +198,14 @@ __device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint3
 // Decode `count` Rice codes with parameter k starting at bit `pos` into dst[0..count).
 // Returns the bit position after the last code; *err != 0 on EOF.  Wave-uniform control flow.
 //
-// Per span of 64 lanes x B bits: (1) every lane walks its chunk once per possible entry state and
-// publishes the exit states; (2) a three-level walk over the 64 chunks (8 groups of 8) resolves every
-// lane's true entry state; (3) lanes mark the codes that *start* in their chunk, a wave prefix sum gives
-// output indices; (4) each lane extracts its codes (clz for the unary part, shift for the remainder)
-// into LDS, from where they are written to HBM coalesced.
+// Per span of 64 lanes x B bits: (1) every lane finds the state in which its chunk is left for every state it may be
+// entered in -- four bits per step through the transition table in LDS for short codes (k <= CLX_LUT_KMAX), a walk of
+// shift / count-leading-zeros / add per code for longer ones; (2) every lane's true entry state: chunks whose exit does
+// not depend on their entry hand it to their successor directly, the rest follow by DPP wave shifts (table path), or a
+// three-level walk over the 64 chunks' exit tables in LDS (8 groups of 8; long codes); (3) lanes mark the codes that
+// *start* in their chunk, a wave prefix sum gives output indices; (4) the start positions are listed in LDS: a code
+// ends where the next one starts, so extraction is balanced over the lanes (code i by lane i mod 64), reads the
+// remainder with one v_alignbit + v_bfe from the window and writes the residuals to HBM coalesced.
 __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32_t k, uint32_t count,
                                        int32_t* dst, uint32_t limit, uint32_t* err, uint32_t& lut_k, int lane CLX_TL_PH_PARAM) {
     // the cursor and the partition's shape are the same in every lane: keep them (and all that follows from them: chunk
@@ -320,9 +323,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             }
         }
         __syncthreads();
-        // (2b) across groups (on the scalar unit: the eight group entry states are packed into two registers, every
-        // lane picks its group's byte), (2c) inside each group
-        // Both walks are chains of LDS look-ups whose address is the previous result; the state in front of every step is
+        // (2b) across groups, (2c) inside each group.  Both walks are chains of LDS look-ups whose address is the previous result; the state in front of every step is
         // dropped into LDS (no VALU work) and each lane picks up the one that is its own afterwards.
         {
             uint32_t m = 0;                                  // a span always begins at a code start
