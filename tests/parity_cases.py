@@ -176,6 +176,33 @@ def range_hop_workload(n=72, bs=1024):
     return synth.concat("range hops", ws)
 
 
+def resync_workload():
+    """Rice streams that never resynchronise: with parameter k the residual -2^(k-1) (0 for k = 0) is the code `1` +
+    k ones, so a partition of it is a run of ones in which a decoder that starts at the wrong bit stays wrong for ever --
+    the exit state of every chunk of the wave-parallel decode depends on its entry state (the worst case for the
+    propagation of entry states).  Mixed with stretches of ordinary noise, with codes whose remainder is all zeros
+    (resynchronises at once), long unary runs, and with every k the table path / the arithmetic walks handle."""
+    rng = np.random.default_rng(777)
+    ws = []
+    for k in (0, 1, 2, 3, 4, 5, 6, 7, 9, 12):
+        for bs, po in ((4096, 0), (1024, 2), (256, 0), (192, 0)):
+            stuck = 0 if k == 0 else -(1 << (k - 1))
+            noise = rng.integers(-(1 << k), (1 << k) + 1, size=bs)
+            zeros_rem = (rng.integers(0, 3, size=bs) << k) >> 1 << 1          # even u, multiples of 2^k: remainder bits all zero
+            runs = np.where(rng.random(bs) < 0.01, rng.integers(0, 40 << k, size=bs), stuck)
+            variants = [np.full(bs, stuck), np.where(np.arange(bs) % 512 < 300, stuck, noise), zeros_rem, runs,
+                        np.where(np.arange(bs) < bs // 2, noise, stuck)]
+            for ca, channels in ((0, 1), (0, 2)):
+                for v in variants:
+                    chans = [np.asarray(v, dtype=np.int32), np.asarray(v[::-1], dtype=np.int32)][:channels]
+                    pcm = np.stack(chans)[None]
+                    fp = synth.FrameParams(ca, 0, len(ws))
+                    for c in range(channels):
+                        fp.sf[c] = synth.sf(synth.SF_FIXED, 0, 0, po, rice_param=k)
+                    ws.append(synth.encode_frames("r", pcm, channels, bs, 16, [fp]))
+    return synth.concat("resync", ws)
+
+
 def check_regressions(oracle, backend):
     """Frames that once decoded differently from the oracle on some kernel selection (found by tools/stress_gpu.py)."""
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "*.npy")))

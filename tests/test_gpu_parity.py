@@ -33,6 +33,10 @@ def test_gpu_edges(oracle, gpu):
     pc.check_workload(oracle, gpu, pc.edge_workload())
 
 
+def test_gpu_never_resynchronising_streams(oracle, gpu):
+    pc.check_workload(oracle, gpu, pc.resync_workload())
+
+
 def test_gpu_range_hops(oracle, gpu):
     pc.check_workload(oracle, gpu, pc.range_hop_workload())
 

@@ -33,6 +33,10 @@ def test_sim_edges(oracle, sim):
     pc.check_workload(oracle, sim, pc.edge_workload())
 
 
+def test_sim_never_resynchronising_streams(oracle, sim):
+    pc.check_workload(oracle, sim, pc.resync_workload())
+
+
 def test_sim_range_hops(oracle, sim):
     pc.check_workload(oracle, sim, pc.range_hop_workload())
 
