@@ -433,6 +433,8 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
         if (!mark("clx_k_residual")) return CLX_API_ERROR;
+        // CLX_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer K1 waves per CU -- the measurement knob behind DESIGN.md's
+        // "lower occupancy is strictly worse" (32 -> 16 waves per CU: 0.28 -> 0.39 ms); not used otherwise
         static const unsigned k1_pad = [] { const char* e = std::getenv("CLX_K1_LDS_PAD"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
         hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), k1_pad, stream,
                            d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);

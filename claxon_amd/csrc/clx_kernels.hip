@@ -59,7 +59,9 @@ struct K1Lds {
 
 // The transition tables of K1Lds::lut for the Rice parameters that use them (k <= CLX_LUT_KMAX), generated at compile time
 // and kept in constant memory: switching the LDS copy to another parameter is one 4-byte load + store in 28 lanes.
+#ifndef CLX_LUT_KMAX            // (CLX_EXTRA_FLAGS=-DCLX_LUT_KMAX=6u builds the other setting the single exit register allows)
 #define CLX_LUT_KMAX 5u
+#endif
 struct K1LutRom { uint32_t w[CLX_LUT_KMAX + 1u][32]; };
 constexpr K1LutRom clx_make_lut_rom() {
     K1LutRom r{};
