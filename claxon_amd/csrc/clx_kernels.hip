@@ -49,7 +49,7 @@ struct K1Lds {
         uint16_t P[CLX_NPOS];      // P[i]: bit position (relative to the span) where code i of the span starts
     } u;
     // lut[s * 16 + nib]: what four stream bits `nib` (MSB first) do to a walk that meets them in state s, for the Rice
-    // parameter of the partition being decoded (k <= 14: at most 16 states; rebuilt when k changes).  High nibble: the
+    // parameter of the partition being decoded (k <= CLX_LUT_KMAX: at most 8 rows; copied from the ROM when k changes).  High nibble: the
     // state behind the four bits; low nibble: which of the four positions are code starts (bit i = the i-th bit).
     // Any byte is a valid entry at all times, so a chain of look-ups never leaves the table.
     uint8_t lut[256];
