@@ -113,6 +113,28 @@ static void verify_decoded_stream(const char* name, const char* file) {
     std::printf("%s samples=%" PRIu64 " md5=%s\n", name, count, hex(digest, 16).c_str());
 }
 
+// FlacReader::into_samples (lib.rs:417-433): the iterator that owns its reader yields what samples() yields
+static void verify_into_samples(const char* name, const char* file) {
+    auto a = claxon::FlacReader::open(g_ctx, path(file).c_str());
+    auto b = claxon::FlacReader::open(g_ctx, path(file).c_str());
+    CHECK(a.is_ok() && b.is_ok());
+    if (!a.is_ok() || !b.is_ok()) return;
+    claxon::FlacSamples borrowed = a.value.samples();
+    claxon::FlacIntoSamples owned = claxon::into_samples(std::move(b.value));
+    int32_t s1 = 0, s2 = 0; claxon::Error e1, e2; bool f1 = false, f2 = false;
+    uint64_t count = 0;
+    for (;;) {
+        const bool m1 = borrowed.next(&s1, &e1, &f1), m2 = owned.next(&s2, &e2, &f2);
+        CHECK(m1 == m2 && f1 == f2);
+        if (!m1 || !m2 || f1 || f2) break;
+        CHECK(s1 == s2);
+        ++count;
+    }
+    const clx_streaminfo si = owned.reader().streaminfo();
+    CHECK(count == (uint64_t)si.samples * si.channels);
+    std::printf("%s samples=%" PRIu64 "\n", name, count);
+}
+
 // the same audio through blocks(): Block accessors agree with each other (frame.rs:402-529)
 static void verify_blocks(const char* name, const char* file) {
     auto r = claxon::FlacReader::open(g_ctx, path(file).c_str());
@@ -251,6 +273,7 @@ int main(int argc, char** argv) {
     if (clx_create(0, &g_ctx) != CLX_OK) { std::fprintf(stderr, "no gfx950 device: this test decodes on the GPU\n"); return 3; }
     static const char* const files[][2] = { { "pop", "pop.flac" }, { "short", "short.flac" }, { "wasted_bits", "wasted_bits.flac" }, { "non_subset", "non_subset.flac" } };
     for (auto& f : files) verify_streaminfo((std::string("verify_streaminfo_") + f[0]).c_str(), f[1]);
+    for (auto& f : files) verify_into_samples((std::string("verify_into_samples_") + f[0]).c_str(), f[1]);
     for (auto& f : files) verify_decoded_stream((std::string("verify_decoded_stream_") + f[0]).c_str(), f[1]);
     for (auto& f : files) verify_blocks((std::string("verify_blocks_") + f[0]).c_str(), f[1]);
     test_flac_reader_get_tag_returns_all_matches();
