@@ -2,6 +2,7 @@
 //   claxon::Error / Result      <- error.rs:18-32, 97
 //   claxon::Block               <- frame.rs:402-529
 //   claxon::FrameReader         <- frame.rs:603-609, 650-785
+//   claxon::decode_packets      <- the per-packet loop of examples/decode_ogg.rs / decode_mp4.rs, as one batch
 //   claxon::FlacReader          <- lib.rs:93-97, 207-471
 //   claxon::FlacSamples         <- lib.rs:169-178, 473-520   (FlacIntoSamples <- lib.rs:181-184, 417, 522-560)
 //   claxon::MetadataBlock, read_metadata_block[_with_header], MetadataBlockReader <- metadata.rs:104-131, 244-319, 553-603
@@ -110,6 +111,51 @@ public:
 private:
     Impl* impl_;
 };
+
+// One frame per packet, a batch of packets at once: what a container demuxer's loop does with the reference --
+// `FrameReader::new(Cursor::new(&packet.data)).read_next_or_eof(buffer)` per packet (examples/decode_ogg.rs:105-114,
+// decode_mp4.rs:143-152) -- with the headers parsed on the host and all frames decoded on the device in one launch
+// (the batch entry next to read_next_or_eof).  Packet i is arena[offs[i] .. offs[i] + lens[i]).
+// Result i is what read_next_or_eof would return for it: a block, Ok(None) for a packet too short to hold a sync code
+// (the examples skip empty packets), or the reference's error.
+inline std::vector<FrameResult> decode_packets(clx_ctx* ctx, const uint8_t* arena, size_t arena_len, const uint64_t* offs,
+                                               const uint32_t* lens, size_t n, bool check_crc = true) {
+    std::vector<FrameResult> out(n);
+    std::vector<clx_frame_desc> descs(n);
+    std::vector<clx_frame_header> hdrs(n);
+    std::vector<clx_frame_result> hres(n);
+    if (n == 0) return out;
+    if (clx_describe_packets(arena, arena_len, offs, lens, n, check_crc ? 1 : 0, descs.data(), hdrs.data(), hres.data()) == CLX_API_ERROR) {
+        for (auto& r : out) { r.is_err = true; r.error = Error::from(CLX_API_ERROR, CLX_MSG_NONE); }
+        return out;
+    }
+    std::vector<size_t> which;                    // packets that go to the device
+    std::vector<clx_frame_desc> d2;
+    std::vector<uint64_t> out_offs;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (hres[i].status == CLX_END_OF_STREAM) continue;                                     // Ok(None), frame.rs:140-143
+        if (hres[i].status != CLX_OK) { out[i].is_err = true; out[i].error = Error::from(hres[i].status, hres[i].msg); continue; }
+        if (hdrs[i].bps == 0) { out[i].is_err = true; out[i].error = Error::from(CLX_UNSUPPORTED, CLX_MSG_NO_BPS_IN_HEADER); continue; }   // frame.rs:687-692
+        which.push_back(i); d2.push_back(descs[i]); out_offs.push_back(total);
+        total += (uint64_t)hdrs[i].block_size * hdrs[i].n_channels;
+    }
+    if (which.empty()) return out;
+    std::vector<int32_t> pcm((size_t)total);
+    std::vector<clx_frame_result> res(which.size());
+    const int st = clx_decode_frames(ctx, arena, arena_len, d2.data(), d2.size(), pcm.data(), out_offs.data(), res.data(),
+                                     check_crc ? CLX_VERIFY_CRC16 : 0u);
+    for (size_t j = 0; j < which.size(); ++j) {
+        FrameResult& r = out[which[j]];
+        const clx_frame_header& h = hdrs[which[j]];
+        if (st != CLX_OK) { r.is_err = true; r.error = Error::from(CLX_API_ERROR, CLX_MSG_NONE); r.error.text = clx_last_error(ctx); continue; }
+        if (res[j].status != CLX_OK) { r.is_err = true; r.error = Error::from(res[j].status, res[j].msg); continue; }
+        const size_t len = (size_t)h.block_size * h.n_channels;
+        r.has_block = true;
+        r.block = Block(h.time, h.block_size, std::vector<int32_t>(pcm.begin() + (ptrdiff_t)out_offs[j], pcm.begin() + (ptrdiff_t)(out_offs[j] + len)));
+    }
+    return out;
+}
 
 class FlacReader;
 

@@ -135,6 +135,57 @@ static void verify_into_samples(const char* name, const char* file) {
     std::printf("%s samples=%" PRIu64 "\n", name, count);
 }
 
+// decode_packets: the frames of a stream handed over as packets (one frame each, as a container demuxer does) decode to
+// the blocks that FlacReader::blocks() yields; an empty packet is Ok(None), a damaged one fails alone
+static void verify_decode_packets(const char* name, const char* file) {
+    std::vector<uint8_t> d;
+    {
+        std::FILE* f = std::fopen(path(file).c_str(), "rb");
+        CHECK(f != nullptr);
+        if (!f) return;
+        uint8_t buf[65536]; size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+        std::fclose(f);
+    }
+    clx_streaminfo si; size_t audio = 0; uint32_t msg = 0;
+    CHECK(clx_read_stream_header(d.data(), d.size(), &si, &audio, &msg) == CLX_OK);
+    std::vector<clx_frame_desc> descs(4096); std::vector<clx_frame_header> hdrs(4096);
+    size_t found = 0, stop = 0;
+    CHECK(clx_index_frames(d.data(), d.size(), audio, descs.data(), hdrs.data(), descs.size(), &found, &stop) == CLX_OK);
+    CHECK(found > 0 && stop == d.size());
+    std::vector<uint64_t> offs; std::vector<uint32_t> lens;
+    for (size_t i = 0; i < found; ++i) {
+        offs.push_back(descs[i].byte_off);
+        lens.push_back((uint32_t)((i + 1 < found ? descs[i + 1].byte_off : d.size()) - descs[i].byte_off));
+    }
+    offs.push_back(d.size()); lens.push_back(0);                                  // an empty packet at the end
+    std::vector<uint8_t> arena(d);
+    arena.resize(d.size() + 32, 0);
+    std::vector<claxon::FrameResult> got = claxon::decode_packets(g_ctx, arena.data(), d.size(), offs.data(), lens.data(), offs.size());
+    CHECK(got.size() == found + 1 && !got[found].is_err && !got[found].has_block);
+    auto r = claxon::FlacReader::open(g_ctx, path(file).c_str());
+    CHECK(r.is_ok());
+    if (!r.is_ok()) return;
+    uint64_t samples = 0;
+    for (size_t i = 0; i < found; ++i) {
+        claxon::FrameResult want = r.value.blocks().read_next_or_eof(std::vector<int32_t>());
+        CHECK(!want.is_err && want.has_block && !got[i].is_err && got[i].has_block);
+        if (want.is_err || !want.has_block || got[i].is_err || !got[i].has_block) return;
+        CHECK(got[i].block.time() == want.block.time() && got[i].block.duration() == want.block.duration() && got[i].block.channels() == want.block.channels());
+        for (uint32_t c = 0; c < want.block.channels(); ++c)
+            CHECK(std::memcmp(got[i].block.channel(c), want.block.channel(c), sizeof(int32_t) * want.block.duration()) == 0);
+        samples += got[i].block.len();
+    }
+    // a flipped bit in the first packet's body: that packet reports the frame CRC mismatch, the others still decode
+    if (lens[0] > 12) {
+        arena[offs[0] + lens[0] / 2] ^= 0x10;
+        std::vector<claxon::FrameResult> bad = claxon::decode_packets(g_ctx, arena.data(), d.size(), offs.data(), lens.data(), offs.size());
+        CHECK(bad[0].is_err);
+        for (size_t i = 1; i < found; ++i) CHECK(!bad[i].is_err && bad[i].has_block);
+    }
+    std::printf("%s packets=%zu samples=%" PRIu64 "\n", name, found, samples);
+}
+
 // the same audio through blocks(): Block accessors agree with each other (frame.rs:402-529)
 static void verify_blocks(const char* name, const char* file) {
     auto r = claxon::FlacReader::open(g_ctx, path(file).c_str());
@@ -273,6 +324,7 @@ int main(int argc, char** argv) {
     if (clx_create(0, &g_ctx) != CLX_OK) { std::fprintf(stderr, "no gfx950 device: this test decodes on the GPU\n"); return 3; }
     static const char* const files[][2] = { { "pop", "pop.flac" }, { "short", "short.flac" }, { "wasted_bits", "wasted_bits.flac" }, { "non_subset", "non_subset.flac" } };
     for (auto& f : files) verify_streaminfo((std::string("verify_streaminfo_") + f[0]).c_str(), f[1]);
+    for (auto& f : files) verify_decode_packets((std::string("verify_decode_packets_") + f[0]).c_str(), f[1]);
     for (auto& f : files) verify_into_samples((std::string("verify_into_samples_") + f[0]).c_str(), f[1]);
     for (auto& f : files) verify_decoded_stream((std::string("verify_decoded_stream_") + f[0]).c_str(), f[1]);
     for (auto& f : files) verify_blocks((std::string("verify_blocks_") + f[0]).c_str(), f[1]);
