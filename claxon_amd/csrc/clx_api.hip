@@ -1090,6 +1090,12 @@ FrameReader::FrameReader(clx_ctx* ctx, const uint8_t* data, size_t len) : impl_(
 FrameReader::FrameReader(FrameReader&& o) noexcept : impl_(o.impl_) { o.impl_ = nullptr; }
 FrameReader::~FrameReader() { delete impl_; }
 size_t FrameReader::position() const { return impl_->pos; }
+std::pair<std::vector<uint8_t>, size_t> FrameReader::into_inner() && {
+    std::pair<std::vector<uint8_t>, size_t> r(std::move(impl_->data), impl_->pos);
+    delete impl_;
+    impl_ = nullptr;
+    return r;
+}
 void FrameReader::set_batch_frames(size_t n) { impl_->batch_frames = n ? n : 1; }
 
 // Decode the next batch of frames starting at impl_->pos into the queue.

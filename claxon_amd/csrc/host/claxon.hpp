@@ -107,6 +107,10 @@ public:
     // recovered with Block::into_buffer().  Frames are decoded on the device in batches ahead of the caller.
     FrameResult read_next_or_eof(std::vector<int32_t> buffer);
     size_t position() const;              // bytes consumed from the stream handed to the constructor
+    // Destroys the frame reader and returns the underlying reader (frame.rs:782): here the stream's bytes and
+    // position() -- the end of the last frame decoded, which lies ahead of the last block handed out while blocks of the
+    // current device batch are still queued; equal to it once read_next_or_eof has returned the end of the stream.
+    std::pair<std::vector<uint8_t>, size_t> into_inner() &&;
     void set_batch_frames(size_t n);      // how many frames to index + decode per device batch
 private:
     Impl* impl_;

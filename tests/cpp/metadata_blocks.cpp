@@ -42,6 +42,11 @@ int main(int argc, char** argv) {
             ++i;
         }
         std::printf("%s end=%zu\n", argv[a], reader.position() + 4);
+        // FrameReader::new / into_inner (frame.rs:652, 782) need no device: nothing is decoded before the first read
+        claxon::FrameReader fr(nullptr, d.data(), d.size());
+        const size_t at = fr.position();
+        std::pair<std::vector<uint8_t>, size_t> inner = std::move(fr).into_inner();
+        if (at != 0 || inner.second != 0 || inner.first != d) { std::printf("%s into_inner mismatch\n", argv[a]); return 3; }
     }
     return 0;
 }
