@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define CLX_VERSION_MAJOR 0
-#define CLX_VERSION_MINOR 1
+#define CLX_VERSION_MINOR 2
 #define CLX_VERSION_PATCH 0
 
 /* ------------------------------------------------------------------------

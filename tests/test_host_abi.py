@@ -29,7 +29,7 @@ def test_exports_match_header(L):
 
 
 def test_version_and_messages(L):
-    assert L.clx_version() == (0 << 16) | (1 << 8) | 0
+    assert L.clx_version() == (0 << 16) | (2 << 8) | 0          # 0.2: metadata blocks, packet descriptors
     # every message id has a string and an error variant; spot-check strings the reference's tests compare
     for name, mid in MSG.items():
         if name in ("CLX_MSG_NONE", "CLX_MSG_COUNT"):
