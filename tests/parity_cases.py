@@ -200,6 +200,15 @@ def resync_workload():
                     for c in range(channels):
                         fp.sf[c] = synth.sf(synth.SF_FIXED, 0, 0, po, rice_param=k)
                     ws.append(synth.encode_frames("r", pcm, channels, bs, 16, [fp]))
+    # the same with the five-bit parameter field (Rice2, subframe.rs:358-380): small parameters take the same table path
+    for k in (0, 3, 5, 6, 15, 20):
+        stuck = 0 if k == 0 else -(1 << (min(k, 14) - 1))
+        for bs, po in ((512, 3), (100, 0)):
+            noise = rng.integers(-(1 << min(k, 13)), (1 << min(k, 13)) + 1, size=bs)
+            for v in (np.full(bs, stuck), noise, np.where(np.arange(bs) % 64 < 40, stuck, noise)):
+                fp = synth.FrameParams(0, 0, len(ws))
+                fp.sf[0] = synth.sf(synth.SF_FIXED, 0, 0, po, rice_param=k, force_rice2=1)
+                ws.append(synth.encode_frames("r2", np.asarray(v, dtype=np.int32)[None, None], 1, bs, 16, [fp]))
     return synth.concat("resync", ws)
 
 
