@@ -290,7 +290,9 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             // plus one per chunk of the longest run of chunks whose exit does depend on their entry -- no LDS traffic.
             uint32_t ent = (lane == 0) ? 0u : 0xffu;         // a span always begins at a code start; 0xff: not known yet
             uint32_t outv = (differs == 0u) ? (pat & 15u) : 0xffu;
+            CLX_STAT(56, lane == 0);                         // (simulator statistics: spans on the table path, rounds below)
             for (;;) {
+                CLX_STAT(57, lane == 0);
                 const uint32_t cand = (xlo >> ((ent & 7u) << 2)) & 15u;
                 if (outv == 0xffu && ent != 0xffu) outv = cand;
                 const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)outv, 0x138, 0xF, 0xF, true);   // wave_shr:1
@@ -299,6 +301,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             }
             my_entry = ent;
         } else {
+        CLX_STAT(58, lane == 0);                             // spans on the arithmetic-walk path
         const uint32_t ex0 = sent ? clx_chunk_exit<true>(cs, B, k, 0u) : clx_chunk_exit<false>(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
             uint32_t packed = 0;
