@@ -254,6 +254,9 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         const bool sent = B < 32u;                           // wave-uniform
         const uint32_t cs = sent ? (c | (0x80000000u >> B)) : c;
         uint32_t my_entry;
+#ifdef CLX_K1_PROP_CAP
+        bool need_walk_any = false;
+#endif
         if (use_lut) {
             const uint32_t nb = B >> 2;
             // The chunk's exit states stay in a register, a nibble per entry state, as the difference from state 0's
@@ -291,6 +294,35 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             uint32_t ent = (lane == 0) ? 0u : 0xffu;         // a span always begins at a code start; 0xff: not known yet
             uint32_t outv = (differs == 0u) ? (pat & 15u) : 0xffu;
             CLX_STAT(56, lane == 0);                         // (simulator statistics: spans on the table path, rounds below)
+#ifdef CLX_K1_PROP_CAP
+            // Experiment (not in the default build): at most CLX_K1_PROP_CAP rounds -- none for
+            // k >= CLX_K1_WALK_FROM --, then the exit states go to LDS and the three-level walk below resolves the entries.
+#ifndef CLX_K1_WALK_FROM
+#define CLX_K1_WALK_FROM 99u
+#endif
+            const uint32_t cap = k >= CLX_K1_WALK_FROM ? 0u : (uint32_t)(CLX_K1_PROP_CAP);
+            bool need_walk = cap == 0u;
+            for (uint32_t round = 0; !need_walk; ++round) {
+                CLX_STAT(57, lane == 0);
+                const uint32_t cand = (xlo >> ((ent & 7u) << 2)) & 15u;
+                if (outv == 0xffu && ent != 0xffu) outv = cand;
+                const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)outv, 0x138, 0xF, 0xF, true);   // wave_shr:1
+                if (ent == 0xffu) ent = pv;
+                if (__all(ent != 0xffu)) break;
+                if (round + 1u >= cap) need_walk = true;
+            }
+            my_entry = ent;
+            need_walk_any = need_walk;
+            if (need_walk) {                                 // a byte per entry state, as the arithmetic walks leave them
+                CLX_STAT(59, lane == 0);
+                uint32_t lo4 = xlo & 0xffffu, hi4 = xlo >> 16;
+                lo4 = (lo4 | (lo4 << 8)) & 0x00ff00ffu; lo4 = (lo4 | (lo4 << 4)) & 0x0f0f0f0fu;
+                hi4 = (hi4 | (hi4 << 8)) & 0x00ff00ffu; hi4 = (hi4 | (hi4 << 4)) & 0x0f0f0f0fu;
+                *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][0]) = lo4;
+                *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4]) = hi4;
+            }
+        } else {
+#else
             for (;;) {
                 CLX_STAT(57, lane == 0);
                 const uint32_t cand = (xlo >> ((ent & 7u) << 2)) & 15u;
@@ -301,6 +333,7 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             }
             my_entry = ent;
         } else {
+#endif
         CLX_STAT(58, lane == 0);                             // spans on the arithmetic-walk path
         const uint32_t ex0 = sent ? clx_chunk_exit<true>(cs, B, k, 0u) : clx_chunk_exit<false>(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
@@ -315,6 +348,10 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             }
             *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4u * g]) = packed;     // states 4g .. 4g+3 (little endian)
         }
+#ifdef CLX_K1_PROP_CAP
+        }
+        if (!use_lut || need_walk_any) {
+#endif
         __syncthreads();
         CLX_TL_PHASE(1);                   // exit tables
         // (2a) group tables: lane (g8, e) walks group g8's 8 chunks for entry states e, e+8, ...
