@@ -17,7 +17,28 @@ static const char* kind_name(claxon::MetadataBlock::Kind k) {
     }
 }
 
+// tests/testsamples.rs:404-426 (verify_limits_on_vendor_string, verify_limits_on_vorbis_comment_block) against
+// FlacReader::open: both files fail while the metadata is read, before anything would be decoded -- no device needed.
+static int verify_limits(const std::string& dir) {
+    int bad = 0;
+    {
+        auto r = claxon::FlacReader::open(nullptr, (dir + "/large_vendor_string.flac").c_str());
+        claxon::Error want; want.kind = claxon::ErrorKind::FormatError; want.text = "vendor string too long";
+        const bool ok = !r.is_ok() && r.error == want;
+        std::printf("verify_limits_on_vendor_string %s (%s)\n", ok ? "ok" : "FAILED", r.error.text.c_str());
+        bad += !ok;
+    }
+    {
+        auto r = claxon::FlacReader::open(nullptr, (dir + "/large_vorbis_comment_block.flac").c_str());
+        const bool ok = !r.is_ok() && r.error.kind == claxon::ErrorKind::Unsupported;
+        std::printf("verify_limits_on_vorbis_comment_block %s (%s)\n", ok ? "ok" : "FAILED", r.error.text.c_str());
+        bad += !ok;
+    }
+    return bad;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 3 && std::string(argv[1]) == "--limits") return verify_limits(argv[2]) ? 4 : 0;
     for (int a = 1; a < argc; ++a) {
         std::FILE* f = std::fopen(argv[a], "rb");
         if (!f) { std::printf("%s: cannot open\n", argv[a]); return 2; }

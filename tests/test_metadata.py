@@ -50,6 +50,16 @@ def both(oracle, data, **opt):
     return p
 
 
+def test_limits_fixtures_match_reference_tests(oracle):
+    """tests/testsamples.rs:404-426: a vendor string that would not fit in its block is a FormatError with this very
+    message; a Vorbis comment block that claims 16 MB is Unsupported (no allocation is attempted).  Both files have no
+    STREAMINFO in front: the block is read first, its error wins (lib.rs:244-248)."""
+    st, msg, *_ = both(oracle, fixture("large_vendor_string.flac"))
+    assert st == cx.FORMAT_ERROR and cx.message(msg) == "vendor string too long"                     # testsamples.rs:412
+    st, msg, *_ = both(oracle, fixture("large_vorbis_comment_block.flac"))
+    assert st == cx.UNSUPPORTED and cx.message(msg) == "Vorbis comment blocks larger than 10 MiB are not supported"   # testsamples.rs:423
+
+
 def test_fixture_tags_match_reference_tests(oracle):
     st, msg, si, off, vendor, tags = both(oracle, fixture("repeated_vorbis_comment.flac"))
     assert st == cx.OK and (b"FOO", b"bar") in tags and (b"FOO", b"baz") in tags

@@ -198,3 +198,18 @@ def test_cpp_metadata_block_reader(oracle):
                 assert mine[-1] == "end=%d" % end
         assert any("kind=Application" in l and "id=41424344 data_len=3" in l for l in lines)
         assert any("cut.flac" in l and "error status=%d" % cx.IO_ERROR in l for l in lines)
+
+
+def test_cpp_reader_limits_match_reference_tests():
+    """verify_limits_on_vendor_string / verify_limits_on_vorbis_comment_block (tests/testsamples.rs:404-426) against the
+    C++ mirror's FlacReader::open -- the files fail in the metadata, so the check runs without a device."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as g
+    cx.build()
+    exe = g.build_cpp_metadata_test()
+    r = subprocess.run([exe, "--limits", FIXTURES], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verify_limits_on_vendor_string ok (vendor string too long)" in r.stdout
+    assert "verify_limits_on_vorbis_comment_block ok (Vorbis comment blocks larger than 10 MiB are not supported)" in r.stdout
