@@ -4,6 +4,7 @@
 //   usage: metadata_blocks <file.flac>...
 #include <cinttypes>
 #include <cstdio>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -37,8 +38,34 @@ static int verify_limits(const std::string& dir) {
     return bad;
 }
 
+// verify_block_sample / verify_block_stereo_samples_iterator (frame.rs:531-543, 582-597) on claxon::Block.  (The
+// reference's second test builds a two-channel block over a longer buffer; here the channel count follows from the
+// buffer, so the block holds the six samples the iterator visits.)
+static int verify_block() {
+    int bad = 0;
+    claxon::Block b(0, 5, std::vector<int32_t>{ 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47 });
+    bad += !(b.sample(0, 2) == 5 && b.sample(1, 3) == 23 && b.sample(2, 4) == 47);
+    bad += !(b.len() == 15 && b.duration() == 5 && b.channels() == 3 && b.time() == 0 && b.channel(1)[0] == 13);
+    bool threw = false;
+    try { (void)b.stereo_samples(); } catch (const std::logic_error&) { threw = true; }      // frame.rs:517-519 panics
+    bad += !threw;
+    claxon::Block s(0, 3, std::vector<int32_t>{ 2, 3, 5, 7, 11, 13 });
+    claxon::StereoSamples it = s.stereo_samples();
+    std::pair<int32_t, int32_t> p;
+    const std::pair<int32_t, int32_t> want[3] = { { 2, 7 }, { 3, 11 }, { 5, 13 } };
+    for (int i = 0; i < 3; ++i) bad += !(it.next(&p) && p == want[i]);
+    bad += it.next(&p) ? 1 : 0;
+    claxon::Block e = claxon::Block::empty();
+    bad += !(e.len() == 0 && e.channels() == 0 && e.duration() == 0);
+    std::vector<int32_t> back = std::move(s).into_buffer();
+    bad += !(back.size() == 6 && back[5] == 13);
+    std::printf(bad ? "block accessors FAILED (%d)\n" : "block accessors ok\n", bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     if (argc == 3 && std::string(argv[1]) == "--limits") return verify_limits(argv[2]) ? 4 : 0;
+    if (argc == 2 && std::string(argv[1]) == "--block") return verify_block() ? 5 : 0;
     for (int a = 1; a < argc; ++a) {
         std::FILE* f = std::fopen(argv[a], "rb");
         if (!f) { std::printf("%s: cannot open\n", argv[a]); return 2; }

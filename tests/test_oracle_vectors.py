@@ -188,3 +188,26 @@ def test_block_planar_indexing():
     assert buf[0 * bs + 2] == 5 and buf[1 * bs + 3] == 23 and buf[2 * bs + 4] == 47
     bs = 3  # stereo_samples iterator yields (buffer[i], buffer[i+bs])
     assert [(buf[i], buf[i + bs]) for i in range(bs)] == [(2, 7), (3, 11), (5, 13)]
+
+
+def test_block_accessors_of_the_host_mirrors():
+    """verify_block_sample / verify_block_stereo_samples_iterator (frame.rs:531-543, 582-597) on the product's own Block
+    classes: the Python one here, the C++ one in tests/cpp/metadata_blocks.cpp (--block; host only)."""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import claxon_amd as cx
+    import __graft_entry__ as g
+    buf = np.array([2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47], dtype=np.int32)
+    b = cx.Block(0, 5, 3, buf)
+    assert (b.sample(0, 2), b.sample(1, 3), b.sample(2, 4)) == (5, 23, 47)
+    assert (b.len(), b.duration(), b.channels(), b.time()) == (15, 5, 3, 0)
+    assert list(b.channel(1)) == [13, 17, 19, 23, 29]
+    with pytest.raises(ValueError):
+        b.stereo_samples()                                         # frame.rs:517-519: panics unless there are two channels
+    s = cx.Block(0, 3, 2, buf)
+    assert list(s.stereo_samples()) == [(2, 7), (3, 11), (5, 13)]
+    cx.build()
+    r = subprocess.run([g.build_cpp_metadata_test(), "--block"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "block accessors ok" in r.stdout, r.stdout + r.stderr
