@@ -1,13 +1,21 @@
 #!/usr/bin/env python
 """bench.py -- decoded Msamples/s of the batched FLAC frame decode hot path on MI355X.
 
-A "step" = one pass of the hot path (K1 Rice/residual decode, K2 predictor + decorrelation) over one
-batch of synthetic frames whose compressed bytes, descriptors and output buffer are already resident
-in HBM.  Workload at every N: BASELINE.json configs[2] -- 10 000 stereo 16-bit frames, block size
-4096, mid/side, both subframes LPC order 8 (SURVEY.md §8d "config 3") -- per GPU (weak scaling:
-frames are independent, ranks share nothing, no collective on the data path).
+A "step" = one pass of the hot path (Rice/residual decode, predictor synthesis, stereo decorrelation) over one batch of
+synthetic frames whose compressed bytes, descriptors and output buffer are already resident in HBM.
 
-One JSON line on rank 0; see DESIGN.md §6 for how roofline / cpu_baseline are derived.
+Workloads (`--workload`):
+  config3 (default, the configuration BASELINE.json's metric is quoted on): 10 000 stereo 16-bit frames per GPU, block size
+          4096, mid/side, both subframes LPC order 8.  At N GPUs the job is ONE frame index of N x 10 000
+          frames (frame g is seeded by g), cut into contiguous ranges by claxon_amd.shard.balanced_ranges; rank r generates
+          and uploads only its range (weak scaling: the per-GPU share is fixed).
+  config2 / config4: the other single-GPU BASELINE shapes (parity-test cases; here for profiling them).
+  config5: `--total-frames` (default 1 000 000) mixed real-world-shaped frames, `--unique` (default 16 384) unique frames
+          tiled with distinct frame numbers / CRCs, sharded over the ranks by algorithmic bytes (strong scaling: the total is
+          fixed).  `--shard-of N --shard-rank r` runs rank r's share of an N-way split on one GPU without a process group.
+Frames are independent: ranks share nothing and there is no collective on the data path (barrier + MAX/SUM reductions only).
+
+One JSON line on rank 0; DESIGN.md section 5 says how `roofline` and `cpu_baseline` are derived.
 """
 import argparse
 import json
@@ -20,21 +28,29 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config: 10000)")
+    ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config3")
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU for config2/3/4 (BASELINE: 10000)")
+    ap.add_argument("--total-frames", type=int, default=1000000, help="config5: frames of the whole job")
+    ap.add_argument("--unique", type=int, default=16384, help="config5: unique frames that are tiled")
+    ap.add_argument("--shard-of", type=int, default=0, help="config5 on one GPU: pretend to be one rank of this many")
+    ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify-crc", action="store_true", help="also run the CRC-16 kernel inside the step")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (CRC-16 step, host-buffer rates)")
     ap.add_argument("--path", choices=["auto", "waves", "lanes"], default="auto", help="kernel path (default: library's choice)")
     args = ap.parse_args()
 
     import torch
     import claxon_amd as cx
     import synth
+    from claxon_amd import shard
     dist = None
 
     rank = int(os.environ.get("RANK", "0"))
@@ -51,77 +67,108 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    # ---- synthetic workload for this rank (distinct seeds per rank: frame indices are offset)
+    # ---- this rank's share of the job's frame index
     t_gen = time.time()
-    w = synth.config3(args.frames) if rank == 0 else _config3_shard(synth, args.frames, rank)
+    sh_world, sh_rank = (args.shard_of, args.shard_rank) if (args.shard_of and world == 1) else (world, rank)
+    shard_info = {"ranks": sh_world, "rank": sh_rank}
+    expected = None                                  # (unique pcm on the device, index of each local frame's unique frame)
+    if args.workload == "config5":
+        ts = synth.config5_tiled(args.total_frames, args.unique)
+        ranges = shard.balanced_ranges(ts.weights(), sh_world)
+        lo, hi = ranges[sh_rank]
+        w = ts.slice(lo, hi)
+        wsum = [int(ts.weights()[a:b].sum()) for a, b in ranges]
+        shard_info.update({"plan": "shard.balanced_ranges over algorithmic bytes of %d frames (%d unique)" % (ts.total, ts.unique.n),
+                           "range": [int(lo), int(hi)], "imbalance": round(max(wsum) / (sum(wsum) / len(wsum)) - 1.0, 5)})
+        workload_name = ("BASELINE configs[4]: %d mixed real-world-shaped stereo 16-bit frames (orders 0-12, all channel modes, "
+                         "%d unique frames tiled with distinct frame numbers / CRCs), rank share %d frames"
+                         % (ts.total, ts.unique.n, hi - lo))
+        scaling = "strong"
+    else:
+        lo, hi = sh_rank * args.frames, (sh_rank + 1) * args.frames
+        gen = {"config2": synth.config2, "config3": synth.config3, "config4": synth.config4}[args.workload]
+        w = _seeded(synth, gen, args.frames, lo)
+        # the ranges are what balanced_ranges gives for the job's index: every frame of these shapes has the same decoded size
+        # and (to within a percent) the same compressed size; the check below makes that an assertion, not a belief
+        shard_info.update({"plan": "contiguous ranges of %d frames of one index of %d (frame g seeded by g)" % (args.frames, sh_world * args.frames),
+                           "range": [int(lo), int(hi)]})
+        workload_name = {
+            "config2": "BASELINE configs[1]: %d mono 16-bit subframes/GPU, bs 4096, FIXED order 2, Rice k=4, one partition",
+            "config3": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 (precision 12), Rice partition order 4, optimal k",
+            "config4": "BASELINE configs[3]: %d stereo 24-bit frames/GPU, bs 4096, LPC order 32, mixed partition orders 0-7, Rice2, wasted bits",
+        }[args.workload] % args.frames
+        scaling = "weak"
     gen_s = time.time() - t_gen
-    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
+    if w.bare_subframes:
+        descs = cx.descs_for_subframes(w.offs, w.block_sizes, w.bps)
+    else:
+        descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
 
     d_arena = torch.from_numpy(w.arena).to(dev)
-    d_out = torch.zeros(w.pcm.size, dtype=torch.int32, device=dev)
+    d_out = torch.zeros(w.total_samples, dtype=torch.int32, device=dev)
     path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES}[args.path]
-    batch = ctx.plan(descs, w.out_offs, verify_crc=args.verify_crc, path=path)
+    batch = ctx.plan(descs, w.out_offs, verify_crc=False, path=path)
     stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():
-        batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    def timed(b, steps):
+        """`steps` passes of batch b, bracketed by barrier + synchronize on both sides; seconds (this rank)."""
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
+        torch.cuda.synchronize(); barrier()
+        return time.perf_counter() - t0
+
     for _ in range(args.warmup):
-        step()
+        batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
     torch.cuda.synchronize()
 
     # ---- parity gate before anything is timed: statuses OK and bit-exact vs the source PCM
     res = batch.results()
-    ok = bool(np.all(res["status"] == 0)) and bool(torch.equal(d_out, torch.from_numpy(w.pcm).to(dev)))
-    if not ok:
+    if w.pcm is not None:
+        same = bool(torch.equal(d_out, torch.from_numpy(w.pcm).to(dev)))
+    else:
+        same = _tiled_equal(torch, d_out, w, ts.unique, dev)
+    if not (bool(np.all(res["status"] == 0)) and same):
         raise SystemExit("bench: decode is not bit-exact; refusing to report a number")
 
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(batch, args.steps)
     # whole-job figures: MAX elapsed over ranks, SUM of samples per step, SUM of failed frames (must be 0)
-    from claxon_amd import shard
     res = batch.results()
-    elapsed, samples_per_step_all, n_bad = shard.reduce_job(dist if world > 1 else None, elapsed, w.total_samples,
-                                                            int((res["status"] != 0).sum()), device=dev)
+    elapsed, samples_all, n_bad = shard.reduce_job(dist if world > 1 else None, elapsed, w.total_samples,
+                                                   int((res["status"] != 0).sum()), device=dev)
     if n_bad:
         raise SystemExit("bench: %d frames failed to decode in the timed region" % n_bad)
     ms_per_step = 1e3 * elapsed / args.steps
-    value = samples_per_step_all / (ms_per_step * 1e-3) / 1e6
+    value = samples_all / (ms_per_step * 1e-3) / 1e6
+    if world > 1:      # how even the shares were (algorithmic bytes): max over ranks / mean
+        t = torch.tensor([float(w.algorithmic_bytes)], dtype=torch.float64, device=dev)
+        mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        shard_info["imbalance"] = round(float(mx.item()) / (float(t.item()) / world) - 1.0, 5)
 
-    # ---- per-kernel durations (HIP events recorded by the library on the launch stream)
-    batch.set_profiling(True)
-    acc = {}
-    reps = max(5, min(args.steps, 20))
-    for _ in range(reps):
-        step()
-        torch.cuda.synchronize()
-        for name, ms in batch.kernel_times().items():
-            acc.setdefault(name, []).append(ms)
-    batch.set_profiling(False)
-    kernel_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+    # ---- per-kernel durations: HIP events recorded by the library on the launch stream, around each of its kernels
+    kernel_ms = _kernel_ms(torch, batch, lambda: batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
+    path_ms = float(sum(kernel_ms.values()))             # all kernels of the path (SURVEY section 8d's t_kernel)
     dom_name = max(kernel_ms, key=kernel_ms.get)
-    dom_ms = kernel_ms[dom_name]
-    alg_bytes = w.algorithmic_bytes          # compressed bytes read once + 4 B per decoded sample written once
-    peak = 8000.0                            # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = _pmc_traffic(dom_name, args.frames)
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
-                "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+    alg_bytes = w.algorithmic_bytes                      # compressed bytes read once + 4 B per decoded sample written once
+    achieved = alg_bytes / (path_ms * 1e-3) / 1e9
+    traffic, traffic_src = _pmc_traffic(args.workload, w.n)
+    roofline = {"bound": "hbm", "kernel": "+".join(kernel_ms.keys()), "achieved": round(achieved, 1), "peak": PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "path_ms": round(path_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "dominant_kernel": {"name": dom_name, "ms": round(kernel_ms[dom_name], 4),
+                                    "note": "one of the path's kernels; the path's bytes over its time alone would overstate it"},
                 "step_achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / peak, 4)}
+                "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_GBS, 4)}
 
-    # achievable-copy ceiling of this box: device-to-device copy of 1 GiB, read + write bytes
-    if rank == 0:
+    extras = rank == 0 and not args.no_extras
+    if extras:
+        # achievable-copy ceiling of this box (SURVEY section 8d): device-to-device copy of 1 GiB, read + write bytes
         src = torch.empty(1 << 28, dtype=torch.int32, device=dev); dst = torch.empty_like(src)
         dst.copy_(src); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -134,97 +181,203 @@ def main():
         roofline["frac_of_copy_ceiling"] = round(achieved / copy_gbs, 4)
         del src, dst
 
+    cfg = {"workload": workload_name, "frames_this_rank": w.n, "samples_per_step": samples_all,
+           "compressed_bytes_this_rank": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
+           "parallelism": "one frame index sharded over %d GPU(s), no collective on the data path" % world, "shard": shard_info,
+           "bit_exact": True, "crc16_in_step": False, "kernel_path": args.path, "gen_seconds": round(gen_s, 1)}
     out = {
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i32 (i64 LPC accumulate)", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 "
-                               "(precision 12), Rice partition order 4, optimal k" % args.frames,
-                   "frames_per_gpu": args.frames, "samples_per_step": samples_per_step_all,
-                   "compressed_bytes_per_gpu": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
-                   "parallelism": "frames sharded across %d GPU(s), no collective" % world,
-                   "bit_exact": True, "crc16_in_step": bool(args.verify_crc), "kernel_path": args.path, "gen_seconds": round(gen_s, 1)},
-        "roofline": roofline,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "i32 (i64 LPC accumulate)", "data": "synthetic", "config": cfg, "roofline": roofline,
     }
-    if rank == 0 and world == 1:
-        out["config"]["pcie_inclusive"] = _pcie_inclusive(ctx, w, descs)
+
+    if not w.bare_subframes and not args.no_extras:
+        # ---- the same step with every frame's CRC-16 verified on the device (frame.rs:752-763: the reference always does);
+        #      this is the figure that corresponds to the cpu_baseline leg, which also verifies
+        bc = ctx.plan(descs, w.out_offs, verify_crc=True, path=path)
+        bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        rc = bc.results()
+        el_c = timed(bc, args.steps)
+        el_c, samples_c, bad_c = shard.reduce_job(dist if world > 1 else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=dev)
+        kc = _kernel_ms(torch, bc, lambda: bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
+        bc.close()
+        if bad_c == 0:
+            ms_c = 1e3 * el_c / args.steps
+            cfg["with_crc16"] = {"value": round(samples_c / (ms_c * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
+                                 "kernel_ms": {k: round(v, 4) for k, v in kc.items()},
+                                 "note": "CLX_VERIFY_CRC16: every frame's CRC-16 footer checked on the device inside the step"}
+    if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
+        cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = _cpu_baseline(w)
     if rank == 0:
         print(json.dumps(out))
+    batch.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def _config3_shard(synth, n, rank):
-    """Rank r decodes frames with PCM seeds offset by r*n (distinct data, same distribution)."""
+def _seeded(synth, gen, n, first):
+    """Frames [first, first + n) of the job's index: frame g's PCM comes from seed BASE_SEED + g."""
     base = synth.BASE_SEED
-    synth.BASE_SEED = base + rank * 1_000_003
+    synth.BASE_SEED = base + first
     try:
-        return synth.config3(n)
+        return gen(n)
     finally:
         synth.BASE_SEED = base
 
 
-def _pcie_inclusive(ctx, w, descs):
-    """The same batch through the one-shot entry that takes and returns HOST buffers (clx_decode_frames: H2D of the
-    compressed bytes, decode, D2H of the PCM, device buffers allocated inside the call): the rate a caller without
-    device-resident data sees.  Reported next to `value`, never as it (SURVEY section 8d "second figure").  Best of 3."""
+def _tiled_equal(torch, d_out, w, unique, dev):
+    """d_out == the unique frames' PCM tiled in this rank's order (all frames of config 5 have the same size)."""
+    per = int(unique.channels[0]) * int(unique.block_sizes[0])
+    exp = torch.from_numpy(unique.pcm.reshape(unique.n, per)).to(dev)
+    idx = torch.from_numpy(w.expected_index).to(dev)
+    got = d_out.view(-1, per)
+    ok = True
+    for a in range(0, got.shape[0], 8192):
+        ok = ok and bool(torch.equal(got[a:a + 8192], exp[idx[a:a + 8192]]))
+    return ok
+
+
+def _kernel_ms(torch, batch, step, steps):
+    batch.set_profiling(True)
+    acc = {}
+    for _ in range(max(5, min(steps, 20))):
+        step()
+        torch.cuda.synchronize()
+        for name, ms in batch.kernel_times().items():
+            acc.setdefault(name, []).append(ms)
+    batch.set_profiling(False)
+    return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def _host_buffer_rates(ctx, cx, w, descs):
+    """The same batch handed over in HOST memory (SURVEY section 8d "second figure"; never `value`)."""
+    out = {}
     try:
         arena = w.arena[:w.arena_len]
-        out = np.zeros(w.pcm.size, dtype=np.int32)
+        host = np.zeros(w.pcm.size, dtype=np.int32)
         best = None
         for _ in range(3):
             t = time.perf_counter()
-            _, res = ctx.decode_frames(arena, descs, w.out_offs, out=out)
+            _, res = ctx.decode_frames(arena, descs, w.out_offs, out=host)
             dt = time.perf_counter() - t
-            if not (np.all(res["status"] == 0) and np.array_equal(out, w.pcm)):
+            if not (np.all(res["status"] == 0) and np.array_equal(host, w.pcm)):
                 return {"error": "host-buffer decode is not bit-exact"}
             best = dt if best is None else min(best, dt)
-        return {"value": round(w.total_samples / best / 1e6, 1), "unit": "Msamples/s", "ms": round(best * 1e3, 3),
-                "h2d_bytes": int(w.arena_len), "d2h_bytes": int(4 * w.total_samples),
-                "note": "pageable host buffers, device buffers allocated per call; best of 3"}
-    except Exception as e:                      # never let the secondary figure take the bench line down
-        return {"error": "%s: %s" % (type(e).__name__, e)}
+        out["one_shot_pageable"] = {"value": round(w.total_samples / best / 1e6, 1), "unit": "Msamples/s", "ms": round(best * 1e3, 3),
+                                    "h2d_bytes": int(w.arena_len), "d2h_bytes": int(4 * w.total_samples),
+                                    "note": "clx_decode_frames: pageable host buffers, device buffers allocated per call, i32 D2H; best of 3"}
+        if hasattr(ctx, "pipeline_rates"):
+            out.update(ctx.pipeline_rates(w, descs))
+    except Exception as e:                      # never let a secondary figure take the bench line down
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
+def _cpu_topology():
+    """(all hardware threads, one hardware thread per physical core), from sysfs; falls back to 0..n-1."""
+    n = os.cpu_count() or 1
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(n))
+    firsts = []
+    for c in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                sib = f.read().strip().replace("-", ",").split(",")
+            if int(sib[0]) == c:
+                firsts.append(c)
+        except Exception:
+            return allowed, allowed
+    return allowed, (firsts or allowed)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except Exception:
+        return None
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def _cpu_baseline(w):
-    """The oracle (a C restatement of Claxon's decode path, `kind: port`; real Claxon is Rust and cannot be
-    built here) on this box's host cores, decoding the same arena from memory with per-thread recycled output
-    buffers (examples/bench_decode.rs:55-78 methodology)."""
+    """The oracle (a C restatement of Claxon's decode path, `kind: port`; real Claxon is Rust and cannot be built here) on
+    this box's host cores, decoding the same arena from memory with per-thread recycled output buffers
+    (examples/bench_decode.rs:55-78), verifying every CRC as the reference does.  Threads are created, pinned and warmed by an
+    untimed pass before the clock starts; the timed region is a number of passes over the frames that lasts >= 0.5 s
+    (tools/benchmark.sh:39-41 methodology).  Three thread counts: 1, one per physical core, every hardware thread."""
     import oracle
-    ncpu = os.cpu_count() or 1
     arena = w.arena[:w.arena_len]
+    # a bounded sample of the step's workload: the first frames of it, enough for every thread to have a few
+    n = min(w.n, 10000)
+    offs, lens = w.offs[:n], w.lens[:n]
+    all_cpus, core_cpus = _cpu_topology()
 
-    def run(nthreads, reps):
-        best = 0.0
-        for _ in range(reps):
-            t = time.perf_counter()
-            r = oracle.decode_batch(arena, w.offs, w.lens, check_crc=True, nthreads=nthreads, want_results=False)
-            dt = time.perf_counter() - t
-            assert r["samples"] == w.total_samples
-            best = max(best, r["samples"] / dt / 1e6)
-        return best
+    def throttled():
+        try:
+            with open("/sys/fs/cgroup/cpu.stat") as f:
+                return {k: int(v) for k, v in (line.split() for line in f)}.get("throttled_usec", 0)
+        except Exception:
+            return None
 
-    run(1, 1)                                   # warm
-    single = run(1, 3)
-    multi = run(ncpu, 5) if ncpu > 1 else single
-    return {"value": round(multi, 1), "unit": "Msamples/s", "cores": ncpu, "kind": "port",
-            "single_thread": round(single, 1),
-            "sample": "the full step workload (%d frames = %.1f Msamples), best of 5 passes on %d threads; "
-                      "single_thread = best of 3 passes on 1 thread; includes Claxon's per-byte CRC-16" %
-                      (w.n, w.total_samples / 1e6, ncpu)}
+    def run(nt, cpus, budget_s):
+        s1, t1 = oracle.bench_batch(arena, offs, lens, check_crc=True, nthreads=nt, passes=1, cpus=cpus)
+        passes = int(min(max(1, np.ceil(0.6 / max(t1, 1e-6))), max(1, budget_s / max(t1, 1e-6))))
+        th0 = throttled()
+        s, t = oracle.bench_batch(arena, offs, lens, check_crc=True, nthreads=nt, passes=passes, cpus=cpus)
+        th1 = throttled()
+        r = {"threads": nt, "pinned": cpus is not None, "value": round(s / t / 1e6, 1), "passes": passes, "timed_s": round(t, 2),
+             "first_pass_value": round(s1 / t1 / 1e6, 1)}
+        if th0 is not None and th1 is not None:
+            r["cgroup_throttled_ms"] = round((th1 - th0) / 1e3, 1)
+        return r
+
+    single = run(1, core_cpus[:1], 4.0)
+    runs = [single]
+    if len(core_cpus) > 1:
+        runs.append(run(len(core_cpus), core_cpus, 5.0))          # one thread per physical core, pinned
+        runs.append(run(len(core_cpus), None, 5.0))               # the same number, placed by the scheduler
+    if len(all_cpus) > len(core_cpus):
+        runs.append(run(len(all_cpus), None, 5.0))                # every hardware thread
+    best = max(runs, key=lambda r: r["value"])
+    for r in runs:
+        r["parallel_efficiency"] = round(r["value"] / (single["value"] * r["threads"]), 3)
+    sample_msamples = float((w.channels[:n].astype(np.int64) * w.block_sizes[:n].astype(np.int64)).sum()) / 1e6
+    return {"value": best["value"], "unit": "Msamples/s", "cores": best["threads"], "kind": "port",
+            "single_thread": single["value"], "runs": runs,
+            "cpu_model": _cpu_model(), "hardware_threads": len(all_cpus), "physical_cores": len(core_cpus), "verifies_crc16": True,
+            "cgroup_cpu_max": _read("/sys/fs/cgroup/cpu.max"),
+            "sample": "the first %d frames of the step's workload (%.1f Msamples per pass), `passes` passes per run (>= 0.5 s timed each); "
+                      "pooled, pre-warmed threads that take 4 frames at a time off a shared counter (first_pass_value: the single calibration "
+                      "pass before it; cgroup_throttled_ms: CPU time the container's quota withheld during the run); includes Claxon's per-byte CRC-16 and "
+                      "the CRC-8 / CRC-16 checks -- compare with config.with_crc16 (the GPU step that verifies too)" % (n, sample_msamples)}
 
 
-def _pmc_traffic(kernel, frames):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary of this same workload size, if there is one."""
+def _pmc_traffic(workload, frames):
+    """HBM bytes per step from a committed rocprofv3 --pmc summary of this workload at this size (profiles/pmc_traffic.json:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the path's kernels, collected in separate --pmc passes), or null.  The
+    counters cannot be read from inside this process; the source (profile directory + commit) travels with the number."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get("frames_%d" % frames, {}).get(kernel)
+            e = json.load(f).get("%s_frames_%d" % (workload, frames))
+        if e:
+            return e.get("path_bytes"), e.get("source")
     except Exception:
-        return None
+        pass
+    return None, None
 
 
 if __name__ == "__main__":

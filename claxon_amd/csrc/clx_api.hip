@@ -219,15 +219,12 @@ struct clx_ctx {
     std::string last_error;
 };
 
-// K2 build by batch size (groups of 64 predictor slots); env CLX_K2_LATENCY_GROUPS overrides it for experiments
-static unsigned k2_latency_groups() {
-    static const unsigned v = [] { const char* e = std::getenv("CLX_K2_LATENCY_GROUPS"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 512u; }();
-    return v;
-}
-#define CLX_K2_LATENCY_GROUPS k2_latency_groups()
+// K2 build by batch size (groups of 64 predictor slots) unless CLX_K2_LATENCY / CLX_K2_THROUGHPUT force one
+#define CLX_K2_LATENCY_GROUPS 512u
 
 struct clx_batch {
     clx_ctx* ctx = nullptr;
+    int device = 0;
     size_t n = 0;
     uint64_t n_slots = 0;
     uint32_t flags = 0;
@@ -293,7 +290,7 @@ extern "C" const char* clx_last_error(const clx_ctx* ctx) { return ctx ? ctx->la
 
 extern "C" void clx_batch_destroy(clx_batch* b) {
     if (!b) return;
-    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    (void)hipSetDevice(b->device);      // (by value: a batch destroyed after its context must not look into it)
     if (b->d_frames) (void)hipFree(b->d_frames);
     if (b->d_sfd) (void)hipFree(b->d_sfd);
     if (b->d_results) (void)hipFree(b->d_results);
@@ -315,7 +312,7 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     clx_batch* b = new (std::nothrow) clx_batch();
     if (!b) return CLX_API_ERROR;
-    b->ctx = ctx; b->n = n; b->flags = flags;
+    b->ctx = ctx; b->device = ctx->device; b->n = n; b->flags = flags;
     b->h_descs.assign(frames, frames + n);
     b->h_frames.resize(n ? n : 1);
     uint64_t slot = 0;
@@ -399,8 +396,14 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         if (name) b->kname[nk] = name;
         return hip_ok(ctx, hipEventRecord(b->ev[nk++], stream), "hipEventRecord");
     };
-    if (b->lanes) {
-        if ((uint64_t)arena_len + 32ull >= (1ull << 32)) { ctx->last_error = "CLX_PATH_LANES needs arena_len < 4 GiB"; return CLX_API_ERROR; }
+    // the lane kernels address the arena with 32-bit offsets: an explicit CLX_PATH_LANES fails beyond 4 GiB, a batch that
+    // only defaulted to them runs the wave kernels instead (their buffers exist for every batch)
+    bool lanes = b->lanes;
+    if (lanes && (uint64_t)arena_len + 32ull >= (1ull << 32)) {
+        if (b->flags & CLX_PATH_LANES) { ctx->last_error = "CLX_PATH_LANES needs arena_len < 4 GiB"; return CLX_API_ERROR; }
+        lanes = false;
+    }
+    if (lanes) {
         HIP_TRY(ctx, hipMemsetAsync(b->d_errkey, 0xff, b->n * sizeof(uint32_t), stream));
         HIP_TRY(ctx, hipMemsetAsync(b->d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream));
         if (b->n_multi) {
@@ -409,12 +412,10 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
                                (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi,
                                b->d_sf_start, b->d_errkey);
         }
-        if (!mark("clx_k_lanes")) return CLX_API_ERROR;
         // the two-wave (latency) build while its workgroups get a CU each (0.50 ms against 1.00 ms at 20k subframes), the fused
-        // single-wave (throughput) build beyond (1.28 against 1.34 ms at 48k subframes); CLX_LANES_BUILD=fused|split forces one
-        static const int forced = [] { const char* e = std::getenv("CLX_LANES_BUILD"); return !e ? 0 : e[0] == 'f' ? 1 : e[0] == 's' ? 2 : 0; }();
-        const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false
-                         : forced == 2 || (forced == 0 && b->n_slots <= 32768);
+        // single-wave (throughput) build beyond (1.28 against 1.34 ms at 48k subframes); CLX_LANES_FUSED / CLX_LANES_SPLIT force one
+        const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false : b->n_slots <= 32768;
+        if (!mark(split ? "clx_k_lanes2" : "clx_k_lanes")) return CLX_API_ERROR;     // (clx_k_lanes: + clx_k_lanes_hi, its order > 12 twin)
         if (!split) {
             hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
                                (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
@@ -440,7 +441,8 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
                            d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
         // K2: the two-wave (latency) build while the groups of 64 rows are few, the one-wave (throughput) build beyond
         const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
-        if (groups <= CLX_K2_LATENCY_GROUPS) {
+        const bool k2_latency = (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
+        if (k2_latency) {
             if (!mark("clx_k_predict")) return CLX_API_ERROR;
             hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(256), 0, stream, d_out,
                                (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
@@ -523,13 +525,17 @@ extern "C" int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t aren
     };
     if (flags & CLX_ARENA_ON_DEVICE) d_arena = const_cast<uint8_t*>(arena);
     else {
-        const size_t alloc = ((arena_len + 15) & ~(size_t)15) + 16;
+        const size_t alloc = ((arena_len + 15) & ~(size_t)15) + 32;
         if (!hip_ok(ctx, hipMalloc((void**)&d_arena, alloc), "hipMalloc arena")) { cleanup(); return CLX_API_ERROR; }
         if (!hip_ok(ctx, hipMemsetAsync(d_arena + (alloc - 32), 0, 32, ctx->stream), "memset") ||
             !hip_ok(ctx, hipMemcpyAsync(d_arena, arena, arena_len, hipMemcpyHostToDevice, ctx->stream), "H2D arena")) { cleanup(); return CLX_API_ERROR; }
     }
     if (flags & CLX_OUT_ON_DEVICE) d_out = out;
-    else if (!hip_ok(ctx, hipMalloc((void**)&d_out, std::max<uint64_t>(out_len, 1) * sizeof(int32_t)), "hipMalloc out")) { cleanup(); return CLX_API_ERROR; }
+    else {
+        // the whole range comes back to the caller: what no frame covers (and what a failed frame leaves) reads as zeros
+        if (!hip_ok(ctx, hipMalloc((void**)&d_out, std::max<uint64_t>(out_len, 1) * sizeof(int32_t)), "hipMalloc out") ||
+            !hip_ok(ctx, hipMemsetAsync(d_out, 0, std::max<uint64_t>(out_len, 1) * sizeof(int32_t), ctx->stream), "memset out")) { cleanup(); return CLX_API_ERROR; }
+    }
     st = clx_batch_run(b, d_arena, arena_len, d_out, ctx->stream);
     if (st == CLX_OK) st = clx_batch_results(b, results);
     if (st == CLX_OK && !(flags & CLX_OUT_ON_DEVICE)) {
@@ -957,13 +963,16 @@ extern "C" int clx_index_frames(const uint8_t* data, size_t len, size_t start_of
 
 // Device frame indexer: same contract and same answer as clx_index_frames; the byte scan and the
 // CRC-16 of every byte run on the GPU (K5-K7 in clx_kernels.hip), the chain walk over the few candidates here.
-extern "C" int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t len, size_t start_off,
-                                       clx_frame_desc* descs, clx_frame_header* headers, size_t cap,
-                                       size_t* n_found, size_t* stop_off, uint32_t flags) {
-    if (!ctx) return CLX_API_ERROR;
-    if (!n_found || !stop_off || (!data && len) || (cap && !descs)) { ctx->last_error = "clx_index_frames_device: bad argument"; return CLX_API_ERROR; }
-    *n_found = 0; *stop_off = start_off;
-    if (start_off + 2 > len || cap == 0) return CLX_OK;
+// `scan_end` <= len bounds the bytes that are looked at: with scan_end < len the stream goes on behind the window, so a frame
+// may only end at a later candidate inside it (never at the window's edge), and descriptors still say "readable to the end
+// of the stream".  Frames are appended to `descs` / `hdrs` (at most `cap`).
+static int index_frames_device_impl(clx_ctx* ctx, const uint8_t* data, size_t len, size_t scan_end, size_t start_off,
+                                    std::vector<clx_frame_desc>& descs, std::vector<clx_frame_header>* hdrs, size_t cap,
+                                    size_t* stop_off, uint32_t flags) {
+    *stop_off = start_off;
+    if (scan_end > len) scan_end = len;
+    if (start_off + 2 > scan_end || cap == 0) return CLX_OK;
+    const bool to_eos = scan_end == len;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     uint8_t* d_data = nullptr; uint64_t* d_cand = nullptr; uint32_t* d_count = nullptr; uint8_t* d_hdr = nullptr;
@@ -979,19 +988,20 @@ extern "C" int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t
     auto fail_api = [&](const char* what) { if (what) ctx->last_error = what; cleanup(); return (int)CLX_API_ERROR; };
     if (flags & CLX_ARENA_ON_DEVICE) d_data = const_cast<uint8_t*>(data);      // (16-byte aligned, padded like a decode arena)
     else {
-        const size_t alloc = ((len + 15) & ~(size_t)15) + 32;
+        const size_t alloc = ((scan_end + 15) & ~(size_t)15) + 32;
         if (!hip_ok(ctx, hipMalloc((void**)&d_data, alloc), "hipMalloc stream") ||
             !hip_ok(ctx, hipMemsetAsync(d_data + (alloc - 48), 0, 48, st), "memset") ||
-            !hip_ok(ctx, hipMemcpyAsync(d_data, data, len, hipMemcpyHostToDevice, st), "H2D stream")) return fail_api(nullptr);
+            !hip_ok(ctx, hipMemcpyAsync(d_data, data, scan_end, hipMemcpyHostToDevice, st), "H2D stream")) return fail_api(nullptr);
     }
-    // ---- K5: candidates
+    // ---- K5: candidates (a frame is at least 10 bytes long, and candidates need a CRC-8 match on top: a list of one entry
+    //      per 16 scanned bytes cannot overflow on real streams; adversarial input is caught by the count check)
     const uint64_t scan0 = (uint64_t)start_off & ~15ull;
-    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((len - scan0) / 16 + 4096, 1u << 26);
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((scan_end - scan0) / 16 + 4096, 1u << 26);
     if (!hip_ok(ctx, hipMalloc((void**)&d_cand, (size_t)cand_cap * 8), "hipMalloc candidates") ||
         !hip_ok(ctx, hipMalloc((void**)&d_count, 4), "hipMalloc count") ||
         !hip_ok(ctx, hipMemsetAsync(d_count, 0, 4, st), "memset")) return fail_api(nullptr);
-    const uint64_t n_threads = (len - scan0 + 15) / 16;
-    hipLaunchKernelGGL(clx_k_find_headers, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, st, d_data, (uint64_t)len,
+    const uint64_t n_threads = (scan_end - scan0 + 15) / 16;
+    hipLaunchKernelGGL(clx_k_find_headers, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, st, d_data, (uint64_t)scan_end,
                        (uint64_t)start_off, d_cand, cand_cap, d_count);
     uint32_t count = 0;
     if (!hip_ok(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, st), "D2H count") ||
@@ -1007,19 +1017,19 @@ extern "C" int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t
         std::vector<uint8_t> bytes((size_t)count * 20);
         if (!hip_ok(ctx, hipMalloc((void**)&d_hdr, bytes.size()), "hipMalloc headers") ||
             !hip_ok(ctx, hipMemcpyAsync(d_cand, cand.data(), (size_t)count * 8, hipMemcpyHostToDevice, st), "H2D candidates")) return fail_api(nullptr);
-        hipLaunchKernelGGL(clx_k_gather_headers, dim3((count + 255) / 256), dim3(256), 0, st, d_data, (uint64_t)len, d_cand, count, d_hdr);
+        hipLaunchKernelGGL(clx_k_gather_headers, dim3((count + 255) / 256), dim3(256), 0, st, d_data, (uint64_t)scan_end, d_cand, count, d_hdr);
         if (!hip_ok(ctx, hipMemcpyAsync(bytes.data(), d_hdr, bytes.size(), hipMemcpyDeviceToHost, st), "D2H headers") ||
             !hip_ok(ctx, hipStreamSynchronize(st), "sync")) return fail_api(nullptr);
         for (uint32_t i = 0; i < count; ++i) {
             clx_frame_header h; uint32_t m;
-            const size_t avail = std::min<size_t>(20, len - (size_t)cand[i]);
+            const size_t avail = std::min<size_t>(20, scan_end - (size_t)cand[i]);
             if (clx_parse_frame_header(bytes.data() + (size_t)i * 20, avail, 1, &h, &m) == CLX_OK) { pos.push_back(cand[i]); hdr.push_back(h); }
         }
     }
     if (pos.empty() || pos[0] != start_off) { cleanup(); return CLX_OK; }          // no frame starts at start_off
-    // ---- K6: CRC-16 of the span between consecutive candidates (the last one runs to the end of the stream)
+    // ---- K6: CRC-16 of the span between consecutive candidates (the last one runs to the end of the scanned bytes)
     const uint32_t m = (uint32_t)pos.size();
-    pos.push_back(len);
+    pos.push_back(scan_end);
     std::vector<uint16_t> crc(m);
     if (!hip_ok(ctx, hipMalloc((void**)&d_pos, (size_t)(m + 1) * 8), "hipMalloc pos") ||
         !hip_ok(ctx, hipMalloc((void**)&d_crc, (size_t)m * 2), "hipMalloc crc") ||
@@ -1030,15 +1040,17 @@ extern "C" int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t
     cleanup();
     // ---- chain: frame i ends at the first later candidate (or the end of the stream) e >= its header + 2 with
     //      crc16([pos_i, e)) == 0, i.e. whose two preceding bytes are the frame's CRC-16
+    const uint32_t last_end = to_eos ? m : m - 1;            // the window's edge is not a frame end unless it is the stream's
     uint32_t cur = 0;
-    while (*n_found < cap && cur < m) {
+    size_t n_found = 0;
+    while (n_found < cap && cur < m) {
         uint32_t acc = 0, end = 0;
-        for (uint32_t j = cur + 1; j <= m; ++j) {
+        for (uint32_t j = cur + 1; j <= last_end; ++j) {
             acc = clx_gf_mulmod(acc, clx_xpow8_64(pos[j] - pos[j - 1])) ^ crc[j - 1];
             if (acc == 0u && pos[j] >= pos[cur] + hdr[cur].header_bytes + 2u) { end = j; break; }
         }
         if (!end) break;
-        clx_frame_desc& d = descs[*n_found];
+        clx_frame_desc d;
         std::memset(&d, 0, sizeof d);
         d.byte_off = pos[cur];
         d.max_bytes = (uint32_t)std::min<uint64_t>(len - pos[cur], 0xffffffffu);
@@ -1047,11 +1059,29 @@ extern "C" int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t
         d.n_channels = hdr[cur].n_channels;
         d.channel_assignment = hdr[cur].channel_assignment;
         d.bps = hdr[cur].bps;
-        if (headers) headers[*n_found] = hdr[cur];
-        ++*n_found;
+        descs.push_back(d);
+        if (hdrs) hdrs->push_back(hdr[cur]);
+        ++n_found;
         cur = end;
     }
     *stop_off = (size_t)pos[cur];
+    return CLX_OK;
+}
+
+// Device frame indexer: same contract and same answer as clx_index_frames; the byte scan and the
+// CRC-16 of every byte run on the GPU (K5-K7 in clx_kernels.hip), the chain walk over the few candidates here.
+extern "C" int clx_index_frames_device(clx_ctx* ctx, const uint8_t* data, size_t len, size_t start_off,
+                                       clx_frame_desc* descs, clx_frame_header* headers, size_t cap,
+                                       size_t* n_found, size_t* stop_off, uint32_t flags) {
+    if (!ctx) return CLX_API_ERROR;
+    if (!n_found || !stop_off || (!data && len) || (cap && !descs)) { ctx->last_error = "clx_index_frames_device: bad argument"; return CLX_API_ERROR; }
+    *n_found = 0; *stop_off = start_off;
+    std::vector<clx_frame_desc> d; std::vector<clx_frame_header> h;
+    const int st = index_frames_device_impl(ctx, data, len, len, start_off, d, headers ? &h : nullptr, cap, stop_off, flags);
+    if (st != CLX_OK) return st;
+    std::copy(d.begin(), d.end(), descs);
+    if (headers) std::copy(h.begin(), h.end(), headers);
+    *n_found = d.size();
     return CLX_OK;
 }
 
@@ -1080,11 +1110,13 @@ struct FrameReader::Impl {
     std::vector<Pending> queue;
     size_t qhead = 0;
     bool failed = false; int fail_status = 0; uint32_t fail_msg = 0;
-    ~Impl() { if (d_arena) { (void)hipSetDevice(ctx->device); (void)hipFree(d_arena); } }
+    int device = 0;                   // (kept by value: the destructor must not look into a context that may be gone)
+    ~Impl() { if (d_arena) { (void)hipSetDevice(device); (void)hipFree(d_arena); } }
 };
 
 FrameReader::FrameReader(clx_ctx* ctx, const uint8_t* data, size_t len) : impl_(new Impl()) {
     impl_->ctx = ctx;
+    impl_->device = ctx ? ctx->device : 0;
     impl_->data.assign(data, data + len);
 }
 FrameReader::FrameReader(FrameReader&& o) noexcept : impl_(o.impl_) { o.impl_ = nullptr; }
@@ -1123,12 +1155,16 @@ static int fill_queue(FrameReader::Impl& I) {
         I.idx_next = 0;
         size_t nf = 0, stop = 0;
         if (len - I.pos >= (256u << 10)) {
+            // a window of the stream at a time: the index costs memory in proportion to the frames found, and a stream whose
+            // chain keeps breaking pays for one window per break, not for the whole remainder
             if (!upload()) return CLX_API_ERROR;
-            const size_t cap = (len - I.pos) / 8 + 2;
-            I.idx_descs.resize(cap); I.idx_hdrs.resize(cap);
-            const int st = clx_index_frames_device(I.ctx, I.d_arena, len, I.pos, I.idx_descs.data(), I.idx_hdrs.data(), cap, &nf, &stop,
-                                                   CLX_ARENA_ON_DEVICE);
+            const size_t window = (size_t)64 << 20;
+            const size_t scan_end = len - I.pos > window + (window >> 2) ? I.pos + window : len;
+            I.idx_descs.clear(); I.idx_hdrs.clear();
+            const int st = index_frames_device_impl(I.ctx, I.d_arena, len, scan_end, I.pos, I.idx_descs, &I.idx_hdrs, (size_t)-1, &stop,
+                                                    CLX_ARENA_ON_DEVICE);
             if (st != CLX_OK) return st;
+            nf = I.idx_descs.size();
         } else {
             I.idx_descs.resize(I.batch_frames); I.idx_hdrs.resize(I.batch_frames);
             clx_index_frames(data, len, I.pos, I.idx_descs.data(), I.idx_hdrs.data(), I.batch_frames, &nf, &stop);
@@ -1283,7 +1319,7 @@ FrameReader& FlacReader::blocks() {
 // ------------------------------------------------------------------------------------------------
 // C handles over the C++ reader
 // ------------------------------------------------------------------------------------------------
-struct clx_reader { claxon::FlacReader reader; std::vector<int32_t> recycle; };
+struct clx_reader { claxon::FlacReader reader; std::vector<int32_t> recycle; claxon::FrameResult pending; bool have_pending = false; };
 extern "C" const clx_tags* clx_reader_tags(const clx_reader* r) { return r ? r->reader.raw_tags() : nullptr; }
 
 extern "C" int clx_reader_new(clx_ctx* ctx, const uint8_t* data, size_t len, clx_reader** out, uint32_t* msg) {
@@ -1292,7 +1328,7 @@ extern "C" int clx_reader_new(clx_ctx* ctx, const uint8_t* data, size_t len, clx
     *out = nullptr;
     auto r = claxon::FlacReader::create(ctx, data, len);
     if (r.is_err) { if (msg) *msg = r.error.msg; return r.error.status; }
-    *out = new clx_reader{ std::move(r.value), {} };
+    *out = new clx_reader{ std::move(r.value), {}, {}, false };
     return CLX_OK;
 }
 
@@ -1302,7 +1338,7 @@ extern "C" int clx_reader_open(clx_ctx* ctx, const char* path, clx_reader** out,
     *out = nullptr;
     auto r = claxon::FlacReader::open(ctx, path);
     if (r.is_err) { if (msg) *msg = r.error.msg; return r.error.status; }
-    *out = new clx_reader{ std::move(r.value), {} };
+    *out = new clx_reader{ std::move(r.value), {}, {}, false };
     return CLX_OK;
 }
 
@@ -1315,12 +1351,18 @@ extern "C" int clx_reader_streaminfo(const clx_reader* r, clx_streaminfo* out) {
 extern "C" int clx_reader_next_block(clx_reader* r, int32_t* buffer, size_t cap, clx_block_info* info, uint32_t* msg) {
     if (msg) *msg = CLX_MSG_NONE;
     if (!r || !info) return CLX_API_ERROR;
-    claxon::FrameResult fr = r->reader.blocks().read_next_or_eof(std::move(r->recycle));
-    r->recycle.clear();
+    // a block that does not fit stays pending: the call can be repeated with a larger buffer (info says how large)
+    if (!r->have_pending) {
+        r->pending = r->reader.blocks().read_next_or_eof(std::move(r->recycle));
+        r->recycle.clear();
+        r->have_pending = true;
+    }
+    claxon::FrameResult& fr = r->pending;
     if (fr.is_err) { if (msg) *msg = fr.error.msg; return fr.error.status; }
     if (!fr.has_block) return CLX_END_OF_STREAM;
     info->time = fr.block.time(); info->block_size = fr.block.duration(); info->channels = fr.block.channels();
     if ((size_t)fr.block.len() > cap || (!buffer && fr.block.len())) return CLX_API_ERROR;
+    r->have_pending = false;
     std::vector<int32_t> buf = fr.block.into_buffer();
     std::memcpy(buffer, buf.data(), buf.size() * sizeof(int32_t));
     r->recycle = std::move(buf);

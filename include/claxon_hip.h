@@ -185,14 +185,18 @@ enum {
     /* Kernel path.  Default (neither bit): chosen from the batch shape.
      * WAVES: one wavefront per frame, wave-parallel Rice decode (lowest latency for a few frames).
      * LANES: one lane per subframe, lane-serial fused decode (highest throughput for many frames;
-     *        needs arena_len < 4 GiB). */
+     *        needs arena_len < 4 GiB: an explicit CLX_PATH_LANES fails beyond, the default falls back to WAVES). */
     CLX_PATH_WAVES      = 1u << 3,
     CLX_PATH_LANES      = 1u << 4,
     CLX_PCM_ON_DEVICE   = 1u << 5,   /* clx_interleave: `pcm` is a device pointer (else host; copied D2H) */
     /* Build of the lane path's decode kernel (with CLX_PATH_LANES; default: by batch size): the fused one-wave
      * kernel (throughput), or the two-wave split kernel (latency). */
     CLX_LANES_FUSED     = 1u << 6,
-    CLX_LANES_SPLIT     = 1u << 7
+    CLX_LANES_SPLIT     = 1u << 7,
+    /* Build of the wave path's predictor kernel (default: by batch size): the multi-wave latency build
+     * (clx_k_predict) or the one-wave throughput build (clx_k_predict_1w / _1w_hi). */
+    CLX_K2_LATENCY      = 1u << 8,
+    CLX_K2_THROUGHPUT   = 1u << 9
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32

@@ -85,6 +85,9 @@ def lib():
     L.clxo_decode_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int]
+    L.clxo_bench_batch.restype = C.c_uint64
+    L.clxo_bench_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.POINTER(C.c_double)]
     L.clxo_decode_subframes.restype = C.c_uint64
     L.clxo_decode_subframes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -308,6 +311,22 @@ def decode_batch(arena, offs, max_bytes=None, out=None, out_offs=None, check_crc
     total = lib().clxo_decode_batch(_ptr(arena), arena.size, _ptr(offs), _ptr(mb), n, _ptr(out), _ptr(oo),
                                     _ptr(st), _ptr(ms), _ptr(eb), 1 if check_crc else 0, int(nthreads))
     return dict(samples=int(total), statuses=st, msgs=ms, end_bits=eb)
+
+
+def bench_batch(arena, offs, max_bytes=None, check_crc=True, nthreads=1, passes=1, cpus=None):
+    """Timed decode for bench.py's cpu_baseline: pooled, pre-warmed threads, thread t pinned to cpus[t] when `cpus` is given;
+    returns (samples, seconds) of the timed region (`passes` passes over the frames by `nthreads` threads)."""
+    arena = _bytes_arr(arena)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    mb = None if max_bytes is None else np.ascontiguousarray(max_bytes, dtype=np.uint32)
+    sec = C.c_double(0.0)
+    nthreads = max(1, int(nthreads))
+    cp = None
+    if cpus is not None:
+        cp = np.ascontiguousarray(np.resize(np.asarray(cpus, dtype=np.int32), nthreads))
+    total = lib().clxo_bench_batch(_ptr(arena), arena.size, _ptr(offs), _ptr(mb), offs.size, 1 if check_crc else 0,
+                                   nthreads, int(passes), _ptr(cp), C.byref(sec))
+    return int(total), float(sec.value)
 
 
 def decode_subframes(arena, offs, block_sizes, bps, out=None, out_offs=None):

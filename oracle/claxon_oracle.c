@@ -18,11 +18,14 @@
  * Each function cites the reference file:line it follows (paths relative to
  * the claxon source tree).
  */
+#define _GNU_SOURCE                     /* pthread_setaffinity_np, pthread barriers (clxo_bench_batch only) */
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
 #include <stdlib.h>
 #include <pthread.h>
+#include <sched.h>
+#include <time.h>
 
 #include "../include/claxon_hip.h"   /* status / message ids only (the shared contract) */
 
@@ -1092,6 +1095,96 @@ uint64_t clxo_decode_batch(const uint8_t* arena, size_t arena_len, const uint64_
     }
     uint64_t total = 0;
     for (int t = 0; t < nthreads; t++) total += jobs[t].samples;
+    free(jobs); free(th);
+    return total;
+}
+
+/* Timing harness for the CPU baseline (bench.py's `cpu_baseline` leg): a persistent pool of `nthreads` threads, created,
+ * pinned (thread t on CPU cpus[t] when `cpus` is given) and warmed by an untimed pass over its share BEFORE the clock starts;
+ * every thread owns a recycled output buffer (examples/bench_decode.rs:55-78).  Between two barriers the threads then decode
+ * `passes` x n frames, taking chunks of `chunk` frames off a shared counter (what a thread-pool decoder does; a static split
+ * would time the unluckiest core of a shared host instead of the machine).  The timed region is barrier to barrier -- no
+ * thread creation, no allocation (tools/benchmark.sh:39-41 pins its process the same way).  Returns the samples decoded
+ * inside the timed region and its duration in *seconds. */
+typedef struct {
+    batch_job job;
+    pthread_barrier_t* bar;
+    uint64_t* next;             /* shared work counter over passes * n frame slots */
+    uint64_t total_slots, n;
+    int cpu, chunk;
+    uint64_t timed_samples;
+    struct timespec t0, t1;
+} bench_job;
+
+static void* bench_worker(void* p) {
+    bench_job* b = (bench_job*)p;
+    if (b->cpu >= 0) {
+        cpu_set_t set; CPU_ZERO(&set); CPU_SET(b->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
+    batch_job* j = &b->job;
+    int32_t* scratch = (int32_t*)malloc(sizeof(int32_t) * 8 * 65535);
+    clxo_frame_info info;
+    for (size_t i = j->lo; i < j->hi; i++) {           /* warm-up: this thread's contiguous share, untimed */
+        size_t avail = j->max_bytes ? j->max_bytes[i] : (j->arena_len - j->offs[i]);
+        if (j->offs[i] + avail > j->arena_len) avail = j->arena_len - j->offs[i];
+        clxo_frame_decode(j->arena + j->offs[i], avail, scratch, (size_t)8 * 65535, j->check_crc, &info);
+    }
+    uint64_t samples = 0;
+    pthread_barrier_wait(b->bar);
+    clock_gettime(CLOCK_MONOTONIC, &b->t0);
+    for (;;) {
+        const uint64_t s0 = __atomic_fetch_add(b->next, (uint64_t)b->chunk, __ATOMIC_RELAXED);
+        if (s0 >= b->total_slots) break;
+        const uint64_t s1 = s0 + (uint64_t)b->chunk < b->total_slots ? s0 + (uint64_t)b->chunk : b->total_slots;
+        for (uint64_t s = s0; s < s1; s++) {
+            const size_t i = (size_t)(s % b->n);
+            size_t avail = j->max_bytes ? j->max_bytes[i] : (j->arena_len - j->offs[i]);
+            if (j->offs[i] + avail > j->arena_len) avail = j->arena_len - j->offs[i];
+            clxo_frame_decode(j->arena + j->offs[i], avail, scratch, (size_t)8 * 65535, j->check_crc, &info);
+            if (info.status == CLX_OK) samples += (uint64_t)info.block_size * info.channels;
+        }
+    }
+    pthread_barrier_wait(b->bar);
+    clock_gettime(CLOCK_MONOTONIC, &b->t1);
+    b->timed_samples = samples;
+    free(scratch);
+    return NULL;
+}
+
+uint64_t clxo_bench_batch(const uint8_t* arena, size_t arena_len, const uint64_t* offs, const uint32_t* max_bytes, size_t n,
+                          int check_crc, int nthreads, int passes, const int* cpus, double* seconds) {
+    pthread_once(&g_crc_once, crc_tables_init);
+    if (seconds) *seconds = 0.0;
+    if (n == 0) return 0;
+    if (nthreads < 1) nthreads = 1;
+    if (passes < 1) passes = 1;
+    bench_job* jobs = (bench_job*)calloc((size_t)nthreads, sizeof(bench_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)nthreads);
+    uint64_t next = 0;
+    for (int t = 0; t < nthreads; t++) {
+        batch_job j = { arena, arena_len, offs, max_bytes, n * (size_t)t / (size_t)nthreads, n * (size_t)(t + 1) / (size_t)nthreads,
+                        NULL, NULL, NULL, NULL, NULL, check_crc, 0 };
+        jobs[t].job = j; jobs[t].bar = &bar; jobs[t].next = &next;
+        jobs[t].total_slots = (uint64_t)passes * n; jobs[t].n = n; jobs[t].chunk = 4;
+        jobs[t].cpu = cpus ? cpus[t] : -1;
+    }
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&bar);
+    uint64_t total = 0;
+    /* barrier to barrier: the earliest start stamp to the latest end stamp */
+    double t0 = 1e300, t1 = 0.0;
+    for (int t = 0; t < nthreads; t++) {
+        total += jobs[t].timed_samples;
+        const double a = (double)jobs[t].t0.tv_sec + 1e-9 * (double)jobs[t].t0.tv_nsec;
+        const double b = (double)jobs[t].t1.tv_sec + 1e-9 * (double)jobs[t].t1.tv_nsec;
+        if (a < t0) t0 = a;
+        if (b > t1) t1 = b;
+    }
+    if (seconds) *seconds = t1 - t0;
     free(jobs); free(th);
     return total;
 }

@@ -53,6 +53,9 @@ def lib():
                                              C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.synth_restamp_frame.restype = C.c_int
         L.synth_restamp_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        L.synth_tile_frames.restype = C.c_size_t
+        L.synth_tile_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -251,7 +254,7 @@ def pcm_music_like(index, n, bits=16):
             np.clip(np.rint(R), -lim, lim - 1).astype(np.int32), g)
 
 
-def config5_unique(n_unique=1024, bs=4096):
+def config5_unique(n_unique=1024, bs=4096, number_base=0):
     """Mixed real-world-shaped stereo 16-bit frames: 88% LPC (orders 1-12, triangular around 8),
     10% FIXED 0-4, 1% CONSTANT, 1% VERBATIM; 40% M/S, 25% L/S, 15% R/S, 20% independent;
     partition order 0-6, optimal k."""
@@ -260,7 +263,7 @@ def config5_unique(n_unique=1024, bs=4096):
     for i in range(n_unique):
         L, R, g = pcm_music_like(i, bs)
         ca = int(g.choice([CH_MID_SIDE, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_INDEPENDENT], p=[0.40, 0.25, 0.15, 0.20]))
-        fp = FrameParams(ca, 0, i)
+        fp = FrameParams(ca, 0, number_base + i)
         for c in range(2):
             u = g.uniform()
             if u < 0.88:
@@ -291,6 +294,53 @@ def config5_unique(n_unique=1024, bs=4096):
         pcm[i, 0], pcm[i, 1] = L, R
         fps.append(fp)
     return encode_frames("config5: %d unique mixed stereo frames bs=%d" % (n_unique, bs), pcm, 2, bs, 16, fps)
+
+
+TILE_NUMBER_BASE = 65536      # frame numbers 65536 .. 2097151 all take a 4-byte number field: every tile can be re-stamped in place
+
+
+class TiledStream:
+    """Config 5: `total` frames, frame i = unique frame i % U re-stamped with frame number
+    TILE_NUMBER_BASE + i (distinct header, CRC-8 and CRC-16 per frame).  Only the index lives here; `slice(lo, hi)` builds the
+    bytes of a contiguous range -- what one rank of a sharded job uploads."""
+
+    def __init__(self, unique, total):
+        assert TILE_NUMBER_BASE + total <= 2097152, "frame numbers must keep a 4-byte number field"
+        self.unique, self.total = unique, int(total)
+        U = unique.n
+        idx = np.arange(self.total, dtype=np.int64) % U
+        self.lens = unique.lens[idx]
+        self.channels = unique.channels[idx]
+        self.block_sizes = unique.block_sizes[idx]
+
+    def weights(self):
+        return self.lens.astype(np.int64) + 4 * self.channels.astype(np.int64) * self.block_sizes.astype(np.int64)
+
+    def slice(self, lo, hi):
+        """Workload of frames [lo, hi): arena bytes, offsets, output offsets (frame order); .pcm is None (the expected
+        decode of frame i is unique.pcm of frame i % U -- see `expected_index`)."""
+        u = self.unique
+        n = int(hi - lo)
+        cap = int(self.lens[lo:hi].astype(np.int64).sum()) if n else 0
+        arena = np.zeros((cap + 15) // 16 * 16 + 64, dtype=np.uint8)
+        offs = np.zeros(max(n, 1), dtype=np.uint64)
+        ua = np.ascontiguousarray(u.arena)
+        used = lib().synth_tile_frames(ua.ctypes.data, u.offs.ctypes.data, u.lens.ctypes.data, u.n, int(lo), int(hi),
+                                       TILE_NUMBER_BASE, arena.ctypes.data, cap, offs.ctypes.data) if n else 0
+        if n and used != cap:
+            raise RuntimeError("synth_tile_frames failed")
+        per = self.channels[lo:hi].astype(np.uint64) * self.block_sizes[lo:hi].astype(np.uint64)
+        out_offs = np.concatenate([[0], np.cumsum(per)[:-1]]).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
+        w = Workload("config5 tiled frames [%d, %d) of %d (%d unique)" % (lo, hi, self.total, u.n), arena, offs[:n], self.lens[lo:hi],
+                     self.channels[lo:hi], self.block_sizes[lo:hi], np.full(n, 16), u.assignments[(np.arange(lo, hi) % u.n)],
+                     None, out_offs)
+        w.expected_index = (np.arange(lo, hi, dtype=np.int64) % u.n)
+        return w
+
+
+def config5_tiled(total=1_000_000, n_unique=16384, bs=4096):
+    """The config-5 stream: `n_unique` unique mixed frames (config5_unique) tiled to `total` frames."""
+    return TiledStream(config5_unique(n_unique, bs, number_base=TILE_NUMBER_BASE), total)
 
 
 def small_mixed(n=64, bs=256, seed_off=0):

@@ -339,3 +339,22 @@ int synth_restamp_frame(uint8_t* frame, size_t len, uint64_t new_number) {
     frame[len - 2] = (uint8_t)(c >> 8); frame[len - 1] = (uint8_t)c;
     return 1;
 }
+
+/* Tile a set of U unique frames into a long stream (">= 16 384 unique frames tiled to 1M with
+ * distinct frame numbers / CRCs"): frame i of the stream is unique frame i % U re-stamped with number `number_base + i`.
+ * Writes frames [lo, hi) back to back into `out` (offs[i - lo] = where frame i starts).  Returns the bytes written, 0 when
+ * `out` is too small or a frame number does not fit the unique frame's number field. */
+size_t synth_tile_frames(const uint8_t* uarena, const uint64_t* uoffs, const uint32_t* ulens, size_t U,
+                         uint64_t lo, uint64_t hi, uint64_t number_base, uint8_t* out, size_t cap, uint64_t* offs) {
+    size_t pos = 0;
+    for (uint64_t i = lo; i < hi; i++) {
+        const size_t u = (size_t)(i % U);
+        const size_t len = ulens[u];
+        if (pos + len > cap) return 0;
+        memcpy(out + pos, uarena + uoffs[u], len);
+        if (!synth_restamp_frame(out + pos, len, number_base + i)) return 0;
+        offs[i - lo] = pos;
+        pos += len;
+    }
+    return pos;
+}

@@ -20,6 +20,16 @@ def workload_descs(w):
     return descs
 
 
+def head(w, k):
+    """The first k frames of a workload (frames are laid out back to back, outputs in frame order)."""
+    k = min(int(k), w.n)
+    used = int(w.offs[k - 1] + w.lens[k - 1]) if k else 0
+    total = int(w.out_offs[k - 1]) + int(w.channels[k - 1]) * int(w.block_sizes[k - 1]) if k else 0
+    return synth.Workload("%s[:%d]" % (w.name, k), synth._pad_arena(w.arena, used), w.offs[:k], w.lens[:k], w.channels[:k],
+                          w.block_sizes[:k], w.bps[:k], w.assignments[:k], w.pcm[:total], w.out_offs[:k],
+                          bare_subframes=w.bare_subframes, header_bytes=w.header_bytes)
+
+
 def check_workload(oracle, backend, w, verify_crc=True):
     """decode(w) == source PCM == oracle decode; statuses OK; end_bit matches the oracle."""
     descs = workload_descs(w)

@@ -15,9 +15,11 @@ def ctx():
     return cx.Context(0, wait_s=120)
 
 
-@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED], ids=["waves", "lanes", "lanes-fused"])
+@pytest.fixture(scope="module", params=[cx.PATH_WAVES | cx.K2_LATENCY, cx.PATH_WAVES | cx.K2_THROUGHPUT, cx.PATH_LANES | cx.LANES_SPLIT,
+                                        cx.PATH_LANES | cx.LANES_FUSED], ids=["waves", "waves-1w", "lanes", "lanes-fused"])
 def gpu(ctx, request):
-    """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip)."""
+    """Both kernel paths, every build of each: wave-per-frame (clx_kernels.hip) with the multi-wave and the one-wave
+    predictor kernels, lane-per-subframe (clx_lanes.hip) with the split and the fused decode kernels."""
     return GpuBackend(ctx, request.param)
 
 

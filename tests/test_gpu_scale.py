@@ -1,0 +1,116 @@
+"""Parity at scale: the kernel builds the library picks BY ITSELF at larger batches must actually run on the GPU and
+agree with the oracle -- status, message, end_bit and every sample (not only the source PCM).
+
+  * above 512 groups of predictor slots the wave path switches to the one-wave K2 builds (clx_k_predict_1w, and
+    clx_k_predict_1w_hi for groups with a predictor order above 12)          -- subframe.rs:524-614
+  * from 48 000 subframes the default path is the lane kernels, fused build above 32 768 subframes -- frame.rs:705-742
+  * BASELINE configs 2 / 4 / 5 at >= 8 000 frames with flags 0 (whatever the library selects)
+
+Every case asserts WHICH kernels ran (names recorded by the library around its launches), so a silent change of the
+selection thresholds cannot turn these tests into repeats of the small ones."""
+import os
+
+import numpy as np
+import pytest
+
+import claxon_amd as cx
+import parity_cases as pc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+NTHREADS = max(1, min(64, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return cx.Context(0, wait_s=120)
+
+
+@pytest.fixture(scope="module")
+def big3():
+    return synth.config3(24576)
+
+
+def run_and_compare(oracle, ctx, w, flags, expect, forbid=()):
+    import torch
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    d_out = torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0")
+    crc = not w.bare_subframes
+    batch = ctx.plan(descs, w.out_offs, verify_crc=crc, path=flags)
+    batch.set_profiling(True)
+    torch.cuda.synchronize()
+    batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr())
+    res = batch.results()
+    ran = set(batch.kernel_times().keys())
+    batch.close()
+    assert set(expect) <= ran, (sorted(ran), expect)
+    assert not (set(forbid) & ran), (sorted(ran), forbid)
+    got = d_out.cpu().numpy()
+    del d_out, d_arena
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    if w.bare_subframes:
+        r = oracle.decode_subframes(w.arena[:w.arena_len], w.offs, w.block_sizes, w.bps, out=ref, out_offs=w.out_offs)
+    else:
+        r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.array_equal(res["status"], r["statuses"])
+    assert np.array_equal(res["msg"], r["msgs"])
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    assert np.all(res["status"] == cx.OK)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got, w.pcm)
+    return ran
+
+
+def test_auto_wave_path_one_wave_predictor(oracle, ctx, big3):
+    """20 480 config-3 frames + 640 order-32 frames: 42 240 slots < 48 000 keeps the wave path, 660 groups > 512 select
+    the one-wave predictor builds; the order-32 frames make clx_k_predict_1w_hi do real work."""
+    w = synth.concat("config3 x 20480 + config4 x 640", [pc.head(big3, 20480), synth.config4(640)])
+    run_and_compare(oracle, ctx, w, 0, ["clx_k_residual", "clx_k_predict_1w", "clx_k_predict_1w_hi", "clx_k_crc16"],
+                    forbid=["clx_k_predict", "clx_k_lanes"])
+
+
+def test_auto_lane_path_fused(oracle, ctx, big3):
+    """24 576 stereo frames = 49 152 subframes: the default is the lane path, fused build."""
+    run_and_compare(oracle, ctx, big3, 0, ["clx_k_scan", "clx_k_lanes", "clx_k_finalize", "clx_k_crc16"],
+                    forbid=["clx_k_residual", "clx_k_lanes2"])
+
+
+def test_forced_builds_at_scale(oracle, ctx, big3):
+    """The builds the thresholds would not pick at this size, forced by flag on the same 12 288 frames."""
+    w = pc.head(big3, 12288)
+    run_and_compare(oracle, ctx, w, cx.PATH_WAVES | cx.K2_LATENCY, ["clx_k_residual", "clx_k_predict"])
+    run_and_compare(oracle, ctx, w, cx.PATH_WAVES | cx.K2_THROUGHPUT, ["clx_k_residual", "clx_k_predict_1w"])
+    run_and_compare(oracle, ctx, w, cx.PATH_LANES | cx.LANES_SPLIT, ["clx_k_lanes2"])
+    run_and_compare(oracle, ctx, w, cx.PATH_LANES | cx.LANES_FUSED, ["clx_k_lanes"])
+
+
+@pytest.mark.parametrize("make", [lambda: synth.config2(8192), lambda: synth.config4(8192), lambda: synth.config5_unique(8192)],
+                         ids=["config2", "config4", "config5"])
+def test_baseline_configs_default_selection(oracle, ctx, make):
+    run_and_compare(oracle, ctx, make(), 0, [])
+
+
+def test_device_indexer_against_oracle_offsets(oracle, ctx):
+    """clx_index_frames_device against the frame starts the ORACLE's reader walks through (oracle.decode_stream), not
+    against the product's own host indexer: a 3 MB raw stream of mixed frames, with and without a garbage tail."""
+    w = synth.config5_unique(600)
+    stream = w.arena[:w.arena_len].tobytes()
+    hdr = bytearray(34)
+    hdr[0:2] = (4096).to_bytes(2, "big"); hdr[2:4] = (4096).to_bytes(2, "big")
+    hdr[10:14] = ((44100 << 12) | (1 << 9) | (15 << 4)).to_bytes(4, "big")
+    head = b"fLaC" + bytes([0x80, 0, 0, 34]) + bytes(hdr)
+    for tail in (b"", bytes(range(256)) * 3):
+        data = head + stream + tail
+        si, blocks, st, msg = oracle.decode_stream(data)
+        starts, pos = [], len(head)
+        for info, _ in blocks:
+            starts.append(pos)
+            pos += int(info.bytes_consumed)
+        assert len(starts) == 600
+        descs, hdrs, stop = ctx.index_frames(np.frombuffer(data, dtype=np.uint8), start=len(head))
+        assert descs["byte_off"].tolist() == starts
+        assert stop == pos
+        assert hdrs["block_size"].tolist() == [int(i.block_size) for i, _ in blocks]
+        assert hdrs["time"].tolist() == [int(i.time) for i, _ in blocks]

@@ -10,7 +10,7 @@ sizes = [int(a) for a in sys.argv[1:]] or [5000, 10000, 16000, 24000, 32000, 480
 ctx = cx.Context(0, wait_s=120)
 sel = (("waves", cx.PATH_WAVES), ("lanes-split", cx.PATH_LANES | cx.LANES_SPLIT), ("lanes-fused", cx.PATH_LANES | cx.LANES_FUSED))
 for n in sizes:
-    w = bench._config3_shard(synth, n, 0)
+    w = bench._seeded(synth, synth.config3, n, 0)
     descs = workload_descs(w)
     d_arena = torch.from_numpy(w.arena).cuda()
     d_out = torch.zeros(w.pcm.size, dtype=torch.int32, device="cuda")
