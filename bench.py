@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, help="config5 on one GPU: pretend to be one rank of this many")
     ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="time steps that do not overlap (clx_batch_run instead of clx_batch_submit)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (CRC-16 step, host-buffer rates)")
     ap.add_argument("--path", choices=["auto", "waves", "lanes"], default="auto", help="kernel path (default: library's choice)")
     args = ap.parse_args()
@@ -106,6 +107,11 @@ def main():
 
     d_arena = torch.from_numpy(w.arena).to(dev)
     d_out = torch.zeros(w.total_samples, dtype=torch.int32, device=dev)
+    # consecutive steps are submitted as a two-stage software pipeline (clx_batch_submit: the predictor stage of step i runs
+    # beside the Rice stage of step i+1), so they alternate between two output buffers -- when there is room for two
+    pipelined = (not args.no_pipeline) and 2 * 4 * w.total_samples < 32 * (1 << 30)
+    d_out2 = torch.zeros(w.total_samples, dtype=torch.int32, device=dev) if pipelined else None
+    outs = [d_out, d_out2] if pipelined else [d_out]
     path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES}[args.path]
     batch = ctx.plan(descs, w.out_offs, verify_crc=False, path=path)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -114,29 +120,45 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed(b, steps):
+    def timed(b, steps, pipe):
         """`steps` passes of batch b, bracketed by barrier + synchronize on both sides; seconds (this rank)."""
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            b.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
+        if pipe:
+            for i in range(steps):
+                b.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+            b.flush(stream)
+        else:
+            for _ in range(steps):
+                b.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
         torch.cuda.synchronize(); barrier()
         return time.perf_counter() - t0
 
-    for _ in range(args.warmup):
-        batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
+    for i in range(max(args.warmup, 2 if pipelined else 0)):
+        if pipelined:
+            batch.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+        else:
+            batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
+    batch.flush(stream)
     torch.cuda.synchronize()
 
-    # ---- parity gate before anything is timed: statuses OK and bit-exact vs the source PCM
+    # ---- parity gate before anything is timed: statuses OK and bit-exact vs the source PCM (every output buffer in use)
     res = batch.results()
     if w.pcm is not None:
-        same = bool(torch.equal(d_out, torch.from_numpy(w.pcm).to(dev)))
+        ref_pcm = torch.from_numpy(w.pcm).to(dev)
+        same = all(bool(torch.equal(o, ref_pcm)) for o in outs)
+        del ref_pcm
     else:
-        same = _tiled_equal(torch, d_out, w, ts.unique, dev)
+        same = all(_tiled_equal(torch, o, w, ts.unique, dev) for o in outs)
     if not (bool(np.all(res["status"] == 0)) and same):
         raise SystemExit("bench: decode is not bit-exact; refusing to report a number")
 
-    elapsed = timed(batch, args.steps)
+    # ---- per-kernel durations: HIP events recorded by the library on the launch stream, around each of its kernels (steps one at
+    #      a time); they also say which kernels the library selected -- only the two-stage wave path pipelines across steps
+    kernel_ms = _kernel_ms(torch, batch, lambda: batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
+    pipelined = pipelined and "clx_k_predict" in kernel_ms
+
+    elapsed = timed(batch, args.steps, pipelined)
     # whole-job figures: MAX elapsed over ranks, SUM of samples per step, SUM of failed frames (must be 0)
     res = batch.results()
     elapsed, samples_all, n_bad = shard.reduce_job(dist if world > 1 else None, elapsed, w.total_samples,
@@ -150,16 +172,19 @@ def main():
         mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(t, op=dist.ReduceOp.SUM)
         shard_info["imbalance"] = round(float(mx.item()) / (float(t.item()) / world) - 1.0, 5)
 
-    # ---- per-kernel durations: HIP events recorded by the library on the launch stream, around each of its kernels
-    kernel_ms = _kernel_ms(torch, batch, lambda: batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
-    path_ms = float(sum(kernel_ms.values()))             # all kernels of the path (SURVEY section 8d's t_kernel)
+    path_ms = float(sum(kernel_ms.values()))             # all kernels of the path, one after the other (SURVEY section 8d's t_kernel)
     dom_name = max(kernel_ms, key=kernel_ms.get)
     alg_bytes = w.algorithmic_bytes                      # compressed bytes read once + 4 B per decoded sample written once
-    achieved = alg_bytes / (path_ms * 1e-3) / 1e9
+    # one step's share of the timed region is what its kernels cost the machine once they overlap the neighbouring steps';
+    # never less than max(kernel), never more than their sum when steps do not overlap
+    t_path_ms = ms_per_step if pipelined else path_ms
+    achieved = alg_bytes / (t_path_ms * 1e-3) / 1e9
     traffic, traffic_src = _pmc_traffic(args.workload, w.n)
     roofline = {"bound": "hbm", "kernel": "+".join(kernel_ms.keys()), "achieved": round(achieved, 1), "peak": PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "path_ms": round(path_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                "path_ms": round(t_path_ms, 4), "path_ms_basis": ("ms_per_step of the pipelined steps (kernels of consecutive steps overlap)" if pipelined
+                                                                  else "sum of the path's kernel durations"),
+                "kernel_ms_sum_unpipelined": round(path_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "dominant_kernel": {"name": dom_name, "ms": round(kernel_ms[dom_name], 4),
                                     "note": "one of the path's kernels; the path's bytes over its time alone would overstate it"},
@@ -184,7 +209,8 @@ def main():
     cfg = {"workload": workload_name, "frames_this_rank": w.n, "samples_per_step": samples_all,
            "compressed_bytes_this_rank": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
            "parallelism": "one frame index sharded over %d GPU(s), no collective on the data path" % world, "shard": shard_info,
-           "bit_exact": True, "crc16_in_step": False, "kernel_path": args.path, "gen_seconds": round(gen_s, 1)}
+           "bit_exact": True, "crc16_in_step": False, "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
+           "steps_in_flight": 2 if pipelined else 1}
     out = {
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,6 +218,14 @@ def main():
         "dtype": "i32 (i64 LPC accumulate)", "data": "synthetic", "config": cfg, "roofline": roofline,
     }
 
+    if pipelined and not args.no_extras:
+        # ---- the same steps one at a time (clx_batch_run: nothing of step i+1 starts before step i has finished)
+        el_1 = timed(batch, args.steps, False)
+        el_1, samples_1, _ = shard.reduce_job(dist if world > 1 else None, el_1, w.total_samples, 0, device=dev)
+        ms_1 = 1e3 * el_1 / args.steps
+        cfg["one_step_at_a_time"] = {"value": round(samples_1 / (ms_1 * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_1, 4),
+                                     "frac": round(alg_bytes / (ms_1 * 1e-3) / 1e9 / PEAK_GBS, 4),
+                                     "note": "clx_batch_run: a batch's latency; `value` is the throughput of consecutive batches with two in flight"}
     if not w.bare_subframes and not args.no_extras:
         # ---- the same step with every frame's CRC-16 verified on the device (frame.rs:752-763: the reference always does);
         #      this is the figure that corresponds to the cpu_baseline leg, which also verifies
@@ -199,7 +233,7 @@ def main():
         bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
         torch.cuda.synchronize()
         rc = bc.results()
-        el_c = timed(bc, args.steps)
+        el_c = timed(bc, args.steps, pipelined)
         el_c, samples_c, bad_c = shard.reduce_job(dist if world > 1 else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=dev)
         kc = _kernel_ms(torch, bc, lambda: bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
         bc.close()

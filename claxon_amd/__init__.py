@@ -84,7 +84,7 @@ assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
 EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
     "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes", "clx_interleave",
-    "clx_batch_create", "clx_batch_run", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
+    "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
     "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
     "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames", "clx_index_frames_device",
@@ -95,7 +95,7 @@ EXPORTS = [
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_lanes.hip", "clx_device.h", "clx_plan.h",
-                                            os.path.join("intrin", "clx_intrin.h"), os.path.join("host", "claxon.hpp"))]
+                                            os.path.join("intrin", "clx_intrin.h"), os.path.join("intrin", "clx_k2_dot2.h"), os.path.join("host", "claxon.hpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "claxon_hip.h"))
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
@@ -148,6 +148,8 @@ def lib():
     L.clx_decode_subframes.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, C.c_uint32]
     L.clx_batch_create.argtypes = [vp, vp, sz, vp, C.c_uint32, C.POINTER(vp)]
     L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
+    L.clx_batch_submit.argtypes = [vp, vp, sz, vp, vp]
+    L.clx_batch_flush.argtypes = [vp, vp]
     L.clx_batch_results.argtypes = [vp, vp]
     L.clx_batch_interleave.argtypes = [vp, vp, vp, C.c_uint32, vp]
     L.clx_index_frames_device.argtypes = [vp, vp, sz, sz, vp, vp, sz, C.POINTER(sz), C.POINTER(sz), C.c_uint32]
@@ -516,6 +518,16 @@ class Batch:
         st = lib().clx_batch_run(self._h, C.c_void_p(d_arena_ptr), arena_len, C.c_void_p(d_out_ptr),
                                  C.c_void_p(stream) if stream else None)
         self.ctx._check(st)
+
+    def submit(self, d_arena_ptr, arena_len, d_out_ptr, stream=0):
+        """Pipelined run (clx_batch_submit): the predictor stage overlaps the next submission's Rice stage.  Alternate the
+        output buffers of consecutive submissions; flush() (or results()) before reading them."""
+        st = lib().clx_batch_submit(self._h, C.c_void_p(d_arena_ptr), arena_len, C.c_void_p(d_out_ptr),
+                                    C.c_void_p(stream) if stream else None)
+        self.ctx._check(st)
+
+    def flush(self, stream=0):
+        self.ctx._check(lib().clx_batch_flush(self._h, C.c_void_p(stream) if stream else None))
 
     def interleave(self, d_planar_ptr, d_pcm_ptr, sample_bytes, stream=0):
         """Device-resident interleave / narrow stage after run(): integer device addresses, async on `stream`."""

@@ -250,6 +250,16 @@ struct clx_batch {
     bool ev_valid = false;
     hipStream_t last_stream = nullptr;
     size_t planned_arena_len = 0;
+    // two-stage software pipeline over consecutive submissions (clx_batch_submit): stage 2 (predictor kernels) of submission i
+    // runs on `stream2` beside stage 1 (Rice / residual kernel) of submission i+1; what stage 1 hands to stage 2 is double-buffered
+    hipStream_t stream2 = nullptr;
+    clx_sf_desc* d_sfd_alt = nullptr;
+    clx_frame_result* d_results_alt = nullptr;
+    hipEvent_t ev_stage1[2] = {}, ev_stage2[2] = {}, ev_gate[2] = {};
+    bool stage2_pending[2] = { false, false };
+    const int32_t* pending_out[2] = { nullptr, nullptr };
+    uint64_t n_submitted = 0;
+    int last_slot = -1;              // slot of the most recent pipelined submission (-1: the last run was a plain clx_batch_run)
 };
 
 namespace {
@@ -301,6 +311,12 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_errkey) (void)hipFree(b->d_errkey);
     if (b->d_endbits) (void)hipFree(b->d_endbits);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : b->ev_stage1) if (e) (void)hipEventDestroy(e);
+    for (auto& e : b->ev_stage2) if (e) (void)hipEventDestroy(e);
+    for (auto& e : b->ev_gate) if (e) (void)hipEventDestroy(e);
+    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
+    if (b->d_sfd_alt) (void)hipFree(b->d_sfd_alt);
+    if (b->d_results_alt) (void)hipFree(b->d_results_alt);
     delete b;
 }
 
@@ -370,6 +386,38 @@ extern "C" int clx_batch_set_profiling(clx_batch* b, int enable) {
     return CLX_OK;
 }
 
+namespace {
+// clamp every frame's readable span against the arena and upload the plan (once per arena size)
+int upload_plan(clx_batch* b, size_t arena_len, hipStream_t stream) {
+    clx_ctx* ctx = b->ctx;
+    if (b->planned_arena_len == arena_len) return CLX_OK;
+    std::vector<clx_dev_frame> up(b->h_frames);
+    clx_plan_limits(b->h_descs.data(), b->n, arena_len, up.data());
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_frames, up.data(), b->n * sizeof(clx_dev_frame), hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));                    // `up` goes out of scope
+    b->planned_arena_len = arena_len;
+    return CLX_OK;
+}
+// the lane kernels address the arena with 32-bit offsets: an explicit CLX_PATH_LANES fails beyond 4 GiB, a batch that only
+// defaulted to them runs the wave kernels instead (their buffers exist for every batch).  -1: error (message set)
+int use_lanes(clx_batch* b, size_t arena_len) {
+    if (!b->lanes) return 0;
+    if ((uint64_t)arena_len + 32ull >= (1ull << 32)) {
+        if (b->flags & CLX_PATH_LANES) { b->ctx->last_error = "CLX_PATH_LANES needs arena_len < 4 GiB"; return -1; }
+        return 0;
+    }
+    return 1;
+}
+void launch_stage1_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
+                         hipStream_t stream) {
+    // CLX_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer K1 waves per CU -- the measurement knob behind DESIGN.md's
+    // "lower occupancy is strictly worse" (32 -> 16 waves per CU: 0.28 -> 0.39 ms); not used otherwise
+    static const unsigned k1_pad = [] { const char* e = std::getenv("CLX_K1_LDS_PAD"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
+    hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), k1_pad, stream,
+                       d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, d_sfd, d_results);
+}
+}  // namespace
+
 extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, void* stream_) {
     if (!b || !b->ctx) return CLX_API_ERROR;
     clx_ctx* ctx = b->ctx;
@@ -378,16 +426,12 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    b->last_stream = stream;
-
-    if (b->planned_arena_len != arena_len) {
-        // clamp every frame's readable span against the arena and upload the plan (once per arena size)
-        std::vector<clx_dev_frame> up(b->h_frames);
-        clx_plan_limits(b->h_descs.data(), b->n, arena_len, up.data());
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_frames, up.data(), b->n * sizeof(clx_dev_frame), hipMemcpyHostToDevice, stream));
-        HIP_TRY(ctx, hipStreamSynchronize(stream));                    // `up` goes out of scope
-        b->planned_arena_len = arena_len;
+    if (b->last_slot >= 0) {                                            // pipelined submissions still in flight touch the same buffers
+        for (int s = 0; s < 2; ++s) if (b->stage2_pending[s]) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[s], 0)); b->stage2_pending[s] = false; }
+        b->last_slot = -1;
     }
+    b->last_stream = stream;
+    if (upload_plan(b, arena_len, stream) != CLX_OK) return CLX_API_ERROR;
     const uint64_t alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;   // claxon_hip.h: the allocation covers this
 
     int nk = 0;
@@ -396,13 +440,8 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         if (name) b->kname[nk] = name;
         return hip_ok(ctx, hipEventRecord(b->ev[nk++], stream), "hipEventRecord");
     };
-    // the lane kernels address the arena with 32-bit offsets: an explicit CLX_PATH_LANES fails beyond 4 GiB, a batch that
-    // only defaulted to them runs the wave kernels instead (their buffers exist for every batch)
-    bool lanes = b->lanes;
-    if (lanes && (uint64_t)arena_len + 32ull >= (1ull << 32)) {
-        if (b->flags & CLX_PATH_LANES) { ctx->last_error = "CLX_PATH_LANES needs arena_len < 4 GiB"; return CLX_API_ERROR; }
-        lanes = false;
-    }
+    const int lanes = use_lanes(b, arena_len);
+    if (lanes < 0) return CLX_API_ERROR;
     if (lanes) {
         HIP_TRY(ctx, hipMemsetAsync(b->d_errkey, 0xff, b->n * sizeof(uint32_t), stream));
         HIP_TRY(ctx, hipMemsetAsync(b->d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream));
@@ -434,17 +473,13 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
         if (!mark("clx_k_residual")) return CLX_API_ERROR;
-        // CLX_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer K1 waves per CU -- the measurement knob behind DESIGN.md's
-        // "lower occupancy is strictly worse" (32 -> 16 waves per CU: 0.28 -> 0.39 ms); not used otherwise
-        static const unsigned k1_pad = [] { const char* e = std::getenv("CLX_K1_LDS_PAD"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
-        hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), k1_pad, stream,
-                           d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, b->d_sfd, b->d_results);
+        launch_stage1_waves(b, d_arena, alloc_len, d_out, b->d_sfd, b->d_results, stream);
         // K2: the two-wave (latency) build while the groups of 64 rows are few, the one-wave (throughput) build beyond
         const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
         const bool k2_latency = (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
         if (k2_latency) {
             if (!mark("clx_k_predict")) return CLX_API_ERROR;
-            hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(256), 0, stream, d_out,
+            hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, stream, d_out,
                                (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
         } else {
             if (!mark("clx_k_predict_1w")) return CLX_API_ERROR;
@@ -465,6 +500,80 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     return CLX_OK;
 }
 
+// Pipelined submission (wave path): the same work as clx_batch_run, but the predictor stage goes to a second, higher-priority
+// stream, so that the NEXT submission's Rice stage -- issue-bound, it fills the machine -- runs beside it: the predictor stage
+// is one serial chain per subframe that occupies a fraction of the SIMDs for its whole duration.  What the stages hand over
+// (subframe descriptors, per-frame results) is double-buffered; the caller keeps consecutive submissions' OUTPUTS apart (a
+// submission whose d_out is still being finished by the previous one waits for it -- correct, not overlapped).
+// clx_batch_flush makes `stream` wait for everything submitted so far; clx_batch_results does so itself.
+extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, void* stream_) {
+    if (!b || !b->ctx) return CLX_API_ERROR;
+    clx_ctx* ctx = b->ctx;
+    if (b->n == 0) return CLX_OK;
+    if (!d_arena || !d_out) { ctx->last_error = "null device pointer"; return CLX_API_ERROR; }
+    if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
+    const int lanes = use_lanes(b, arena_len);
+    if (lanes < 0) return CLX_API_ERROR;
+    const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
+    const bool k2_latency = (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
+    // the lane kernels are one fused stage, and the one-wave predictor build is chosen when the machine is full anyway
+    if (lanes || !k2_latency || b->profiling) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    if (!b->stream2) {
+        int lo = 0, hi = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));                   // (hi is the numerically lowest = highest priority)
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, hi));
+        const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_sfd_alt, ns * sizeof(clx_sf_desc)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_results_alt, nf * sizeof(clx_frame_result)));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_stage1[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_stage2[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_gate[i], hipEventDisableTiming));
+        }
+    }
+    if (upload_plan(b, arena_len, stream) != CLX_OK) return CLX_API_ERROR;
+    const uint64_t alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;
+    const int slot = (int)(b->n_submitted & 1u), other = slot ^ 1;
+    clx_sf_desc* sfd = slot ? b->d_sfd_alt : b->d_sfd;
+    clx_frame_result* results = slot ? b->d_results_alt : b->d_results;
+    // this slot's descriptors are free once the submission before the previous one has been finished ...
+    if (b->stage2_pending[slot]) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[slot], 0)); b->stage2_pending[slot] = false; }
+    // ... and an output buffer that the previous submission is still finishing cannot take new residuals yet
+    if (b->stage2_pending[other] && b->pending_out[other] == d_out) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[other], 0)); b->stage2_pending[other] = false; }
+    // the previous submission's predictor stage goes first: its few workgroups need a large share of a CU each and would trickle
+    // in behind this submission's 10^4 one-wave workgroups if those were dispatched the moment its Rice stage ends.  The gate
+    // event sits right in front of that predictor launch in stream2's queue, so this stream sees it a queue hop later.
+    if (b->stage2_pending[other]) HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_gate[other], 0));
+    HIP_TRY(ctx, hipMemsetAsync(sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
+    launch_stage1_waves(b, d_arena, alloc_len, d_out, sfd, results, stream);
+    HIP_TRY(ctx, hipEventRecord(b->ev_stage1[slot], stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(b->stream2, b->ev_stage1[slot], 0));
+    HIP_TRY(ctx, hipEventRecord(b->ev_gate[slot], b->stream2));
+    hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, b->stream2, d_out, (const clx_sf_desc*)sfd, (uint32_t)b->n_slots, b->d_dump);
+    HIP_TRY(ctx, hipEventRecord(b->ev_stage2[slot], b->stream2));
+    if (b->flags & CLX_VERIFY_CRC16)       // needs stage 1's end_bit only: runs beside the predictor stage
+        hipLaunchKernelGGL(clx_k_crc16, dim3((unsigned)b->n), dim3(64), 0, stream, d_arena, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, results);
+    b->stage2_pending[slot] = true;
+    b->pending_out[slot] = d_out;
+    b->last_slot = slot;
+    b->last_stream = stream;
+    ++b->n_submitted;
+    b->ev_valid = false;
+    HIP_TRY(ctx, hipGetLastError());
+    return CLX_OK;
+}
+
+extern "C" int clx_batch_flush(clx_batch* b, void* stream_) {
+    if (!b || !b->ctx) return CLX_API_ERROR;
+    clx_ctx* ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : (b->last_stream ? b->last_stream : ctx->stream);
+    for (int s = 0; s < 2; ++s) if (b->stage2_pending[s]) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[s], 0)); b->stage2_pending[s] = false; }
+    return CLX_OK;
+}
+
 extern "C" int clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void* d_pcm, uint32_t sample_bytes, void* stream_) {
     if (!b || !b->ctx) return CLX_API_ERROR;
     clx_ctx* ctx = b->ctx;
@@ -473,7 +582,7 @@ extern "C" int clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void*
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : (b->last_stream ? b->last_stream : ctx->stream);
     hipLaunchKernelGGL(clx_k_interleave, dim3((unsigned)b->n), dim3(256), 0, stream, d_planar,
-                       (const clx_dev_frame*)b->d_frames, (const clx_frame_result*)b->d_results, (uint32_t)b->n,
+                       (const clx_dev_frame*)b->d_frames, (const clx_frame_result*)(b->last_slot == 1 ? b->d_results_alt : b->d_results), (uint32_t)b->n,
                        (uint8_t*)d_pcm, sample_bytes);
     HIP_TRY(ctx, hipGetLastError());
     return CLX_OK;
@@ -485,7 +594,9 @@ extern "C" int clx_batch_results(clx_batch* b, clx_frame_result* results) {
     if (b->n == 0) return CLX_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = b->last_stream ? b->last_stream : ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(results, b->d_results, b->n * sizeof(clx_frame_result), hipMemcpyDeviceToHost, stream));
+    if (clx_batch_flush(b, stream) != CLX_OK) return CLX_API_ERROR;       // (pipelined submissions: the predictor stage too)
+    const clx_frame_result* src = b->last_slot == 1 ? b->d_results_alt : b->d_results;
+    HIP_TRY(ctx, hipMemcpyAsync(results, src, b->n * sizeof(clx_frame_result), hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     return CLX_OK;
 }

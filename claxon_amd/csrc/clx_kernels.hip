@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include <clx_intrin.h>
+#include <clx_k2_dot2.h>
 
 #include "../../include/claxon_hip.h"
 #include "clx_device.h"
@@ -787,26 +788,63 @@ struct K2Slot {
 // The recurrence of one row, a block of CLX_BLK samples at a time: 24-bit fast evaluation with a range check, exact i64
 // re-run of a block that leaves the proven range (see the header comment of this section).
 template <int OMAX>
+__device__ __forceinline__ void clx_dot2_block_any(const int32_t (&x)[CLX_BLK], int32_t (&y)[CLX_BLK], int32_t (&pr)[OMAX > 1 ? OMAX - 1 : 1],
+                                                   const int32_t (&C)[OMAX / 2], uint32_t shift, int32_t prev) {
+    if constexpr (OMAX <= 12) clx_dot2_block<OMAX>(x, y, pr, C, shift, prev);
+}
+
+// Three evaluations of the same recurrence, fastest first; each is exact on the inputs it accepts and a block that turns out
+// to leave an evaluation's range is re-run with the next one from the saved history:
+//   16-bit : history as packed pairs, two taps per v_dot2_i32_i16 (clx_k2_dot2.h): every sample inside [-lim16, lim16),
+//            lim16 = min(lim, 2^15) -- 16-bit audio, the common case (mid is 16 bits wide; side is 17 but small)
+//   24-bit : v_mad_i32_i24 chain: every sample inside [-lim, lim), lim <= 2^23 with sum|c| * lim < 2^31 (from K1)
+//   exact  : v_mad_i64_i32, any input -- garbage in, the reference's garbage out
+template <int OMAX>
 struct K2Predictor {
+    static constexpr bool HAS16 = OMAX <= 12;
     int32_t c[OMAX], hist[OMAX];
-    int32_t lim;
+    int32_t C2[OMAX / 2];      // (c[2p] << 16) | (c[2p+1] & 0xffff)
+    int32_t lim, lim16;
     uint32_t n, order, shift;
-    bool trivial, h_ok;
+    bool trivial, h_ok, h16_ok;
     __device__ __forceinline__ void init(const K2Slot& S) {
         n = S.n; order = S.order; shift = S.shift;
 #pragma unroll
         for (int j = 0; j < OMAX; ++j) { c[j] = (n != 0u && (uint32_t)j < order) ? (int32_t)S.d->coef[j] : 0; hist[j] = 0; }
+#pragma unroll
+        for (int p = 0; p < OMAX / 2; ++p) C2[p] = (int32_t)(((uint32_t)c[2 * p] << 16) | ((uint32_t)c[2 * p + 1] & 0xffffu));
         // |s| <= lim proves the i32/i24 evaluation exact; lanes K1 could not prove (lim_log2 = 0xff) force the wide path
         // (range is [-lim, lim-1]: the 24-bit signed factor range when lim = 2^23)
         lim = (S.lim_log2 <= 23u) ? (int32_t)(1u << S.lim_log2) : -1;
+        lim16 = lim > 32768 ? 32768 : lim;
         trivial = (n == 0u) || (order == 0u);                 // nothing is predicted: any evaluation is exact
         h_ok = (lim >= 0) || trivial;
+        h16_ok = h_ok;                                        // (the history starts as zeros)
     }
     // x: residuals / warm-up samples of samples t0 .. t0+15  ->  y: the channel's samples before shift / decorrelation
     // hook(i), i = 0..15, is called exactly once per block, after sample i of the first evaluation
     template <typename Hook>
     __device__ __forceinline__ void block(const int32_t (&x)[CLX_BLK], int32_t (&y)[CLX_BLK], uint32_t t0, Hook&& hook) {
         bool done = false, hooked = false;
+        if (HAS16 && t0 >= (uint32_t)OMAX && __all(h16_ok)) {     // (past every lane's warm-up: nothing to mask)
+            int32_t pr[OMAX > 1 ? OMAX - 1 : 1];
+#pragma unroll
+            for (int j = 0; j + 1 < OMAX; ++j) pr[j] = (int32_t)clx_perm((uint32_t)hist[j], (uint32_t)hist[j + 1], 0x05040100u);     // (lo: the older sample, hi: the newer)
+            clx_dot2_block_any<OMAX>(x, y, pr, C2, shift, hist[0]);
+            int32_t mx = y[0], mn = y[0];
+#pragma unroll
+            for (int i = 1; i + 1 < CLX_BLK; i += 2) { mx = clx_max3(mx, y[i], y[i + 1]); mn = clx_min3(mn, y[i], y[i + 1]); }
+            mx = y[CLX_BLK - 1] > mx ? y[CLX_BLK - 1] : mx; mn = y[CLX_BLK - 1] < mn ? y[CLX_BLK - 1] : mn;
+            const bool in16 = trivial || t0 >= n || (mx < lim16 && mn >= -lim16);
+            if (__all(in16)) {
+#pragma unroll
+                for (int j = 0; j < OMAX; ++j) hist[j] = y[CLX_BLK - 1 - j];
+#pragma unroll
+                for (int i = 0; i < CLX_BLK; ++i) hook(i);
+                return;
+            }
+            h16_ok = in16;             // the lanes that left the range sit out until their history is back inside (below)
+        }
         if (__all(h_ok)) {
             hooked = true;
             int32_t h0[OMAX];
@@ -819,8 +857,10 @@ struct K2Predictor {
             for (int i = 1; i + 1 < CLX_BLK; i += 2) { mx = clx_max3(mx, y[i], y[i + 1]); mn = clx_min3(mn, y[i], y[i + 1]); }
             mx = y[CLX_BLK - 1] > mx ? y[CLX_BLK - 1] : mx; mn = y[CLX_BLK - 1] < mn ? y[CLX_BLK - 1] : mn;
             const bool in_range = trivial || t0 >= n || (mx < lim && mn >= -lim);
-            if (__all(in_range)) done = true;
-            else {
+            if (__all(in_range)) {
+                done = true;
+                if (HAS16) h16_ok = trivial || t0 >= n || (mx < lim16 && mn >= -lim16);
+            } else {
 #pragma unroll
                 for (int j = 0; j < OMAX; ++j) hist[j] = h0[j];
             }
@@ -828,10 +868,11 @@ struct K2Predictor {
         if (!done) {
             if (hooked) clx_iir_block<OMAX, true, true>(x, y, hist, c, t0, order, shift, K2NoHook());
             else        clx_iir_block<OMAX, true, true>(x, y, hist, c, t0, order, shift, hook);
-            bool ok = lim >= 0;
+            bool ok = lim >= 0, ok16 = lim16 >= 0;
 #pragma unroll
-            for (int j = 0; j < OMAX; ++j) ok = ok && hist[j] < lim && hist[j] >= -lim;
+            for (int j = 0; j < OMAX; ++j) { ok = ok && hist[j] < lim && hist[j] >= -lim; ok16 = ok16 && hist[j] < lim16 && hist[j] >= -lim16; }
             h_ok = ok || trivial || t0 + CLX_BLK >= n;
+            h16_ok = ok16 || trivial || t0 + CLX_BLK >= n;
         }
     }
 };
@@ -890,6 +931,28 @@ struct K2Finisher {
             hook(i);
         }
     }
+    // the same for samples LO .. HI-1 only, without the wasted-bits shift (shift_all does all 16 at once)
+    __device__ __forceinline__ void shift_all(int32_t (&y)[CLX_BLK]) const {
+        if (any_wasted) {
+#pragma unroll
+            for (int i = 0; i < CLX_BLK; ++i) y[i] = (int32_t)((uint32_t)y[i] << wasted);
+        }
+    }
+    template <int MODE, int LO, int HI>
+    __device__ __forceinline__ void decorrelate(int32_t (&y)[CLX_BLK]) const {
+#pragma unroll
+        for (int i = LO; i < HI; ++i) {
+            if (MODE == 0) y[i] = clx_ms_pair(y[i], sgn, nsg, 1u);
+            else if (MODE == 1) {
+                const int32_t mine = y[i];
+                const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+                const uint32_t P = (uint32_t)(p_other ? other : mine);
+                const uint32_t R = (uint32_t)(r_other ? other : mine) & rmask;
+                const uint32_t m = (P << s1) | (R & bit);
+                y[i] = (int32_t)(m + ((R ^ sg) - sg)) >> s1;
+            }
+        }
+    }
     __device__ __forceinline__ int mode() const { return all_ms ? 0 : any_decor ? 1 : 2; }
     template <typename Hook>
     __device__ __forceinline__ void block(int32_t (&y)[CLX_BLK], Hook&& hook) const {
@@ -940,7 +1003,11 @@ __device__ __forceinline__ void clx_predict_unaligned(const K2Slot& S, int32_t* 
 // instructions blocks the wave's issue for hundreds of cycles.  Its vmcnt counts 4 stores + 4 DMAs per turn, the turn's
 // last one a DMA (every turn, also the first two, whose stores go to the dump area): DMA(i+2), issued in turn
 // i+4-DEPTH, is followed by 8*(DEPTH-4) younger operations when turn i ends.
-#define CLX_K2_DEPTH 8
+
+#ifndef CLX_K2_PRIO
+#define CLX_K2_PRIO 3
+#endif
+#define CLX_K2_DEPTH 12       // tiles in a group's ring (see clx_load_wave for what it has to cover)
 
 // what a lane needs to move "its" 16 bytes of every tile: instruction k moves rows 16k .. 16k+15, 4 lanes per row
 struct K2Mover {
@@ -972,6 +1039,9 @@ __device__ __forceinline__ void clx_predict_wave(int4 (*ring)[4][64], const K2Sl
         }
     };
     int32_t xa[CLX_BLK], xb[CLX_BLK], y[CLX_BLK];
+    // this wave's chain is the kernel's duration: it goes first whenever it can issue, also past the Rice waves of another
+    // batch that share the SIMD when submissions are pipelined (clx_batch_submit)
+    __builtin_amdgcn_s_setprio(CLX_K2_PRIO);
     clx_wg_barrier();                          // tiles 0 and 1 have landed
     fetch(xa, 0u);
     // two turns per trip so that the "current" and "next" blocks alternate between xa and xb without copies
@@ -990,55 +1060,78 @@ __device__ __forceinline__ void clx_predict_wave(int4 (*ring)[4][64], const K2Sl
     for (uint32_t i = 0; i < nturn; i += 2u) { turn(xa, xb, i); if (i + 1u < nturn) turn(xb, xa, i + 1u); }
 }
 
+// ---- aligned rows, four waves per 64 rows (the latency build's current form) -----------------------------------------------
+// A two-wave schedule (predictor + one finisher that also moved the data) left both waves with ~240 instructions per turn, and a
+// turn lasts as long as the busier one.  Only the recurrence has to be one wave's serial chain: finishing a tile is independent
+// of finishing the next one, and moving tiles is independent of both.  So per 64 rows:
+//   predictor P, turn i : read x(i+1) | recurrence on x(i) | write y(i)                                  (clx_predict_wave)
+//   finisher F(i mod 2) : turn i+1: read y(i) | wasted shift | decorrelate samples 0..7
+//                         turn i+2: decorrelate samples 8..15 | tile | transposed read | 4 stores          (two turns per tile)
+//   loader L, turn t    : DMA of block t-3+DEPTH into the tile that F finished reading in turn t-1 | wait until block t+2 landed
+// and a turn is the predictor's chain and nothing else.  The loader's vmcnt counts LDS-DMA loads only (the finishers issue the
+// stores): block j, requested in turn j+3-DEPTH, is followed by the DEPTH-5 younger blocks (4 loads each) when the turn before
+// the predictor's read of it ends.  (One wave that mixes stores and DMAs under a counted vmcnt decoded wrongly under load with
+// less than ~3 us between request and use.)
 template <int MODE>
-__device__ __forceinline__ void clx_finish_wave(int4 (*ring)[4][64], int4 (*scratch)[64], int32_t* __restrict__ out, const K2Slot& S,
-                                                const K2Finisher& F, int32_t* __restrict__ dump, uint32_t nblk, int lane CLX_TL_PARAM) {
+__device__ __forceinline__ void clx_finish_wave_alt(int4 (*ring)[4][64], int32_t* __restrict__ out, const K2Slot& S, const K2Finisher& F,
+                                                    int32_t* __restrict__ dump, uint32_t nblk, uint32_t parity, int lane CLX_TL_PARAM) {
     constexpr int DEPTH = CLX_K2_DEPTH;
     K2Mover M; M.init(out, S, lane);
     const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // lane = row view
-    auto dma1 = [&](uint32_t blk, int k) __attribute__((always_inline)) {
-        const uint32_t t = blk * CLX_BLK + 4u * M.pc;
-        const uint32_t last = M.rn[k] >= 4u ? M.rn[k] - 4u : 0u;                  // clamped: what lies past a row's end is never stored
-        clx_glds16(M.rp[k] + (t < last ? t : last), clx_lds_addr(&ring[blk % DEPTH][k][0]));
-    };
-    for (uint32_t i = 0; i + 2u < (uint32_t)DEPTH; ++i) {                          // tiles 0 .. DEPTH-3; turn i refills with block i-2+DEPTH
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dma1(i, k);
-    }
-    clx_wait_vmcnt<4 * (DEPTH - 4)>();         // tiles 0 and 1
-    clx_wg_barrier();
-    // block i-2 in the instruction view, read from its tile at the end of turn i-1
-    int4 w0 = make_int4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
-    const uint32_t nturn = nblk + 2u;
-    // The loop body is one straight line: turns that have nothing to finish (the first, the last) work on a scratch tile,
-    // turns that have nothing to store (the first two) store to the dump area.
-    for (uint32_t i = 0; i < nturn; ++i) {
-        const bool have_store = i >= 2u;                       // (i - 2 < nblk always holds inside the loop)
-        const bool have_block = i >= 1u && i <= nblk;
-        const uint32_t t_st = (i - 2u) * CLX_BLK + 4u * M.pc;
-        int4* const tile = have_block ? &ring[(i - 1u) % DEPTH][0][0] : &scratch[0][0];
+    clx_wg_barrier();                          // = the predictor's first barrier: tiles 0 and 1 are there
+    const uint32_t nturn = nblk + 2u;          // barriers after the first one (clx_predict_wave)
+    uint32_t done = 0;                         // barriers passed
+    // turns before this wave's first tile is written: 0 (and 1 for the odd finisher)
+    for (uint32_t i = 0; i <= parity; ++i) { CLX_TL_WAIT(clx_wg_barrier()); ++done; }
+    for (uint32_t k = parity; k < nblk; k += 2u) {
+        int4* const tile = &ring[k % DEPTH][0][0];
         int32_t y[CLX_BLK];
+        // ---- turn k+1
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
             const int4 v = tile[(uint32_t)lane * 4u + (q ^ sw)];
             y[4 * q] = v.x; y[4 * q + 1] = v.y; y[4 * q + 2] = v.z; y[4 * q + 3] = v.w;
         }
-        // (w0..w3 are separate variables and the hook spells its four cases out: an array indexed by smp >> 2 is
-        //  sent to scratch memory, whose loads would both drain the ring -- vmcnt(0) -- and break the vmcnt count)
-        auto move = [&](int k, const int4& wk) __attribute__((always_inline)) {
-            int32_t* p = (have_store && t_st < M.rn[k]) ? const_cast<int32_t*>(M.rp[k]) + t_st : dump + 4 * k;
-            *reinterpret_cast<int4*>(p) = wk;
-            dma1(i - 2u + DEPTH, k);
-        };
-        F.template block<MODE>(y, [&](int smp) __attribute__((always_inline)) {
-            if (smp == 1) move(0, w0); else if (smp == 5) move(1, w1); else if (smp == 9) move(2, w2); else if (smp == 13) move(3, w3);
-        });
+        F.shift_all(y);
+        F.template decorrelate<MODE, 0, CLX_BLK / 2>(y);
+        CLX_TL_WAIT(clx_wg_barrier()); ++done;
+        // ---- turn k+2
+        F.template decorrelate<MODE, CLX_BLK / 2, CLX_BLK>(y);
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) tile[(uint32_t)lane * 4u + (q ^ sw)] = make_int4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
         clx_wave_sync();
-        w0 = tile[lane]; w1 = tile[64 + lane]; w2 = tile[128 + lane]; w3 = tile[192 + lane];
-        if (i + 5u <= (uint32_t)DEPTH) clx_wait_vmcnt<4 * (DEPTH - 3)>(); else clx_wait_vmcnt<8 * (DEPTH - 4)>();
-        CLX_TL_WAIT(clx_wg_barrier());                       // (also waits for the LDS reads: the next turn's DMA may refill the tile)
+        const int4 w0 = tile[lane], w1 = tile[64 + lane], w2 = tile[128 + lane], w3 = tile[192 + lane];
+        const uint32_t t_st = k * CLX_BLK + 4u * M.pc;
+        auto move = [&](int kk, const int4& wk) __attribute__((always_inline)) {
+            int32_t* p = (t_st < M.rn[kk]) ? const_cast<int32_t*>(M.rp[kk]) + t_st : dump + 4 * kk;
+            *reinterpret_cast<int4*>(p) = wk;
+        };
+        move(0, w0); move(1, w1); move(2, w2); move(3, w3);
+        CLX_TL_WAIT(clx_wg_barrier()); ++done;             // (also waits for the LDS reads: the loader may refill the tile next turn)
+    }
+    while (done < nturn) { CLX_TL_WAIT(clx_wg_barrier()); ++done; }
+}
+
+__device__ __forceinline__ void clx_load_wave(int4 (*ring)[4][64], const int32_t* __restrict__ out, const K2Slot& S, uint32_t nblk, int lane CLX_TL_PARAM) {
+    constexpr int DEPTH = CLX_K2_DEPTH;
+    static_assert(4 * DEPTH < 64, "vmcnt is a 6-bit counter: the whole ring is requested at once at the start");
+    K2Mover M; M.init(out, S, lane);
+    auto dma = [&](uint32_t blk) __attribute__((always_inline)) {
+        const uint32_t t = blk * CLX_BLK + 4u * M.pc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t last = M.rn[k] >= 4u ? M.rn[k] - 4u : 0u;              // clamped: what lies past a row's end is never stored
+            clx_glds16(M.rp[k] + (t < last ? t : last), clx_lds_addr(&ring[blk % DEPTH][k][0]));
+        }
+    };
+    for (uint32_t i = 0; i < (uint32_t)DEPTH; ++i) dma(i);
+    clx_wait_vmcnt<4 * (DEPTH - 2)>();         // tiles 0 and 1
+    clx_wg_barrier();
+    const uint32_t nturn = nblk + 2u;
+    for (uint32_t t = 0; t < nturn; ++t) {
+        if (t >= 3u) dma(t - 3u + (uint32_t)DEPTH);            // (wave-uniform; the loader has no other memory operation to disturb)
+        clx_wait_vmcnt<4 * (DEPTH - 5)>();                      // block t+2 has landed: the predictor reads it next turn
+        CLX_TL_WAIT(clx_wg_barrier());
     }
     clx_wait_vmcnt<0>();
 }
@@ -1111,21 +1204,20 @@ __device__ __forceinline__ void clx_predict_single_mode(int4 (*ring)[4][64], int
     else                clx_predict_single<OMAX, 2, DEPTH>(ring, out, S, F, dump, nblk, lane);
 }
 
-// Workgroup = 4 waves = two (predictor, finisher) pairs, 64 rows each.  Four waves so that a workgroup fills the four
-// SIMDs of its CU by construction: with two-wave workgroups, CUs that receive two workgroups sometimes get both
-// predictors on ONE SIMD (measured with tools/timeline.py: 245 us against 170 us for an undisturbed pair, and the
-// kernel lasts as long as its slowest wave).  The pairs share nothing but the barrier.
-extern "C" __global__ __launch_bounds__(256)
+// Workgroup = 8 waves = two groups of 64 rows, each with a predictor, two finishers and a loader.  Waves go to the CU's four
+// SIMDs in cyclic order: waves w and w+4 share one.  The predictors (waves 0, 1), whose chains decide the kernel's duration,
+// share theirs with the loaders (waves 4, 5: a handful of instructions per turn); the finishers (2, 3, 6, 7) share the other two.
+// The groups share nothing but the barrier.
+extern "C" __global__ __launch_bounds__(512)
 void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     CLX_TL_BEGIN();
-    __shared__ int4 ring2[2][CLX_K2_DEPTH][4][64];    // per pair 32 KiB: 8 tiles x 64 B of each of its 64 rows
-    __shared__ int4 scratch2[2][4][64];               // per pair a tile nobody reads, for the finisher's idle turns
+    __shared__ int4 ring2[2][CLX_K2_DEPTH][4][64];    // per group 48 KiB: 12 tiles x 64 B of each of its 64 rows
     const int lane = (int)threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t pair = wave & 1u;
-    const bool finisher = wave >= 2u;              // wave-uniform
+    const uint32_t role = wave >> 1;               // 0: predictor, 1: finisher of the even tiles, 2: loader, 3: finisher of the odd tiles
+    const bool finisher = (role & 1u) != 0u;       // wave-uniform
     int4 (*ring)[4][64] = ring2[pair];
-    int4 (*scratch)[64] = scratch2[pair];
     const uint32_t group = blockIdx.x * 2u + pair;
     const uint32_t slot = group * 64u + (uint32_t)lane;
     K2Slot S;
@@ -1148,11 +1240,11 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
         uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
         uint32_t o = __shfl_xor(omax, s, 64); omax = o > omax ? o : omax;
     }
-    int32_t* const dump = dump_all + (size_t)(group * 64u + (uint32_t)lane) * CLX_BLK;      // 64 bytes per lane (finisher / unaligned only)
+    int32_t* const dump = dump_all + (size_t)(group * 64u + (uint32_t)lane) * CLX_BLK;      // 64 bytes per lane (finishers / unaligned only)
     const bool work = (S.order != 0u) || (S.wasted != 0u) || S.pair_ok;
     // rows of nothing but CONSTANT / VERBATIM / FIXED-0 mono subframes without wasted bits are already final
-    // (both waves of a pair see the same 64 slots, so every decision below is the same in both; a wave that returns
-    //  no longer takes part in the workgroup's barriers)
+    // (the three waves of a group see the same 64 slots, so every decision below is the same in all of them; a wave that
+    //  returns no longer takes part in the workgroup's barriers)
     if (nmax == 0u || !__any(work)) return;
     // 16-byte row accesses need 16-byte aligned rows whose length is a multiple of 4 samples
     const bool al = (S.n == 0u) || ((((uintptr_t)S.row) & 15u) == 0u && (S.n & 3u) == 0u);
@@ -1161,21 +1253,23 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
         if (finisher) {
             K2Finisher F; F.init(S, lane);
             const int mode = F.mode();
-            if (mode == 0)      clx_finish_wave<0>(ring, scratch, out, S, F, dump, nblk, lane CLX_TL_ARG);
-            else if (mode == 1) clx_finish_wave<1>(ring, scratch, out, S, F, dump, nblk, lane CLX_TL_ARG);
-            else                clx_finish_wave<2>(ring, scratch, out, S, F, dump, nblk, lane CLX_TL_ARG);
+            const uint32_t parity = role >> 1;
+            if (mode == 0)      clx_finish_wave_alt<0>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
+            else if (mode == 1) clx_finish_wave_alt<1>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
+            else                clx_finish_wave_alt<2>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
         }
+        else if (role == 2u)  clx_load_wave(ring, out, S, nblk, lane CLX_TL_ARG);
         else if (omax <= 4u)  clx_predict_wave<4>(ring, S, nblk, lane CLX_TL_ARG);
         else if (omax <= 8u)  clx_predict_wave<8>(ring, S, nblk, lane CLX_TL_ARG);
         else if (omax <= 12u) clx_predict_wave<12>(ring, S, nblk, lane CLX_TL_ARG);
         else                  clx_predict_wave<32>(ring, S, nblk, lane CLX_TL_ARG);
-    } else if (!finisher) {
+    } else if (role == 0u) {
         if (omax <= 4u)       clx_predict_unaligned<4>(S, dump, nmax, lane);
         else if (omax <= 8u)  clx_predict_unaligned<8>(S, dump, nmax, lane);
         else if (omax <= 12u) clx_predict_unaligned<12>(S, dump, nmax, lane);
         else                  clx_predict_unaligned<32>(S, dump, nmax, lane);
     }
-    CLX_TL_END(1, blockIdx.x * 4u + (threadIdx.x >> 6));
+    CLX_TL_END(1, blockIdx.x * 8u + (threadIdx.x >> 6));
 }
 
 // K2, throughput build (see clx_predict_single): one wave per 64 rows, picked by the host for large batches.

@@ -11,6 +11,8 @@ __device__ __forceinline__ uint32_t clx_alignbit(uint32_t hi, uint32_t lo, uint3
 __device__ __forceinline__ uint32_t clx_bfe(uint32_t src, uint32_t offset, uint32_t width) {
     return __builtin_amdgcn_ubfe(src, offset, width);
 }
+// v_perm_b32: byte i of the result is byte sel[8i+7:8i] of the 8-byte value {hi, lo} (selectors 0-3: lo, 4-7: hi)
+__device__ __forceinline__ uint32_t clx_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // v_mad_i32_i24: low 32 bits of sext24(a)*sext24(b) + c.  Inline asm so that the accumulation stays a chain in
 // the order written (oldest tap first, newest last): only the last mad then depends on the newest sample.
 __device__ __forceinline__ int32_t clx_mad24(int32_t a, int32_t b, int32_t c) {

@@ -11,6 +11,12 @@ static inline uint32_t clx_bfe(uint32_t src, uint32_t offset, uint32_t width) {
     if (width == 0u) return 0u;
     return (src >> offset) & (width >= 32u ? 0xffffffffu : ((1u << width) - 1u));
 }
+static inline uint32_t clx_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) { const uint32_t b = (sel >> (8 * i)) & 0xffu; r |= (b < 8u ? (uint32_t)((v >> (8 * b)) & 0xffu) : (b >= 13u ? 0xffu : 0u)) << (8 * i); }
+    return r;
+}
 static inline int32_t clx_mad24(int32_t a, int32_t b, int32_t c) {
     return (int32_t)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8) + (uint32_t)c);
 }

@@ -50,7 +50,7 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         SIM_LAUNCH(clx_k_predict_1w, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data());
         SIM_LAUNCH(clx_k_predict_1w_hi, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data());
     }
-    else SIM_LAUNCH(clx_k_predict, (n_slots + 127) / 128, 256, out, sfd.data(), (uint32_t)n_slots, dump.data());
+    else SIM_LAUNCH(clx_k_predict, (n_slots + 127) / 128, 512, out, sfd.data(), (uint32_t)n_slots, dump.data());
     if (flags & CLX_VERIFY_CRC16)
         SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
     return CLX_OK;

@@ -18,13 +18,14 @@ for _ in range(5):
     batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), 0)
 torch.cuda.synchronize()
 nslot_waves = (2 * n + 63) // 64
-kernels = [(0, "clx_k_residual", n), (1, "clx_k_predict", 4 * ((nslot_waves + 1) // 2))] if path == "waves" else \
+kernels = [(0, "clx_k_residual", n), (1, "clx_k_predict", 8 * ((nslot_waves + 1) // 2))] if path == "waves" else \
           [(2, "clx_k_scan", (n + 63) // 64), (3, "clx_k_lanes", nslot_waves)]
 cx.lib().clx_debug_timeline.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
 for kid, name, nw in kernels:
     nw = min(nw, 65536)
     tl = np.zeros((nw, 14), dtype=np.uint64)
     assert cx.lib().clx_debug_timeline(kid, tl.ctypes.data_as(C.c_void_p), nw) == 0
+    ids = np.nonzero(tl[:, 1] != 0)[0]
     tl = tl[tl[:, 1] != 0]
     r0, r1, c0, c1 = (tl[:, i].astype(np.int64) for i in range(4))
     hw = tl[:, 4]
@@ -58,6 +59,13 @@ for kid, name, nw in kernels:
         sel = key == u
         shape[tuple(sorted(np.bincount(simd[sel], minlength=4).tolist(), reverse=True))] += 1
     print(f"   SIMD occupancy shapes of CUs with more than one wave: {dict(shape)}")
+    if name == "clx_k_predict" and tl[:, 5].any():
+        # the eight waves of a workgroup by role: 0,1 predictors, 2,3 finishers (even tiles), 4,5 loaders, 6,7 finishers (odd tiles)
+        wt = tl[:, 5].astype(np.int64) / np.maximum(c1 - c0, 1)
+        for role, rname in enumerate(("predictor", "finisher even", "loader", "finisher odd")):
+            sel = ((ids % 8) >> 1) == role
+            if sel.any():
+                print(f"   {rname:14s}: {int(sel.sum())} waves, duration us {q(dur_us[sel])}, share of time in barriers % {q(wt[sel] * 100)}")
     if name == "clx_k_predict":
         for u in uniq[cnt > 2][:3]:
             sel = np.nonzero(key == u)[0]
