@@ -387,6 +387,8 @@ extern "C" int clx_batch_set_profiling(clx_batch* b, int enable) {
 }
 
 namespace {
+// K3: four frames per workgroup at a time; beyond 8 workgroups per CU the waves loop
+unsigned crc_grid(size_t n) { return (unsigned)std::min<size_t>((n + 3) / 4, 2048); }
 // clamp every frame's readable span against the arena and upload the plan (once per arena size)
 int upload_plan(clx_batch* b, size_t arena_len, hipStream_t stream) {
     clx_ctx* ctx = b->ctx;
@@ -492,7 +494,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     }
     if (b->flags & CLX_VERIFY_CRC16) {
         if (!mark("clx_k_crc16")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_crc16, dim3((unsigned)b->n), dim3(64), 0, stream, d_arena,
+        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, b->d_results);
     }
     if (b->profiling) { if (!mark(nullptr)) return CLX_API_ERROR; b->n_kernels = nk - 1; b->ev_valid = true; }
@@ -554,7 +556,7 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, b->stream2, d_out, (const clx_sf_desc*)sfd, (uint32_t)b->n_slots, b->d_dump);
     HIP_TRY(ctx, hipEventRecord(b->ev_stage2[slot], b->stream2));
     if (b->flags & CLX_VERIFY_CRC16)       // needs stage 1's end_bit only: runs beside the predictor stage
-        hipLaunchKernelGGL(clx_k_crc16, dim3((unsigned)b->n), dim3(64), 0, stream, d_arena, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, results);
+        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, results);
     b->stage2_pending[slot] = true;
     b->pending_out[slot] = d_out;
     b->last_slot = slot;

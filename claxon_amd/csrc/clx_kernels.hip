@@ -1004,9 +1004,6 @@ __device__ __forceinline__ void clx_predict_unaligned(const K2Slot& S, int32_t* 
 // last one a DMA (every turn, also the first two, whose stores go to the dump area): DMA(i+2), issued in turn
 // i+4-DEPTH, is followed by 8*(DEPTH-4) younger operations when turn i ends.
 
-#ifndef CLX_K2_PRIO
-#define CLX_K2_PRIO 3
-#endif
 #define CLX_K2_DEPTH 12       // tiles in a group's ring (see clx_load_wave for what it has to cover)
 
 // what a lane needs to move "its" 16 bytes of every tile: instruction k moves rows 16k .. 16k+15, 4 lanes per row
@@ -1039,9 +1036,8 @@ __device__ __forceinline__ void clx_predict_wave(int4 (*ring)[4][64], const K2Sl
         }
     };
     int32_t xa[CLX_BLK], xb[CLX_BLK], y[CLX_BLK];
-    // this wave's chain is the kernel's duration: it goes first whenever it can issue, also past the Rice waves of another
-    // batch that share the SIMD when submissions are pipelined (clx_batch_submit)
-    __builtin_amdgcn_s_setprio(CLX_K2_PRIO);
+    // (raising this wave's issue priority with s_setprio -- its chain is the kernel's duration -- changed nothing measurable,
+    //  alone or beside the Rice waves of a pipelined submission: 0.369 against 0.371 ms per step)
     clx_wg_barrier();                          // tiles 0 and 1 have landed
     fetch(xa, 0u);
     // two turns per trip so that the "current" and "next" blocks alternate between xa and xb without copies
@@ -1371,34 +1367,108 @@ __host__ __device__ __forceinline__ uint32_t clx_xpow8_64(uint64_t nbytes) {
     return result;
 }
 
-extern "C" __global__ __launch_bounds__(64)
+// K3 tables, generated at compile time (constant memory), copied to LDS by every workgroup:
+//   t[k][v]  state after byte v followed by k zero bytes, from state 0 ("slicing by 4": a dword of the message is four
+//            independent look-ups instead of four dependent ones)
+//   gap[h][v] (v << 8h) * x^(8*1008) mod P: carries a lane's running CRC over the 1008 bytes that the other lanes cover
+//            before its next 16
+//   lane[L]  x^(8*16*(63-L)) mod P: what lane L's CRC is multiplied by in the final sum (its bytes are followed by the 63-L
+//            later lanes' 16 each)
+struct K3Rom { uint16_t t[4][256]; uint16_t gap[2][256]; uint16_t lane[64]; };
+constexpr uint32_t clx_c_mulmod(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+    for (int i = 15; i >= 0; --i) {
+        r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu;
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+constexpr uint32_t clx_c_xpow8(uint32_t nbytes) {
+    uint32_t result = 1u, base = 0x0100u;
+    while (nbytes) { if (nbytes & 1u) result = clx_c_mulmod(result, base); base = clx_c_mulmod(base, base); nbytes >>= 1; }
+    return result;
+}
+constexpr K3Rom clx_make_k3_rom() {
+    K3Rom r{};
+    for (uint32_t v = 0; v < 256u; ++v) {
+        uint32_t c = v << 8;
+        for (int i = 0; i < 8; ++i) c = (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu;
+        r.t[0][v] = (uint16_t)c;
+    }
+    for (uint32_t k = 1; k < 4u; ++k)
+        for (uint32_t v = 0; v < 256u; ++v) { const uint32_t c = r.t[k - 1][v]; r.t[k][v] = (uint16_t)(((c << 8) & 0xffffu) ^ r.t[0][c >> 8]); }
+    const uint32_t g = clx_c_xpow8(1008u);
+    for (uint32_t v = 0; v < 256u; ++v) { r.gap[0][v] = (uint16_t)clx_c_mulmod(v, g); r.gap[1][v] = (uint16_t)clx_c_mulmod(v << 8, g); }
+    for (uint32_t L = 0; L < 64u; ++L) r.lane[L] = (uint16_t)clx_c_xpow8(16u * (63u - L));
+    return r;
+}
+__constant__ K3Rom clx_k3_rom = clx_make_k3_rom();
+
+// One wavefront per frame (four per workgroup, which share the tables; a wave takes frames f, f + waves, ...).  The frame's bytes
+// are taken in rounds of 1 KiB that END at the frame's end -- lane L the 16 bytes [1024 r + 16 L, +16) of the round -- so the
+// first round starts in front of the frame: those bytes count as zeros, which a CRC with initial value 0 does not see
+// (crc.rs:109-112).  Every position then has a multiplier that does not depend on the frame's length.
+extern "C" __global__ __launch_bounds__(256)
 void clx_k_crc16(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
                  clx_frame_result* __restrict__ results) {
-    const int lane = (int)threadIdx.x;
-    const uint32_t f = blockIdx.x;
-    if (f >= n_frames) return;
-    const clx_dev_frame fr = frames[f];
-    clx_frame_result r = results[f];
-    if (r.status != CLX_OK || (fr.flags & 1u)) return;
-    const uint32_t nbytes = (uint32_t)((r.end_bit + 7u) >> 3);
-    if ((uint64_t)nbytes * 8u + 16u > (uint64_t)fr.limit_bits) {           // read_be_u16 fails: frame.rs:754
-        if (lane == 0) { results[f].status = CLX_IO_ERROR; results[f].msg = CLX_MSG_UNEXPECTED_EOF; }
-        return;
+    __shared__ K3Rom T;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&clx_k3_rom);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&T);
+        for (uint32_t i = threadIdx.x; i < sizeof(K3Rom) / 4u; i += 256u) dst[i] = src[i];
     }
-    const uint8_t* p = arena + fr.byte_off;
-    const uint32_t per = (nbytes + 63u) / 64u;
-    const uint32_t lo = (uint32_t)lane * per < nbytes ? (uint32_t)lane * per : nbytes;
-    const uint32_t hi = lo + per < nbytes ? lo + per : nbytes;
-    uint32_t crc = 0;
-    for (uint32_t i = lo; i < hi; ++i) crc = clx_crc16_byte(crc, p[i]);
-    // combine: lane L's CRC must be advanced over all bytes to its right
-    const uint32_t tail = nbytes - hi;
-    uint32_t contrib = (hi > lo) ? clx_gf_mulmod(crc, clx_xpow8(tail)) : 0u;
+    __syncthreads();
+    const int lane = (int)threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6, n_waves = gridDim.x * 4u;
+    for (uint32_t f = blockIdx.x * 4u + wave; f < n_frames; f += n_waves) {
+        const clx_dev_frame fr = frames[f];
+        const clx_frame_result r = results[f];
+        if (r.status != CLX_OK || (fr.flags & 1u)) continue;                 // wave-uniform
+        const uint32_t nbytes = (uint32_t)((r.end_bit + 7u) >> 3);
+        if ((uint64_t)nbytes * 8u + 16u > (uint64_t)fr.limit_bits) {           // read_be_u16 fails: frame.rs:754
+            if (lane == 0) { results[f].status = CLX_IO_ERROR; results[f].msg = CLX_MSG_UNEXPECTED_EOF; }
+            continue;
+        }
+        const uint8_t* const p = arena + fr.byte_off;
+        const uint32_t rounds = (nbytes + 1023u) >> 10;
+        // byte offset (relative to the frame's first byte) of this lane's 16 bytes in round 0; negative in front of the frame
+        int32_t o = (int32_t)nbytes - (int32_t)(rounds << 10) + 16 * lane;
+        uint32_t crc = 0;
+        for (uint32_t rd = 0; rd < rounds; ++rd, o += 1024) {
+            // the 16 message bytes as four little-endian dwords (byte 0 first = lowest byte of w[0])
+            uint32_t w[4];
+            if (o >= 0) {
+                const uintptr_t adr = (uintptr_t)(p + o);
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(adr & ~(uintptr_t)3);
+                const uint32_t sh = 8u * (uint32_t)(adr & 3u);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];   // (the arena is padded by 16 bytes: claxon_hip.h)
+                w[0] = clx_alignbit(d1, d0, sh); w[1] = clx_alignbit(d2, d1, sh); w[2] = clx_alignbit(d3, d2, sh); w[3] = clx_alignbit(d4, d3, sh);
+            } else {
+                // (only in round 0, only the lanes in front of the frame's first byte) byte by byte, zeros in front
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) contrib ^= __shfl_xor(contrib, s, 64);
-    if (lane == 0) {
-        const uint32_t presumed = ((uint32_t)p[nbytes] << 8) | (uint32_t)p[nbytes + 1];
-        if (contrib != presumed) { results[f].status = CLX_FORMAT_ERROR; results[f].msg = CLX_MSG_FRAME_CRC_MISMATCH; }
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int32_t at = o + 4 * k + j; if (at >= 0) v |= (uint32_t)p[at] << (8 * j); }
+                    w[k] = v;
+                }
+            }
+            if (rd != 0u) crc = (uint32_t)T.gap[1][crc >> 8] ^ (uint32_t)T.gap[0][crc & 0xffu];      // over the other lanes' 1008 bytes
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // state folded into the first two bytes, then four independent look-ups
+                const uint32_t t = w[k] ^ (crc >> 8) ^ ((crc & 0xffu) << 8);
+                crc = (uint32_t)T.t[3][t & 0xffu] ^ (uint32_t)T.t[2][(t >> 8) & 0xffu] ^ (uint32_t)T.t[1][(t >> 16) & 0xffu] ^ (uint32_t)T.t[0][t >> 24];
+            }
+        }
+        // crc(A || B) = crc(A) * x^(8|B|) xor crc(B): every lane's bytes are followed by the later lanes' 16 each
+        uint32_t contrib = clx_gf_mulmod(crc, (uint32_t)T.lane[lane]);
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) contrib ^= __shfl_xor(contrib, s2, 64);
+        if (lane == 0) {
+            const uint32_t presumed = ((uint32_t)p[nbytes] << 8) | (uint32_t)p[nbytes + 1];
+            if (contrib != presumed) { results[f].status = CLX_FORMAT_ERROR; results[f].msg = CLX_MSG_FRAME_CRC_MISMATCH; }
+        }
     }
 }
 

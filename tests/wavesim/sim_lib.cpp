@@ -37,7 +37,7 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
                        errkey.data(), endbits.data(), dump.data());
         }
         SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, dev.data(), errkey.data(), endbits.data(), (uint32_t)n, results);
-        if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
+        if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16, (n + 3) / 4, 256, arena, dev.data(), (uint32_t)n, results);
         return CLX_OK;
     }
     SIM_LAUNCH(clx_k_residual, n, 64, arena, alloc_len, dev.data(), (uint32_t)n, out, sfd.data(), results);
@@ -52,7 +52,7 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
     }
     else SIM_LAUNCH(clx_k_predict, (n_slots + 127) / 128, 512, out, sfd.data(), (uint32_t)n_slots, dump.data());
     if (flags & CLX_VERIFY_CRC16)
-        SIM_LAUNCH(clx_k_crc16, n, 64, arena, dev.data(), (uint32_t)n, results);
+        SIM_LAUNCH(clx_k_crc16, (n + 3) / 4, 256, arena, dev.data(), (uint32_t)n, results);
     return CLX_OK;
 }
 
