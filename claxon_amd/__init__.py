@@ -83,7 +83,7 @@ assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
 
 EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
-    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_subframes", "clx_interleave",
+    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_frames_multi", "clx_decode_subframes", "clx_interleave",
     "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
     "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
@@ -147,6 +147,7 @@ def lib():
     L.clx_decode_frames.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, C.c_uint32]
     L.clx_decode_subframes.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, C.c_uint32]
     L.clx_batch_create.argtypes = [vp, vp, sz, vp, C.c_uint32, C.POINTER(vp)]
+    L.clx_decode_frames_multi.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, C.c_uint32]
     L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_submit.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_flush.argtypes = [vp, vp]
@@ -368,6 +369,23 @@ def descs_for_subframes(offs, block_sizes, bps):
 
 
 # ----------------------------------------------------------------------------- device objects
+
+def decode_frames_multi(ctxs, arena, descs, out_offs, out=None, verify_crc=False, path=0):
+    """clx_decode_frames_multi: one batch, several contexts (one per GPU, or several on one), no exchange between them."""
+    a = _u8(arena)
+    descs = np.ascontiguousarray(descs, dtype=FRAME_DESC_DTYPE)
+    out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+    n = descs.size
+    total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+    if out is None:
+        out = np.zeros(total, dtype=np.int32)
+    res = np.zeros(n, dtype=FRAME_RESULT_DTYPE)
+    hs = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    st = lib().clx_decode_frames_multi(hs, len(ctxs), _np_ptr(a), a.size, _np_ptr(descs), n, _np_ptr(out), _np_ptr(out_offs),
+                                       _np_ptr(res), (VERIFY_CRC16 if verify_crc else 0) | path)
+    ctxs[0]._check(st)
+    return out, res
+
 
 def _wait_for_gpu_node(deadline):
     """Poll (in child processes) until the kernel driver exposes a gfx950 agent or the deadline passes."""

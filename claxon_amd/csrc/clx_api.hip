@@ -16,6 +16,7 @@
 #include <string>
 #include <memory>
 #include <vector>
+#include <thread>
 
 #include "clx_plan.h"
 #include "host/claxon.hpp"
@@ -225,6 +226,7 @@ struct clx_ctx {
 struct clx_batch {
     clx_ctx* ctx = nullptr;
     int device = 0;
+    clx_path_choice choice = { false, true };
     size_t n = 0;
     uint64_t n_slots = 0;
     uint32_t flags = 0;
@@ -346,15 +348,19 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
         clx_batch_destroy(b); return CLX_API_ERROR;
     }
     for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
-    // path: explicit flag, else by batch shape -- the lane-serial kernels need many independent subframes to fill
-    // the machine (their duration is one lane's serial chain: ~0.7-0.9 ms for 4096-sample subframes however few there
-    // are, until every SIMD has a wave), the wave-per-frame kernels scale with the batch (0.44 ms per 10k stereo
-    // frames).  Measured on MI355X, BASELINE configs[2] frames (tools/sweep_paths.py), ms for
-    // waves / lanes two-wave build / lanes fused build: 32k subframes 0.58 / 0.71 / 0.87; 40k 0.77 / 1.17 / 0.92;
-    // 48k 0.85 / 1.17 / 0.93; 64k 1.08 / 1.18 / 0.97 -- the curves cross near 54k subframes.  Frames of mixed shapes and
-    // higher bit rates (synth.config5) cost the wave path more per frame than the lane path, so the switch sits a
-    // little below that.
-    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : (slot >= 48000);
+    // path: explicit flag, else by the batch's shape and content (clx_select_path, clx_plan.h)
+    {
+        uint64_t samples = 0, wide = 0, bytes = 0; bool all_mono = true, lengths_known = true;
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t sm = (uint64_t)frames[i].n_channels * frames[i].block_size;
+            samples += sm;
+            if (frames[i].bps > 16) wide += sm;
+            if (frames[i].max_bytes >= (1u << 24)) lengths_known = false; else bytes += frames[i].max_bytes;
+            all_mono = all_mono && frames[i].n_channels == 1;
+        }
+        b->choice = clx_select_path(slot, samples, lengths_known ? bytes : 0, 4 * wide >= samples && samples != 0, all_mono);
+    }
+    b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : b->choice.lanes;
     {   // where stores that fall outside a row go (K2 and D2 keep their store instructions unconditional)
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
@@ -455,7 +461,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         }
         // the two-wave (latency) build while its workgroups get a CU each (0.50 ms against 1.00 ms at 20k subframes), the fused
         // single-wave (throughput) build beyond (1.28 against 1.34 ms at 48k subframes); CLX_LANES_FUSED / CLX_LANES_SPLIT force one
-        const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false : b->n_slots <= 32768;
+        const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false : b->choice.lanes_split;
         if (!mark(split ? "clx_k_lanes2" : "clx_k_lanes")) return CLX_API_ERROR;     // (clx_k_lanes: + clx_k_lanes_hi, its order > 12 twin)
         if (!split) {
             hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
@@ -658,6 +664,63 @@ extern "C" int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t aren
     }
     cleanup();
     return st;
+}
+
+// Several contexts (one per GPU, or several on one GPU) decode one batch: SURVEY section 8(e).  Frames are independent
+// (frame.rs:667-779 touches only its own bytes and buffer), so the batch is cut into contiguous ranges of near-equal algorithmic
+// weight (compressed bytes + 4 B per decoded sample), every range is decoded by one context on a host thread of its own --
+// only its slice of the arena goes to that device -- and nothing is exchanged between them.  Host buffers only.
+extern "C" int clx_decode_frames_multi(clx_ctx* const* ctxs, size_t n_ctx, const uint8_t* arena, size_t arena_len,
+                                       const clx_frame_desc* frames, size_t n, int32_t* out, const uint64_t* out_sample_offsets,
+                                       clx_frame_result* results, uint32_t flags) {
+    if (!ctxs || n_ctx == 0) return CLX_API_ERROR;
+    for (size_t c = 0; c < n_ctx; ++c) if (!ctxs[c]) return CLX_API_ERROR;
+    if (n == 0) return CLX_OK;
+    if (flags & (CLX_ARENA_ON_DEVICE | CLX_OUT_ON_DEVICE)) { ctxs[0]->last_error = "clx_decode_frames_multi takes host buffers"; return CLX_API_ERROR; }
+    if (!arena || !frames || !out || !out_sample_offsets || !results) { ctxs[0]->last_error = "null argument"; return CLX_API_ERROR; }
+    // a context's share must own a contiguous piece of `out`: frames in increasing, non-overlapping output order
+    for (size_t i = 1; i < n; ++i)
+        if (out_sample_offsets[i] < out_sample_offsets[i - 1] + (uint64_t)frames[i - 1].n_channels * frames[i - 1].block_size) n_ctx = 1;
+    std::vector<double> cum(n + 1, 0.0);
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t avail = frames[i].byte_off < arena_len ? (uint64_t)arena_len - frames[i].byte_off : 0;
+        cum[i + 1] = cum[i] + (double)std::min<uint64_t>(frames[i].max_bytes, avail) + 4.0 * frames[i].n_channels * frames[i].block_size;
+    }
+    std::vector<size_t> cut(n_ctx + 1, n);
+    cut[0] = 0;
+    for (size_t c = 1; c < n_ctx; ++c) {
+        const double target = cum[n] * (double)c / (double)n_ctx;
+        size_t i = (size_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        cut[c] = std::min(std::max(i, cut[c - 1]), n);
+    }
+    std::vector<int> status(n_ctx, CLX_OK);
+    auto work = [&](size_t c) {
+        const size_t lo = cut[c], hi = cut[c + 1];
+        if (hi <= lo) return;
+        // this share's slice of the arena (16-byte aligned start) and of the output
+        uint64_t a0 = UINT64_MAX, a1 = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const uint64_t off = std::min<uint64_t>(frames[i].byte_off, arena_len);
+            a0 = std::min(a0, off);
+            a1 = std::max(a1, std::min<uint64_t>(off + frames[i].max_bytes, arena_len));
+        }
+        a0 &= ~15ull;
+        std::vector<clx_frame_desc> d(frames + lo, frames + hi);
+        std::vector<uint64_t> offs(hi - lo);
+        const uint64_t o0 = out_sample_offsets[lo];
+        for (size_t i = lo; i < hi; ++i) {
+            d[i - lo].byte_off = frames[i].byte_off >= a0 ? frames[i].byte_off - a0 : 0;     // (a frame past the arena keeps failing the same way)
+            if (frames[i].byte_off >= arena_len) d[i - lo].byte_off = a1 - a0;
+            offs[i - lo] = out_sample_offsets[i] - o0;
+        }
+        status[c] = clx_decode_frames(ctxs[c], arena + a0, (size_t)(a1 - a0), d.data(), hi - lo, out + o0, offs.data(), results + lo, flags);
+    };
+    std::vector<std::thread> th;
+    for (size_t c = 1; c < n_ctx; ++c) th.emplace_back(work, c);
+    work(0);
+    for (auto& t : th) t.join();
+    for (size_t c = 0; c < n_ctx; ++c) if (status[c] != CLX_OK) { if (c) ctxs[0]->last_error = ctxs[c]->last_error; return status[c]; }
+    return CLX_OK;
 }
 
 extern "C" int clx_interleave(clx_ctx* ctx, const int32_t* planar, const clx_frame_desc* frames, size_t n,

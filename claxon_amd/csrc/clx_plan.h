@@ -40,6 +40,32 @@ static inline long clx_plan_frames(const clx_frame_desc* frames, size_t n, const
     return -1;
 }
 
+// Which kernels decode a batch when the caller does not say (measured on MI355X: tools/bench_configs.py).
+// The wave-per-frame kernels scale with the work in the batch; the lane-per-subframe kernels last as long as one lane's serial
+// chain however few subframes there are, and win once the batch fills the machine -- earlier the more work a subframe carries:
+//   24-bit audio (order-32 predictors, Rice2: the wave path's slow cases)            lanes from ~3 000 subframes
+//   16-bit, ~9.5 compressed bits per sample (mixed real-world shapes, config 5)      lanes from ~20 000 subframes
+//   16-bit, ~5 bits per sample (configs 2 and 3)                                     lanes from ~52 000 subframes (28 000 when mono:
+//                                                                                    no scan pass for the later channels)
+// and between the two lane builds the two-wave one while its workgroups still get a CU each (longer for 24-bit audio).
+// `bytes` = sum of the frames' max_bytes when those are real frame lengths (0 = unknown, e.g. "to the end of the stream").
+struct clx_path_choice { bool lanes, lanes_split; };
+static inline clx_path_choice clx_select_path(uint64_t slots, uint64_t samples, uint64_t bytes, bool heavy, bool all_mono) {
+    clx_path_choice c;
+    double rate = (samples && bytes) ? 8.0 * (double)bytes / (double)samples : 7.5;      // compressed bits per sample
+    if (rate > 32.0) rate = 7.5;                                                          // not frame lengths: unknown
+    double threshold;
+    if (heavy) threshold = 3000.0;                 // (a quarter or more of the samples are wider than 16 bits)
+    else {
+        const double lo = all_mono ? 28000.0 : 52000.0, hi = all_mono ? 14000.0 : 20000.0;  // at <= 6.5 / >= 8.5 bits per sample
+        const double t = rate <= 6.5 ? 0.0 : rate >= 8.5 ? 1.0 : (rate - 6.5) / 2.0;
+        threshold = lo + (hi - lo) * t;
+    }
+    c.lanes = (double)slots >= threshold;
+    c.lanes_split = slots <= 40000 || (heavy && slots <= 80000);
+    return c;
+}
+
 // limit_bits = 8 * min(max_bytes, arena_len - byte_off), capped at 2^31 bits (no frame needs more).
 static inline void clx_plan_limits(const clx_frame_desc* frames, size_t n, size_t arena_len, clx_dev_frame* dev) {
     for (size_t i = 0; i < n; ++i) {

@@ -207,6 +207,15 @@ int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t arena_len,
                       int32_t* out, const uint64_t* out_sample_offsets,
                       clx_frame_result* results, uint32_t flags);
 
+/* The same with several contexts -- one per GPU (or several on one GPU): the batch is cut into contiguous frame ranges of
+ * near-equal algorithmic weight, context c decodes range c on a host thread of its own and receives only that range's slice
+ * of the arena; nothing is exchanged between the devices (frames are independent: frame.rs:667-779 touches only its own bytes
+ * and buffer; the reference's counterpart is one FrameReader per thread).  Host buffers only; frames in increasing,
+ * non-overlapping output order (else the whole batch goes to ctxs[0]). */
+int clx_decode_frames_multi(clx_ctx* const* ctxs, size_t n_ctx, const uint8_t* arena, size_t arena_len,
+                            const clx_frame_desc* frames, size_t n, int32_t* out, const uint64_t* out_sample_offsets,
+                            clx_frame_result* results, uint32_t flags);
+
 /* One-shot interleave / narrow stage (see clx_batch_interleave).  `planar` follows CLX_OUT_ON_DEVICE, `pcm`
  * CLX_PCM_ON_DEVICE; `results` (may be NULL) marks frames to skip (status != CLX_OK). */
 int clx_interleave(clx_ctx* ctx, const int32_t* planar, const clx_frame_desc* frames, size_t n,

@@ -3,8 +3,9 @@ agree with the oracle -- status, message, end_bit and every sample (not only the
 
   * above 512 groups of predictor slots the wave path switches to the one-wave K2 builds (clx_k_predict_1w, and
     clx_k_predict_1w_hi for groups with a predictor order above 12)          -- subframe.rs:524-614
-  * from 48 000 subframes the default path is the lane kernels, fused build above 32 768 subframes -- frame.rs:705-742
-  * BASELINE configs 2 / 4 / 5 at >= 8 000 frames with flags 0 (whatever the library selects)
+  * from 52 000 subframes of this shape (content dependent: clx_select_path, clx_plan.h) the default path is the lane
+    kernels, fused build above 40 000 subframes                                  -- frame.rs:705-742
+  * BASELINE configs 2 / 4 / 5 at >= 8 000 frames with flags 0: the selection the measurements ask for (tools/bench_configs.py)
 
 Every case asserts WHICH kernels ran (names recorded by the library around its launches), so a silent change of the
 selection thresholds cannot turn these tests into repeats of the small ones."""
@@ -29,7 +30,7 @@ def ctx():
 
 @pytest.fixture(scope="module")
 def big3():
-    return synth.config3(24576)
+    return synth.config3(28672)
 
 
 def run_and_compare(oracle, ctx, w, flags, expect, forbid=()):
@@ -72,7 +73,7 @@ def test_auto_wave_path_one_wave_predictor(oracle, ctx, big3):
 
 
 def test_auto_lane_path_fused(oracle, ctx, big3):
-    """24 576 stereo frames = 49 152 subframes: the default is the lane path, fused build."""
+    """28 672 stereo frames = 57 344 subframes of ~5 bits per sample: the default is the lane path, fused build."""
     run_and_compare(oracle, ctx, big3, 0, ["clx_k_scan", "clx_k_lanes", "clx_k_finalize", "clx_k_crc16"],
                     forbid=["clx_k_residual", "clx_k_lanes2"])
 
@@ -86,10 +87,14 @@ def test_forced_builds_at_scale(oracle, ctx, big3):
     run_and_compare(oracle, ctx, w, cx.PATH_LANES | cx.LANES_FUSED, ["clx_k_lanes"])
 
 
-@pytest.mark.parametrize("make", [lambda: synth.config2(8192), lambda: synth.config4(8192), lambda: synth.config5_unique(8192)],
-                         ids=["config2", "config4", "config5"])
-def test_baseline_configs_default_selection(oracle, ctx, make):
-    run_and_compare(oracle, ctx, make(), 0, [])
+@pytest.mark.parametrize("make,expect,forbid", [
+    (lambda: synth.config2(8192), ["clx_k_residual", "clx_k_predict"], ["clx_k_lanes", "clx_k_lanes2"]),     # 8 192 mono subframes, 5.7 bits/sample
+    (lambda: synth.config4(8192), ["clx_k_lanes2"], ["clx_k_residual"]),                                      # 24-bit: lane kernels, two-wave build
+    (lambda: synth.config5_unique(8192), ["clx_k_residual", "clx_k_predict"], ["clx_k_lanes", "clx_k_lanes2"]),  # 16 384 subframes at 9.5 bits/sample
+    (lambda: synth.config5_unique(12288), ["clx_k_lanes2"], ["clx_k_residual"]),                              # 24 576 of them: lane kernels
+], ids=["config2", "config4", "config5", "config5-more"])
+def test_baseline_configs_default_selection(oracle, ctx, make, expect, forbid):
+    run_and_compare(oracle, ctx, make(), 0, expect, forbid=forbid)
 
 
 def test_device_indexer_against_oracle_offsets(oracle, ctx):

@@ -19,6 +19,7 @@ for crc in (False, True):
     for mode in ("run", "submit"):
         f = b.run if mode == "run" else b.submit
         for o in outs: o.zero_()
+        torch.cuda.synchronize()          # (the library's stream does not wait for torch's)
         for i in range(4): f(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
         b.flush(stream); torch.cuda.synchronize()
         t = time.perf_counter()
