@@ -83,7 +83,7 @@ assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
 
 EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
-    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_frames_multi", "clx_decode_subframes", "clx_interleave",
+    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_frames_multi", "clx_decode_frames_stream", "clx_host_alloc", "clx_host_free", "clx_decode_subframes", "clx_interleave",
     "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
     "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
@@ -148,6 +148,10 @@ def lib():
     L.clx_decode_subframes.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, C.c_uint32]
     L.clx_batch_create.argtypes = [vp, vp, sz, vp, C.c_uint32, C.POINTER(vp)]
     L.clx_decode_frames_multi.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, C.c_uint32]
+    L.clx_decode_frames_stream.argtypes = [vp, vp, sz, vp, sz, vp, C.c_uint32, vp, vp, C.c_uint32]
+    L.clx_host_alloc.restype = vp
+    L.clx_host_alloc.argtypes = [sz]
+    L.clx_host_free.argtypes = [vp]
     L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_submit.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_flush.argtypes = [vp, vp]
@@ -370,6 +374,32 @@ def descs_for_subframes(offs, block_sizes, bps):
 
 # ----------------------------------------------------------------------------- device objects
 
+class PinnedArray:
+    """A numpy view of pinned host memory from clx_host_alloc (freed with the object): buffers handed to
+    Context.decode_frames_stream in this kind of memory are copied asynchronously at link speed."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        self._p = lib().clx_host_alloc(max(n, 1))
+        if not self._p:
+            raise MemoryError("clx_host_alloc(%d) failed" % n)
+        buf = (C.c_uint8 * max(n, 1)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().clx_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def decode_frames_multi(ctxs, arena, descs, out_offs, out=None, verify_crc=False, path=0):
     """clx_decode_frames_multi: one batch, several contexts (one per GPU, or several on one), no exchange between them."""
     a = _u8(arena)
@@ -472,6 +502,25 @@ class Context:
                                      _np_ptr(res), (VERIFY_CRC16 if verify_crc else 0) | path)
         self._check(st)
         return out, res
+
+    def decode_frames_stream(self, arena, descs, out_offs, out=None, sample_bytes=0, verify_crc=False, path=0, copy_back=True):
+        """clx_decode_frames_stream: host-to-host decode, chunks pipelined (upload | decode | download).  sample_bytes 0: planar
+        int32 (returned as int32 array); 1..4: channel-interleaved little-endian PCM (returned as uint8 array);
+        copy_back=False: only the results come back.  Returns (out or None, results)."""
+        a = _u8(arena)
+        descs = np.ascontiguousarray(descs, dtype=FRAME_DESC_DTYPE)
+        out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+        n = descs.size
+        total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+        if copy_back and out is None:
+            out = np.zeros(total, dtype=np.int32) if sample_bytes == 0 else np.zeros(total * sample_bytes, dtype=np.uint8)
+        if copy_back:
+            assert out.nbytes >= total * (sample_bytes or 4)
+        res = np.zeros(n, dtype=FRAME_RESULT_DTYPE)
+        st = lib().clx_decode_frames_stream(self._h, _np_ptr(a), a.size, _np_ptr(descs), n, _np_ptr(out) if copy_back else None, sample_bytes,
+                                            _np_ptr(out_offs), _np_ptr(res), (VERIFY_CRC16 if verify_crc else 0) | path)
+        self._check(st)
+        return (out if copy_back else None), res
 
     def interleave(self, planar, descs, out_offs, sample_bytes, results=None, pcm=None):
         """One-shot interleave / narrow stage on host arrays: planar i32 -> channel-interleaved little-endian PCM of

@@ -214,10 +214,22 @@ extern "C" int clx_parse_frame_header(const uint8_t* p, size_t avail, int check_
 // ------------------------------------------------------------------------------------------------
 // context / batch
 // ------------------------------------------------------------------------------------------------
+// one of the three chunks in flight of clx_decode_frames_stream: a stream, a re-plannable batch and the chunk's device buffers
+struct clx_stream_slot {
+    clx_batch* b = nullptr;
+    hipStream_t st = nullptr;
+    uint8_t* d_arena = nullptr; size_t arena_cap = 0;
+    int32_t* d_out = nullptr;   size_t out_cap = 0;
+    uint8_t* d_pcm = nullptr;   size_t pcm_cap = 0;
+    clx_frame_result* h_res = nullptr; size_t res_cap = 0;      // pinned: results come back without stalling the stream
+    size_t lo = 0, hi = 0;                                      // frames of the chunk whose results are pending (hi > lo)
+};
+
 struct clx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     std::string last_error;
+    clx_stream_slot slots[3];
 };
 
 // K2 build by batch size (groups of 64 predictor slots) unless CLX_K2_LATENCY / CLX_K2_THROUGHPUT force one
@@ -227,6 +239,8 @@ struct clx_batch {
     clx_ctx* ctx = nullptr;
     int device = 0;
     clx_path_choice choice = { false, true };
+    clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
+    size_t cap[9] = {};              // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits
     size_t n = 0;
     uint64_t n_slots = 0;
     uint32_t flags = 0;
@@ -273,6 +287,8 @@ bool hip_ok(clx_ctx* ctx, hipError_t e, const char* what) {
 #define HIP_TRY(ctx, call) do { if (!hip_ok((ctx), (call), #call)) return CLX_API_ERROR; } while (0)
 }  // namespace
 
+extern "C" void clx_batch_destroy(clx_batch* b);
+
 extern "C" int clx_create(int device, clx_ctx** out) {
     if (!out) return CLX_API_ERROR;
     *out = nullptr;
@@ -294,6 +310,15 @@ extern "C" int clx_create(int device, clx_ctx** out) {
 extern "C" void clx_destroy(clx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (auto& sl : ctx->slots) {
+        if (sl.st) (void)hipStreamSynchronize(sl.st);
+        if (sl.b) clx_batch_destroy(sl.b);
+        if (sl.d_arena) (void)hipFree(sl.d_arena);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.d_pcm) (void)hipFree(sl.d_pcm);
+        if (sl.h_res) (void)hipHostFree(sl.h_res);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -319,35 +344,36 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
     if (b->d_sfd_alt) (void)hipFree(b->d_sfd_alt);
     if (b->d_results_alt) (void)hipFree(b->d_results_alt);
+    if (b->h_up) (void)hipHostFree(b->h_up);
     delete b;
 }
 
-extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
-                                const uint64_t* out_sample_offsets, uint32_t flags, clx_batch** out) {
-    if (!ctx || !out || (n && (!frames || !out_sample_offsets))) return CLX_API_ERROR;
-    *out = nullptr;
-    if (n > 0xfffffff0ull) { ctx->last_error = "too many frames in one batch"; return CLX_API_ERROR; }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    clx_batch* b = new (std::nothrow) clx_batch();
-    if (!b) return CLX_API_ERROR;
-    b->ctx = ctx; b->device = ctx->device; b->n = n; b->flags = flags;
+namespace {
+// device buffer of at least `need` bytes: kept when large enough, else replaced (contents are never carried over)
+template <typename T> bool grow(clx_ctx* ctx, T** p, size_t* cap, size_t need, const char* what) {
+    if (*p && *cap >= need) return true;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = need + need / 4;                                   // head room: a stream of similar chunks settles at once
+    if (!hip_ok(ctx, hipMalloc((void**)p, want ? want : 16), what)) return false;
+    *cap = want;
+    return true;
+}
+// (Re)plan `b` for a list of frames: host-side planning, kernel selection, device buffers (reused when they are large enough).
+int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
+    clx_ctx* ctx = b->ctx;
+    b->n = n; b->flags = flags;
     b->h_descs.assign(frames, frames + n);
     b->h_frames.resize(n ? n : 1);
     uint64_t slot = 0;
     const long bad = clx_plan_frames(frames, n, out_sample_offsets, b->h_frames.data(), &slot);
-    if (bad >= 0) {
-        ctx->last_error = "invalid clx_frame_desc at index " + std::to_string(bad);
-        clx_batch_destroy(b); return CLX_API_ERROR;
-    }
-    if (slot > 0xfffffff0ull) { ctx->last_error = "too many subframes in one batch"; clx_batch_destroy(b); return CLX_API_ERROR; }
+    if (bad >= 0) { ctx->last_error = "invalid clx_frame_desc at index " + std::to_string(bad); return CLX_API_ERROR; }
+    if (slot > 0xfffffff0ull) { ctx->last_error = "too many subframes in one batch"; return CLX_API_ERROR; }
     b->n_slots = slot;
     const size_t nf = n ? n : 1, ns = slot ? (size_t)slot : 1;
-    if (!hip_ok(ctx, hipMalloc((void**)&b->d_frames, nf * sizeof(clx_dev_frame)), "hipMalloc frames") ||
-        !hip_ok(ctx, hipMalloc((void**)&b->d_sfd, ns * sizeof(clx_sf_desc)), "hipMalloc sfdesc") ||
-        !hip_ok(ctx, hipMalloc((void**)&b->d_results, nf * sizeof(clx_frame_result)), "hipMalloc results")) {
-        clx_batch_destroy(b); return CLX_API_ERROR;
-    }
-    for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) { clx_batch_destroy(b); return CLX_API_ERROR; }
+    if (!grow(ctx, &b->d_frames, &b->cap[0], nf * sizeof(clx_dev_frame), "hipMalloc frames") ||
+        !grow(ctx, &b->d_sfd, &b->cap[1], ns * sizeof(clx_sf_desc), "hipMalloc sfdesc") ||
+        !grow(ctx, &b->d_results, &b->cap[2], nf * sizeof(clx_frame_result), "hipMalloc results")) return CLX_API_ERROR;
+    if (!b->ev[0]) for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) return CLX_API_ERROR;
     // path: explicit flag, else by the batch's shape and content (clx_select_path, clx_plan.h)
     {
         uint64_t samples = 0, wide = 0, bytes = 0; bool all_mono = true, lengths_known = true;
@@ -363,22 +389,39 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : b->choice.lanes;
     {   // where stores that fall outside a row go (K2 and D2 keep their store instructions unconditional)
         const size_t lanes64 = ((ns + 127) / 128) * 128;
-        if (!hip_ok(ctx, hipMalloc((void**)&b->d_dump, lanes64 * 16 * sizeof(int32_t)), "hipMalloc dump")) { clx_batch_destroy(b); return CLX_API_ERROR; }
+        if (!grow(ctx, &b->d_dump, &b->cap[3], lanes64 * 16 * sizeof(int32_t), "hipMalloc dump")) return CLX_API_ERROR;
     }
     if (b->lanes) {
         std::vector<uint32_t> slot_frame(ns), multi(nf);
         b->n_multi = clx_plan_lanes(b->h_frames.data(), n, slot, slot_frame.data(), multi.data());
-        if (!hip_ok(ctx, hipMalloc((void**)&b->d_slot_frame, ns * sizeof(uint32_t)), "hipMalloc slot_frame") ||
-            !hip_ok(ctx, hipMalloc((void**)&b->d_multi, nf * sizeof(uint32_t)), "hipMalloc multi") ||
-            !hip_ok(ctx, hipMalloc((void**)&b->d_sf_start, ns * sizeof(uint32_t)), "hipMalloc sf_start") ||
-            !hip_ok(ctx, hipMalloc((void**)&b->d_errkey, nf * sizeof(uint32_t)), "hipMalloc errkey") ||
-            !hip_ok(ctx, hipMalloc((void**)&b->d_endbits, nf * sizeof(uint64_t)), "hipMalloc endbits") ||
+        if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
+            !grow(ctx, &b->d_multi, &b->cap[5], nf * sizeof(uint32_t), "hipMalloc multi") ||
+            !grow(ctx, &b->d_sf_start, &b->cap[6], ns * sizeof(uint32_t), "hipMalloc sf_start") ||
+            !grow(ctx, &b->d_errkey, &b->cap[7], nf * sizeof(uint32_t), "hipMalloc errkey") ||
+            !grow(ctx, &b->d_endbits, &b->cap[8], nf * sizeof(uint64_t), "hipMalloc endbits") ||
             !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
-            !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) {
-            clx_batch_destroy(b); return CLX_API_ERROR;
-        }
+            !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) return CLX_API_ERROR;
     }
+    // (a re-planned batch starts over: nothing of the previous plan may be in flight -- the caller's contract)
+    if (b->d_sfd_alt) { (void)hipFree(b->d_sfd_alt); b->d_sfd_alt = nullptr; }
+    if (b->d_results_alt) { (void)hipFree(b->d_results_alt); b->d_results_alt = nullptr; }
+    b->stage2_pending[0] = b->stage2_pending[1] = false; b->last_slot = -1;
     b->planned_arena_len = (size_t)-1;
+    b->ev_valid = false;
+    return CLX_OK;
+}
+}  // namespace
+
+extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
+                                const uint64_t* out_sample_offsets, uint32_t flags, clx_batch** out) {
+    if (!ctx || !out || (n && (!frames || !out_sample_offsets))) return CLX_API_ERROR;
+    *out = nullptr;
+    if (n > 0xfffffff0ull) { ctx->last_error = "too many frames in one batch"; return CLX_API_ERROR; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    clx_batch* b = new (std::nothrow) clx_batch();
+    if (!b) return CLX_API_ERROR;
+    b->ctx = ctx; b->device = ctx->device;
+    if (batch_plan(b, frames, n, out_sample_offsets, flags) != CLX_OK) { clx_batch_destroy(b); return CLX_API_ERROR; }
     *out = b;
     return CLX_OK;
 }
@@ -399,10 +442,18 @@ unsigned crc_grid(size_t n) { return (unsigned)std::min<size_t>((n + 3) / 4, 204
 int upload_plan(clx_batch* b, size_t arena_len, hipStream_t stream) {
     clx_ctx* ctx = b->ctx;
     if (b->planned_arena_len == arena_len) return CLX_OK;
-    std::vector<clx_dev_frame> up(b->h_frames);
-    clx_plan_limits(b->h_descs.data(), b->n, arena_len, up.data());
-    HIP_TRY(ctx, hipMemcpyAsync(b->d_frames, up.data(), b->n * sizeof(clx_dev_frame), hipMemcpyHostToDevice, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));                    // `up` goes out of scope
+    // staged in pinned memory that lives with the batch: the copy is asynchronous and nothing has to be waited for here (the
+    // next re-plan of this batch comes after the caller has waited for its stream: clx_batch_run's contract)
+    if (b->up_cap < b->n) {
+        if (b->h_up) (void)hipHostFree(b->h_up);
+        b->h_up = nullptr; b->up_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc((void**)&b->h_up, (b->n + b->n / 4 + 1) * sizeof(clx_dev_frame), hipHostMallocDefault));
+        b->up_cap = b->n + b->n / 4 + 1;
+    }
+    if (b->planned_arena_len != (size_t)-1) HIP_TRY(ctx, hipStreamSynchronize(stream));      // (a copy of the staging may be in flight)
+    std::memcpy(b->h_up, b->h_frames.data(), b->n * sizeof(clx_dev_frame));
+    clx_plan_limits(b->h_descs.data(), b->n, arena_len, b->h_up);
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_frames, b->h_up, b->n * sizeof(clx_dev_frame), hipMemcpyHostToDevice, stream));
     b->planned_arena_len = arena_len;
     return CLX_OK;
 }
@@ -532,14 +583,16 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         int lo = 0, hi = 0;
         HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));                   // (hi is the numerically lowest = highest priority)
         HIP_TRY(ctx, hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, hi));
-        const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_sfd_alt, ns * sizeof(clx_sf_desc)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_results_alt, nf * sizeof(clx_frame_result)));
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_stage1[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_stage2[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_gate[i], hipEventDisableTiming));
         }
+    }
+    if (!b->d_sfd_alt) {
+        const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_sfd_alt, ns * sizeof(clx_sf_desc)));
+        HIP_TRY(ctx, hipMalloc((void**)&b->d_results_alt, nf * sizeof(clx_frame_result)));
     }
     if (upload_plan(b, arena_len, stream) != CLX_OK) return CLX_API_ERROR;
     const uint64_t alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;
@@ -656,6 +709,9 @@ extern "C" int clx_decode_frames(clx_ctx* ctx, const uint8_t* arena, size_t aren
             !hip_ok(ctx, hipMemsetAsync(d_out, 0, std::max<uint64_t>(out_len, 1) * sizeof(int32_t), ctx->stream), "memset out")) { cleanup(); return CLX_API_ERROR; }
     }
     st = clx_batch_run(b, d_arena, arena_len, d_out, ctx->stream);
+    if (st == CLX_OK && !(flags & CLX_OUT_ON_DEVICE))
+        hipLaunchKernelGGL(clx_k_clear_failed, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_out, (const clx_dev_frame*)b->d_frames,
+                           (const clx_frame_result*)b->d_results, (uint32_t)n);
     if (st == CLX_OK) st = clx_batch_results(b, results);
     if (st == CLX_OK && !(flags & CLX_OUT_ON_DEVICE)) {
         // only blocks of successfully decoded frames are observable (frame.rs:667: Err drops the buffer)
@@ -721,6 +777,104 @@ extern "C" int clx_decode_frames_multi(clx_ctx* const* ctxs, size_t n_ctx, const
     for (auto& t : th) t.join();
     for (size_t c = 0; c < n_ctx; ++c) if (status[c] != CLX_OK) { if (c) ctxs[0]->last_error = ctxs[c]->last_error; return status[c]; }
     return CLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-to-host decode as a pipeline: the batch is cut into chunks of frames; chunk c's compressed bytes go to the device
+// while chunk c-1 is decoded and chunk c-2's PCM comes back -- three slots, a stream each, device buffers and plans kept in the
+// context and reused from call to call.  Output either planar i32 (Block layout) or, with sample_bytes != 0, the narrow stage's
+// channel-interleaved little-endian PCM (what callers of the reference write out: lib.rs:473-520, examples/decode.rs:48-62),
+// which halves the bytes that cross the link for 16-bit audio.  Pinned host buffers (clx_host_alloc) let the copies run
+// asynchronously at link speed; pageable ones work, staged by the runtime.
+// ------------------------------------------------------------------------------------------------
+extern "C" void* clx_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+extern "C" void clx_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int clx_decode_frames_stream(clx_ctx* ctx, const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
+                                        void* out, uint32_t sample_bytes, const uint64_t* out_sample_offsets,
+                                        clx_frame_result* results, uint32_t flags) {
+    if (!ctx) return CLX_API_ERROR;
+    if (n == 0) return CLX_OK;
+    if (!arena || !frames || !out_sample_offsets || !results || sample_bytes > 4u) { ctx->last_error = "clx_decode_frames_stream: bad argument"; return CLX_API_ERROR; }
+    if (flags & (CLX_ARENA_ON_DEVICE | CLX_OUT_ON_DEVICE)) { ctx->last_error = "clx_decode_frames_stream takes host buffers"; return CLX_API_ERROR; }
+    for (size_t i = 1; i < n; ++i)
+        if (out_sample_offsets[i] < out_sample_offsets[i - 1] + (uint64_t)frames[i - 1].n_channels * frames[i - 1].block_size) {
+            ctx->last_error = "clx_decode_frames_stream: frames must be in increasing, non-overlapping output order"; return CLX_API_ERROR;
+        }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t per = std::min<size_t>(std::max<size_t>((n + 3) / 4, 256), 4096);      // frames per chunk
+    auto harvest = [&](clx_stream_slot& S) -> bool {                                       // results of the slot's finished chunk
+        if (S.hi <= S.lo) return true;
+        if (!hip_ok(ctx, hipStreamSynchronize(S.st), "sync")) return false;
+        std::memcpy(results + S.lo, S.h_res, (S.hi - S.lo) * sizeof(clx_frame_result));
+        S.lo = S.hi = 0;
+        return true;
+    };
+    int st = CLX_OK;
+    size_t c = 0;
+    for (size_t lo = 0; lo < n && st == CLX_OK; lo += per, ++c) {
+        const size_t hi = std::min(n, lo + per), nc = hi - lo;
+        clx_stream_slot& S = ctx->slots[c % 3];
+        if (!S.st && !hip_ok(ctx, hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking), "hipStreamCreate")) { st = CLX_API_ERROR; break; }
+        if (!harvest(S)) { st = CLX_API_ERROR; break; }                                  // (also: the slot's buffers are free again)
+        if (!S.b) {
+            S.b = new (std::nothrow) clx_batch();
+            if (!S.b) { st = CLX_API_ERROR; break; }
+            S.b->ctx = ctx; S.b->device = ctx->device;
+        }
+        // the chunk's slice of the arena (16-byte aligned start) and of the output
+        uint64_t a0 = UINT64_MAX, a1 = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const uint64_t off = std::min<uint64_t>(frames[i].byte_off, arena_len);
+            a0 = std::min(a0, off);
+            a1 = std::max(a1, std::min<uint64_t>(off + frames[i].max_bytes, arena_len));
+        }
+        a0 &= ~15ull;
+        const size_t span = (size_t)(a1 - a0);
+        std::vector<clx_frame_desc> d(frames + lo, frames + hi);
+        std::vector<uint64_t> offs(nc);
+        const uint64_t o0 = out_sample_offsets[lo];
+        const uint64_t o1 = out_sample_offsets[hi - 1] + (uint64_t)frames[hi - 1].n_channels * frames[hi - 1].block_size;
+        for (size_t i = lo; i < hi; ++i) {
+            d[i - lo].byte_off = frames[i].byte_off >= arena_len ? a1 - a0 : frames[i].byte_off - a0;
+            offs[i - lo] = out_sample_offsets[i] - o0;
+        }
+        if (batch_plan(S.b, d.data(), nc, offs.data(), flags) != CLX_OK) { st = CLX_API_ERROR; break; }
+        const size_t arena_alloc = ((span + 15) & ~(size_t)15) + 32, out_n = (size_t)(o1 - o0);
+        if (!grow(ctx, &S.d_arena, &S.arena_cap, arena_alloc, "hipMalloc arena") ||
+            !grow(ctx, &S.d_out, &S.out_cap, std::max<size_t>(out_n, 1) * sizeof(int32_t), "hipMalloc out") ||
+            (sample_bytes && !grow(ctx, &S.d_pcm, &S.pcm_cap, std::max<size_t>(out_n, 1) * sample_bytes, "hipMalloc pcm"))) { st = CLX_API_ERROR; break; }
+        if (S.res_cap < nc) {
+            if (S.h_res) (void)hipHostFree(S.h_res);
+            S.h_res = nullptr; S.res_cap = 0;
+            if (!hip_ok(ctx, hipHostMalloc((void**)&S.h_res, (nc + nc / 4) * sizeof(clx_frame_result), hipHostMallocDefault), "hipHostMalloc results")) { st = CLX_API_ERROR; break; }
+            S.res_cap = nc + nc / 4;
+        }
+        const bool ok =
+            hip_ok(ctx, hipMemsetAsync(S.d_arena + (arena_alloc - 48), 0, 48, S.st), "memset") &&
+            hip_ok(ctx, hipMemcpyAsync(S.d_arena, arena + a0, span, hipMemcpyHostToDevice, S.st), "H2D arena") &&
+            // what no frame covers, and what a failed frame leaves, comes back as zeros
+            hip_ok(ctx, hipMemsetAsync(sample_bytes ? (void*)S.d_pcm : (void*)S.d_out, 0, out_n * (sample_bytes ? sample_bytes : 4u), S.st), "memset out");
+        if (!ok) { st = CLX_API_ERROR; break; }
+        st = clx_batch_run(S.b, S.d_arena, span, S.d_out, S.st);
+        if (st != CLX_OK) break;
+        if (sample_bytes) {
+            st = clx_batch_interleave(S.b, S.d_out, S.d_pcm, sample_bytes, S.st);
+            if (st != CLX_OK) break;
+            if (out && !hip_ok(ctx, hipMemcpyAsync((uint8_t*)out + o0 * sample_bytes, S.d_pcm, out_n * sample_bytes, hipMemcpyDeviceToHost, S.st), "D2H pcm")) { st = CLX_API_ERROR; break; }
+        } else if (out) {
+            hipLaunchKernelGGL(clx_k_clear_failed, dim3((unsigned)nc), dim3(256), 0, S.st, S.d_out, (const clx_dev_frame*)S.b->d_frames,
+                               (const clx_frame_result*)S.b->d_results, (uint32_t)nc);
+            if (!hip_ok(ctx, hipMemcpyAsync((int32_t*)out + o0, S.d_out, out_n * sizeof(int32_t), hipMemcpyDeviceToHost, S.st), "D2H out")) { st = CLX_API_ERROR; break; }
+        }
+        if (!hip_ok(ctx, hipMemcpyAsync(S.h_res, S.b->d_results, nc * sizeof(clx_frame_result), hipMemcpyDeviceToHost, S.st), "D2H results")) { st = CLX_API_ERROR; break; }
+        S.lo = lo; S.hi = hi;
+    }
+    for (auto& S : ctx->slots) if (S.st && !harvest(S)) st = CLX_API_ERROR;     // (also after an error: nothing stays in flight)
+    return st;
 }
 
 extern "C" int clx_interleave(clx_ctx* ctx, const int32_t* planar, const clx_frame_desc* frames, size_t n,

@@ -1517,6 +1517,18 @@ void clx_k_interleave(const int32_t* __restrict__ planar, const clx_dev_frame* _
     }
 }
 
+// K4b: what a failed frame left in the planar output is cleared -- the reference drops the buffer of a frame that fails
+// (frame.rs:667: Err consumes it), so nothing of it may be observable in a buffer handed back to the host.
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_clear_failed(int32_t* __restrict__ planar, const clx_dev_frame* __restrict__ frames,
+                        const clx_frame_result* __restrict__ results, uint32_t n_frames) {
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames || results[f].status == CLX_OK) return;
+    const clx_dev_frame fr = frames[f];
+    const uint32_t total = (uint32_t)fr.n_channels * fr.block_size;
+    for (uint32_t i = threadIdx.x; i < total; i += 256u) planar[fr.out_off + i] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5 / K6: frame indexer for raw streams (header grammar frame.rs:131-316; the reference has no resync,
 // frame.rs:601-602).  The byte work is data-parallel and lives here; the (tiny) chain logic lives in the host

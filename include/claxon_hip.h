@@ -216,6 +216,22 @@ int clx_decode_frames_multi(clx_ctx* const* ctxs, size_t n_ctx, const uint8_t* a
                             const clx_frame_desc* frames, size_t n, int32_t* out, const uint64_t* out_sample_offsets,
                             clx_frame_result* results, uint32_t flags);
 
+/* Host-to-host decode as a pipeline (what a caller without device-resident data uses): the batch is cut into chunks of
+ * frames; one chunk's compressed bytes travel to the device while the previous chunk is decoded and the one before that
+ * returns its PCM.  Device buffers and plans live in the context and are reused from call to call.
+ *   sample_bytes == 0: `out` is planar int32_t, as clx_decode_frames
+ *   sample_bytes 1..4: `out` receives the narrow stage's channel-interleaved little-endian PCM (clx_batch_interleave), frame i
+ *                      at byte out_sample_offsets[i] * sample_bytes -- what callers of the reference write out
+ *                      (examples/decode.rs:48-62), half the bytes over the link for 16-bit audio
+ *   out == NULL      : nothing is copied back but the results (decode throughput with the upload included)
+ * Samples of failed frames read as zeros.  Frames in increasing, non-overlapping output order.  Buffers from clx_host_alloc
+ * (pinned) make the copies asynchronous at link speed; any host memory works. */
+int   clx_decode_frames_stream(clx_ctx* ctx, const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
+                               void* out, uint32_t sample_bytes, const uint64_t* out_sample_offsets,
+                               clx_frame_result* results, uint32_t flags);
+void* clx_host_alloc(size_t bytes);      /* pinned host memory (hipHostMalloc); NULL on failure */
+void  clx_host_free(void* p);
+
 /* One-shot interleave / narrow stage (see clx_batch_interleave).  `planar` follows CLX_OUT_ON_DEVICE, `pcm`
  * CLX_PCM_ON_DEVICE; `results` (may be NULL) marks frames to skip (status != CLX_OK). */
 int clx_interleave(clx_ctx* ctx, const int32_t* planar, const clx_frame_desc* frames, size_t n,
