@@ -688,6 +688,7 @@ class FlacReader:
             self._h = None
             raise ClaxonError(st, int(m.value))
         self._si = StreamInfo()
+        self._buf = None
         lib().clx_reader_streaminfo(self._h, C.byref(self._si))
 
     @classmethod
@@ -714,11 +715,18 @@ class FlacReader:
 
     def read_next_or_eof(self):
         """Returns a Block, or None at the end of the stream; raises ClaxonError like the reference returns Err."""
-        cap = 8 * 65535
-        buf = np.empty(cap, dtype=np.int32)
+        # one staging buffer per reader, sized from STREAMINFO (max block size x channels); a block that is larger than announced
+        # stays pending in the library and is fetched again into a buffer of the size it reports
+        if self._buf is None:
+            si = self._si
+            self._buf = np.empty(max(1, int(si.max_block_size or 65535) * int(si.channels or 8)), dtype=np.int32)
+        buf = self._buf
         info = BlockInfo()
         m = C.c_uint32(0)
-        st = lib().clx_reader_next_block(self._h, _np_ptr(buf), cap, C.byref(info), C.byref(m))
+        st = lib().clx_reader_next_block(self._h, _np_ptr(buf), buf.size, C.byref(info), C.byref(m))
+        if st == API_ERROR and info.block_size * info.channels > buf.size:
+            self._buf = buf = np.empty(int(info.block_size) * int(info.channels), dtype=np.int32)
+            st = lib().clx_reader_next_block(self._h, _np_ptr(buf), buf.size, C.byref(info), C.byref(m))
         if st == END_OF_STREAM:
             return None
         if st != OK:

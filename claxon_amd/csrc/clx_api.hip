@@ -575,7 +575,9 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     if (lanes < 0) return CLX_API_ERROR;
     const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
     const bool k2_latency = (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
-    // the lane kernels are one fused stage, and the one-wave predictor build is chosen when the machine is full anyway
+    // the lane kernels are one fused stage, and the one-wave predictor build is chosen when the machine is full anyway.  (Whole
+    // submissions of those side by side on streams of their own were measured -- three in flight, tools/bench_configs.py: no
+    // gain for the two-wave lane build, a loss for the one-wave predictor build -- and are not done.)
     if (lanes || !k2_latency || b->profiling) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
@@ -1441,7 +1443,17 @@ struct FrameReader::Impl {
     size_t qhead = 0;
     bool failed = false; int fail_status = 0; uint32_t fail_msg = 0;
     int device = 0;                   // (kept by value: the destructor must not look into a context that may be gone)
-    ~Impl() { if (d_arena) { (void)hipSetDevice(device); (void)hipFree(d_arena); } }
+    // one re-plannable batch, one output buffer on the device and one pinned on the host, reused by every fill of the queue
+    clx_batch* batch = nullptr;
+    int32_t* d_out = nullptr; size_t out_cap = 0;
+    int32_t* h_out = nullptr; size_t h_out_cap = 0;
+    ~Impl() {
+        (void)hipSetDevice(device);
+        if (batch) clx_batch_destroy(batch);
+        if (d_out) (void)hipFree(d_out);
+        if (h_out) (void)hipHostFree(h_out);
+        if (d_arena) (void)hipFree(d_arena);
+    }
 };
 
 FrameReader::FrameReader(clx_ctx* ctx, const uint8_t* data, size_t len) : impl_(new Impl()) {
@@ -1522,16 +1534,28 @@ static int fill_queue(FrameReader::Impl& I) {
     std::vector<uint64_t> offs(usable);
     uint64_t total = 0;
     for (size_t i = 0; i < usable; ++i) { offs[i] = total; total += (uint64_t)descs[i].n_channels * descs[i].block_size; }
-    int32_t* d_out = nullptr;
-    std::vector<int32_t> host_out(total);
+    const int32_t* host_out = I.h_out;
     if (usable) {
-        if (hipSetDevice(I.ctx->device) != hipSuccess) return CLX_API_ERROR;
+        clx_ctx* ctx = I.ctx;
+        if (hipSetDevice(ctx->device) != hipSuccess) return CLX_API_ERROR;
         if (!upload()) return CLX_API_ERROR;
-        if (hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * sizeof(int32_t)) != hipSuccess) return CLX_API_ERROR;
-        int st = clx_decode_frames(I.ctx, I.d_arena, len, descs.data(), usable, d_out, offs.data(), results.data(),
-                                   CLX_ARENA_ON_DEVICE | CLX_OUT_ON_DEVICE | CLX_VERIFY_CRC16);
-        if (st == CLX_OK && hipMemcpy(host_out.data(), d_out, total * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) st = CLX_API_ERROR;
-        (void)hipFree(d_out);
+        if (!I.batch) {
+            I.batch = new (std::nothrow) clx_batch();
+            if (!I.batch) return CLX_API_ERROR;
+            I.batch->ctx = ctx; I.batch->device = ctx->device;
+        }
+        if (batch_plan(I.batch, descs.data(), usable, offs.data(), CLX_VERIFY_CRC16) != CLX_OK) return CLX_API_ERROR;
+        if (!grow(ctx, &I.d_out, &I.out_cap, std::max<uint64_t>(total, 1) * sizeof(int32_t), "hipMalloc out")) return CLX_API_ERROR;
+        if (I.h_out_cap < total) {
+            if (I.h_out) (void)hipHostFree(I.h_out);
+            I.h_out = nullptr; I.h_out_cap = 0;
+            if (!hip_ok(ctx, hipHostMalloc((void**)&I.h_out, (size_t)(total + total / 4 + 1) * sizeof(int32_t), hipHostMallocDefault), "hipHostMalloc out")) return CLX_API_ERROR;
+            I.h_out_cap = (size_t)(total + total / 4 + 1);
+        }
+        host_out = I.h_out;
+        int st = clx_batch_run(I.batch, I.d_arena, len, I.d_out, ctx->stream);
+        if (st == CLX_OK && !hip_ok(ctx, hipMemcpyAsync(I.h_out, I.d_out, total * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), "D2H out")) st = CLX_API_ERROR;
+        if (st == CLX_OK) st = clx_batch_results(I.batch, results.data());        // (waits for the stream: the samples are there too)
         if (st != CLX_OK) return st;
     }
     size_t expect = I.pos;
@@ -1543,7 +1567,7 @@ static int fill_queue(FrameReader::Impl& I) {
         p.status = results[i].status; p.msg = results[i].msg;
         if (p.status == CLX_OK) {
             const size_t cnt = (size_t)descs[i].n_channels * descs[i].block_size;
-            p.samples.assign(host_out.begin() + (ptrdiff_t)offs[i], host_out.begin() + (ptrdiff_t)(offs[i] + cnt));
+            p.samples.assign(host_out + offs[i], host_out + offs[i] + cnt);
             expect = (size_t)descs[i].byte_off + (size_t)((results[i].end_bit + 7) / 8) + 2;
             I.queue.push_back(std::move(p));
         } else { I.queue.push_back(std::move(p)); break; }
