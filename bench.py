@@ -95,7 +95,7 @@ def main():
                            "range": [int(lo), int(hi)]})
         workload_name = {
             "config2": "BASELINE configs[1]: %d mono 16-bit subframes/GPU, bs 4096, FIXED order 2, Rice k=4, one partition",
-            "config3": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 (precision 12), Rice partition order 4, optimal k",
+            "config3": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 (coefficient precision 12-14), Rice partition order 4, optimal k",
             "config4": "BASELINE configs[3]: %d stereo 24-bit frames/GPU, bs 4096, LPC order 32, mixed partition orders 0-7, Rice2, wasted bits",
         }[args.workload] % args.frames
         scaling = "weak"

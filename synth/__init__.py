@@ -196,15 +196,18 @@ def pcm_stereo(index, n, bits=16):
     return L, np.clip(R, -lim, lim - 1).astype(np.int32)
 
 
-def config3(n=10000, bs=4096, order=8, precision=12, partition_order=4):
-    """10k stereo 16-bit frames, mid/side, both subframes LPC order 8, per-partition optimal k."""
+def config3(n=10000, bs=4096, order=8, precision=None, partition_order=4):
+    """10k stereo 16-bit frames, mid/side, both subframes LPC order 8, coefficient precision 12-14 (frame g
+    of the job's index takes 12 + g mod 3), per-partition optimal k."""
     pcm = np.empty((n, 2, bs), dtype=np.int32)
     fps = []
+    first = BASE_SEED - 20260925               # bench.py shifts BASE_SEED by the first frame of a rank's range
     for i in range(n):
         pcm[i, 0], pcm[i, 1] = pcm_stereo(i, bs)
         fp = FrameParams(CH_MID_SIDE, 0, i)
-        fp.sf[0] = sf(SF_LPC, order, precision, partition_order)
-        fp.sf[1] = sf(SF_LPC, order, precision, partition_order)
+        prec = precision if precision is not None else 12 + (first + i) % 3
+        fp.sf[0] = sf(SF_LPC, order, prec, partition_order)
+        fp.sf[1] = sf(SF_LPC, order, prec, partition_order)
         fps.append(fp)
     return encode_frames("config3: %d stereo frames bs=%d 16-bit M/S LPC-%d P%d" % (n, bs, order, partition_order),
                          pcm, 2, bs, 16, fps)
