@@ -1,0 +1,74 @@
+"""clx_batch_submit / clx_batch_flush: consecutive submissions as a two-stage pipeline (the predictor stage of one beside the Rice
+stage of the next) must give exactly what clx_batch_run gives -- the oracle's samples, statuses and end bits -- whatever the
+caller does with its output buffers: two alternating buffers, the same buffer every time (the library then waits), runs and
+submissions mixed, with the CRC-16 kernel in the step, and for the kernel selections that fall back to plain runs."""
+import numpy as np
+import pytest
+
+import claxon_amd as cx
+import parity_cases as pc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(oracle):
+    import torch
+    ctx = cx.Context(0, wait_s=120)
+    w = synth.concat("mix", [synth.config3(2500), synth.config5_unique(500), synth.small_mixed(150, seed_off=33)])
+    arena = w.arena.copy()
+    arena[int(w.offs[1234] + w.lens[1234]) - 1] ^= 0x40                        # one frame whose CRC-16 no longer matches
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=8)
+    d_arena = torch.from_numpy(arena).to("cuda:0")
+    torch.cuda.synchronize()
+    return ctx, w, pc.workload_descs(w), d_arena, ref, r
+
+
+def check(w, out, res, ref, r, crc):
+    got = out.cpu().numpy()
+    want_status = r["statuses"].copy()
+    if not crc:
+        want_status[1234] = 0                                                   # without the comparison the damaged footer goes unnoticed
+    assert np.array_equal(res["status"], want_status)
+    ok = want_status == 0
+    assert np.array_equal(res["end_bit"][ok], r["end_bits"][ok])
+    for i in np.nonzero(ok)[0][::7]:
+        a = int(w.out_offs[i]); b = a + int(w.channels[i]) * int(w.block_sizes[i])
+        assert np.array_equal(got[a:b], ref[a:b]), i
+    bad = ~ok
+    mask = np.ones(got.size, dtype=bool)
+    for i in np.nonzero(bad)[0]:
+        a = int(w.out_offs[i]); mask[a:a + int(w.channels[i]) * int(w.block_sizes[i])] = False
+    assert np.array_equal(got[mask], ref[mask])
+
+
+@pytest.mark.parametrize("flags,crc", [(cx.PATH_WAVES | cx.K2_LATENCY, False), (cx.PATH_WAVES | cx.K2_LATENCY, True), (0, True),
+                                       (cx.PATH_WAVES | cx.K2_THROUGHPUT, True), (cx.PATH_LANES | cx.LANES_SPLIT, True)],
+                         ids=["waves", "waves-crc", "auto-crc", "waves-1w-crc", "lanes-crc"])
+def test_submit_matches_run(setup, flags, crc):
+    import torch
+    ctx, w, descs, d_arena, ref, r = setup
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    b = ctx.plan(descs, w.out_offs, verify_crc=crc, path=flags)
+    # alternating buffers
+    for i in range(5):
+        b.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr())
+    res = b.results()                                                          # flushes
+    for o in outs:
+        check(w, o, res, ref, r, crc)
+    # the same buffer every time, a plain run in between, then a flush and the narrow stage on the last output
+    for o in outs:
+        o.fill_(0x13131313)
+    torch.cuda.synchronize()
+    b.submit(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    b.submit(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    b.run(d_arena.data_ptr(), w.arena_len, outs[1].data_ptr())
+    b.submit(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    b.flush()
+    res = b.results()
+    check(w, outs[0], res, ref, r, crc)
+    check(w, outs[1], res, ref, r, crc)
+    b.close()
