@@ -239,6 +239,7 @@ struct clx_batch {
     clx_ctx* ctx = nullptr;
     int device = 0;
     clx_path_choice choice = { false, true };
+    bool sfd_stale[2] = { true, true };  // d_sfd / d_sfd_alt hold something other than a previous run's descriptors
     clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
     size_t cap[9] = {};              // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits
     size_t n = 0;
@@ -406,6 +407,7 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
     if (b->d_sfd_alt) { (void)hipFree(b->d_sfd_alt); b->d_sfd_alt = nullptr; }
     if (b->d_results_alt) { (void)hipFree(b->d_results_alt); b->d_results_alt = nullptr; }
     b->stage2_pending[0] = b->stage2_pending[1] = false; b->last_slot = -1;
+    b->sfd_stale[0] = b->sfd_stale[1] = true;
     b->planned_arena_len = (size_t)-1;
     b->ev_valid = false;
     return CLX_OK;
@@ -530,7 +532,8 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_errkey, (const uint64_t*)b->d_endbits, (uint32_t)b->n, b->d_results);
     } else {
-        HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
+        // (K1 writes every slot of every frame on every run; the slots that only pad a stereo pair to an even index are cleared once)
+        if (b->sfd_stale[0]) { HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream)); b->sfd_stale[0] = false; }
         if (!mark("clx_k_residual")) return CLX_API_ERROR;
         launch_stage1_waves(b, d_arena, alloc_len, d_out, b->d_sfd, b->d_results, stream);
         // K2: the two-wave (latency) build while the groups of 64 rows are few, the one-wave (throughput) build beyond
@@ -609,7 +612,7 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     // in behind this submission's 10^4 one-wave workgroups if those were dispatched the moment its Rice stage ends.  The gate
     // event sits right in front of that predictor launch in stream2's queue, so this stream sees it a queue hop later.
     if (b->stage2_pending[other]) HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_gate[other], 0));
-    HIP_TRY(ctx, hipMemsetAsync(sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream));
+    if (b->sfd_stale[slot]) { HIP_TRY(ctx, hipMemsetAsync(sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream)); b->sfd_stale[slot] = false; }
     launch_stage1_waves(b, d_arena, alloc_len, d_out, sfd, results, stream);
     HIP_TRY(ctx, hipEventRecord(b->ev_stage1[slot], stream));
     HIP_TRY(ctx, hipStreamWaitEvent(b->stream2, b->ev_stage1[slot], 0));

@@ -538,6 +538,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     const uint32_t bs = fr.block_size;
     const uint32_t ca = fr.channel_assignment;
 
+    uint32_t n_handed = 0;                   // channels whose descriptor has been handed to K2
     for (uint32_t ch = 0; ch < fr.n_channels && h.err == CLX_ERR_NONE; ++ch) {
         // side channels carry one extra bit (frame.rs:713-741)
         uint32_t bps = fr.bps;
@@ -676,8 +677,12 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                 d->reserved = 0;
                 d->n = (uint16_t)bs;
             }
+            n_handed = ch + 1u;
         }
     }
+    // the slots of subframes that were never reached (the frame failed before them) are empty for K2: every slot of the frame
+    // is written by this wave on every run, so the descriptors need no clearing between runs
+    if ((uint32_t)lane < fr.n_channels - n_handed) sfd[fr.first_slot + n_handed + (uint32_t)lane].n = 0;
     // the footer is read whether or not it is compared (frame.rs:754; under cfg(fuzzing) only the comparison goes away)
     if (!h.err && !(fr.flags & 1u) && (uint64_t)(((h.pos - o) + 7u) & ~7u) + 16u > (uint64_t)fr.limit_bits)
         h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);

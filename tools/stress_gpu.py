@@ -10,7 +10,7 @@ from parity_util import GpuBackend, product_frame_decode
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = cx.Context(0, wait_s=120)
-paths = (("waves", cx.PATH_WAVES), ("lanes-split", cx.PATH_LANES | cx.LANES_SPLIT), ("lanes-fused", cx.PATH_LANES | cx.LANES_FUSED))
+paths = (("waves", cx.PATH_WAVES | cx.K2_LATENCY), ("waves-1w", cx.PATH_WAVES | cx.K2_THROUGHPUT), ("lanes-split", cx.PATH_LANES | cx.LANES_SPLIT), ("lanes-fused", cx.PATH_LANES | cx.LANES_FUSED))
 n_bad = n_all = 0
 for si in range(n_seeds):
     seed = seed0 + 1000 * si
