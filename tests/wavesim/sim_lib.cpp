@@ -56,6 +56,12 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
     return CLX_OK;
 }
 
+// the library's kernel selection rule (clx_plan.h), for tests/test_select_path.py: returns lanes | lanes_split << 1
+extern "C" int sim_select_path(uint64_t slots, uint64_t samples, uint64_t bytes, int heavy, int all_mono) {
+    const clx_path_choice c = clx_select_path(slots, samples, bytes, heavy != 0, all_mono != 0);
+    return (c.lanes ? 1 : 0) | (c.lanes_split ? 2 : 0);
+}
+
 extern "C" int sim_interleave(const int32_t* planar, const clx_frame_desc* frames, size_t n, const uint64_t* out_offs,
                               const clx_frame_result* results, uint8_t* pcm, uint32_t sample_bytes) {
     std::vector<clx_dev_frame> dev(n ? n : 1);
