@@ -16,6 +16,7 @@
 #endif
 
 #include <stdint.h>
+#include <stddef.h>
 
 struct clx_dev_frame {
     uint64_t byte_off;       // frame start (sync code) in the arena
@@ -45,6 +46,10 @@ struct clx_sf_desc {
 #ifdef __cplusplus
 static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
 static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
+// K1 writes the 16 bytes in front of `coef` as one store: {out_base | n, lim_log2, reserved | order, shift, wasted, decor}
+static_assert(offsetof(clx_sf_desc, out_base) == 0 && offsetof(clx_sf_desc, n) == 8 && offsetof(clx_sf_desc, lim_log2) == 10 &&
+              offsetof(clx_sf_desc, reserved) == 11 && offsetof(clx_sf_desc, order) == 12 && offsetof(clx_sf_desc, shift) == 13 &&
+              offsetof(clx_sf_desc, wasted) == 14 && offsetof(clx_sf_desc, decor) == 15 && offsetof(clx_sf_desc, coef) == 16, "clx_sf_desc layout");
 
 // Debug aid (tools/timeline.py): with -DCLX_TIMELINE every wave of an instrumented kernel records when it started and
 // ended (s_memrealtime, 100 MHz), its shader clock ticks and where it ran.  Not part of the product build.

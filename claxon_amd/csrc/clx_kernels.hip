@@ -661,21 +661,19 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
             // inside [-lim, lim), lim <= 2^23 and sum|c| * lim < 2^31 (exact for every in-range history; K2 checks the data)
             uint32_t cabs = (uint32_t)(my_coef < 0 ? -my_coef : my_coef);
             if ((uint32_t)lane >= order || kind < 2u) cabs = 0;
-#pragma unroll
-            for (int sx = 32; sx >= 1; sx >>= 1) cabs += __shfl_xor(cabs, sx, 64);
+            uint32_t csum;
+            (void)clx_wave_excl_scan(cabs, lane, &csum);             // (its total: a DPP reduction, no LDS round trips)
             if (lane == 0) {
-                d->out_base = fr.out_off + (uint64_t)ch * bs;
-                d->order = (uint8_t)((kind >= 2u) ? order : 0u);
-                d->shift = (uint8_t)qshift;
-                d->wasted = (uint8_t)wasted;
-                d->decor = (uint8_t)ca;
-                {   // the largest power of two that keeps sum|c| * lim < 2^31 (and 24-bit factors): K2 checks the data against it
-                    const uint32_t by_sum = cabs != 0u ? 0x7fffffffu / cabs : 0x7fffffffu;
-                    const uint32_t ll = 31u - (uint32_t)__clz((int)(by_sum | 1u));
-                    d->lim_log2 = (uint8_t)(ll < 23u ? ll : 23u);
-                }
-                d->reserved = 0;
-                d->n = (uint16_t)bs;
+                // the largest power of two that keeps sum|c| * lim < 2^31 (and 24-bit factors): K2 checks the data against it
+                const uint32_t by_sum = csum != 0u ? 0x7fffffffu / csum : 0x7fffffffu;
+                const uint32_t ll = 31u - (uint32_t)__clz((int)(by_sum | 1u));
+                // the 16 bytes in front of the coefficients as ONE store (clx_sf_desc's layout: static_asserts in clx_device.h)
+                const uint64_t base = fr.out_off + (uint64_t)ch * bs;
+                uint4 hdr16;
+                hdr16.x = (uint32_t)base; hdr16.y = (uint32_t)(base >> 32);
+                hdr16.z = (bs & 0xffffu) | ((ll < 23u ? ll : 23u) << 16);                                  // n, lim_log2, reserved = 0
+                hdr16.w = ((kind >= 2u) ? order : 0u) | (qshift << 8) | (wasted << 16) | (ca << 24);       // order, shift, wasted, decor
+                *reinterpret_cast<uint4*>(d) = hdr16;
             }
             n_handed = ch + 1u;
         }
@@ -686,12 +684,8 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     // the footer is read whether or not it is compared (frame.rs:754; under cfg(fuzzing) only the comparison goes away)
     if (!h.err && !(fr.flags & 1u) && (uint64_t)(((h.pos - o) + 7u) & ~7u) + 16u > (uint64_t)fr.limit_bits)
         h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-    if (lane == 0) {
-        clx_frame_result r;
-        r.status = (int32_t)(h.err >> 16);
-        r.msg = h.err & 0xffffu;
-        r.end_bit = (uint64_t)(h.pos - o);
-        results[f] = r;
+    if (lane == 0) {                         // status, msg, end_bit (64 bits, upper half 0) as one 16-byte store
+        *reinterpret_cast<uint4*>(&results[f]) = make_uint4(h.err >> 16, h.err & 0xffffu, h.pos - o, 0u);
     }
     CLX_TL_PHASE(5);
     CLX_TL_END(0, blockIdx.x);
