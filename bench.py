@@ -107,11 +107,12 @@ def main():
 
     d_arena = torch.from_numpy(w.arena).to(dev)
     d_out = torch.zeros(w.total_samples, dtype=torch.int32, device=dev)
-    # consecutive steps are submitted as a two-stage software pipeline (clx_batch_submit: the predictor stage of step i runs
-    # beside the Rice stage of step i+1), so they alternate between two output buffers -- when there is room for two
-    pipelined = (not args.no_pipeline) and 2 * 4 * w.total_samples < 32 * (1 << 30)
-    d_out2 = torch.zeros(w.total_samples, dtype=torch.int32, device=dev) if pipelined else None
-    outs = [d_out, d_out2] if pipelined else [d_out]
+    # consecutive steps are submitted with up to cx.SUBMIT_DEPTH of them in flight (clx_batch_submit: each step a whole run on an
+    # internal stream of the library, the Rice stage of one beside the predictor stage and the draining Rice stage of others), so
+    # they rotate over that many output buffers -- when there is room for them
+    depth = cx.SUBMIT_DEPTH
+    pipelined = (not args.no_pipeline) and depth * 4 * w.total_samples < 64 * (1 << 30)
+    outs = [d_out] + ([torch.zeros(w.total_samples, dtype=torch.int32, device=dev) for _ in range(depth - 1)] if pipelined else [])
     path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES}[args.path]
     batch = ctx.plan(descs, w.out_offs, verify_crc=False, path=path)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -126,7 +127,7 @@ def main():
         t0 = time.perf_counter()
         if pipe:
             for i in range(steps):
-                b.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+                b.submit(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
             b.flush(stream)
         else:
             for _ in range(steps):
@@ -134,9 +135,9 @@ def main():
         torch.cuda.synchronize(); barrier()
         return time.perf_counter() - t0
 
-    for i in range(max(args.warmup, 2 if pipelined else 0)):
+    for i in range(max(args.warmup, len(outs) if pipelined else 0)):
         if pipelined:
-            batch.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+            batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
         else:
             batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
     batch.flush(stream)
@@ -154,7 +155,7 @@ def main():
         raise SystemExit("bench: decode is not bit-exact; refusing to report a number")
 
     # ---- per-kernel durations: HIP events recorded by the library on the launch stream, around each of its kernels (steps one at
-    #      a time); they also say which kernels the library selected -- only the two-stage wave path pipelines across steps
+    #      a time); they also say which kernels the library selected -- only the wave path with the latency build of the predictor keeps several steps in flight
     kernel_ms = _kernel_ms(torch, batch, lambda: batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
     pipelined = pipelined and "clx_k_predict" in kernel_ms
 
@@ -210,7 +211,7 @@ def main():
            "compressed_bytes_this_rank": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
            "parallelism": "one frame index sharded over %d GPU(s), no collective on the data path" % world, "shard": shard_info,
            "bit_exact": True, "crc16_in_step": False, "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
-           "steps_in_flight": 2 if pipelined else 1}
+           "steps_in_flight": depth if pipelined else 1}
     out = {
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -225,7 +226,7 @@ def main():
         ms_1 = 1e3 * el_1 / args.steps
         cfg["one_step_at_a_time"] = {"value": round(samples_1 / (ms_1 * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_1, 4),
                                      "frac": round(alg_bytes / (ms_1 * 1e-3) / 1e9 / PEAK_GBS, 4),
-                                     "note": "clx_batch_run: a batch's latency; `value` is the throughput of consecutive batches with two in flight"}
+                                     "note": "clx_batch_run: a batch's latency; `value` is the throughput of consecutive batches with up to %d in flight" % depth}
     if extras and world == 1 and args.workload == "config3" and 8 * 4 * w.total_samples < 16 * (1 << 30):
         cfg["deep_queue"] = _deep_queue(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
     if not w.bare_subframes and not args.no_extras:
@@ -233,9 +234,9 @@ def main():
         #      this is the figure that corresponds to the cpu_baseline leg, which also verifies
         bc = ctx.plan(descs, w.out_offs, verify_crc=True, path=path)
         bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
-        if pipelined:                          # (the first submissions set the pipeline's second stream and buffers up)
-            for i in range(2):
-                bc.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+        if pipelined:                          # (the first submissions set the internal streams and buffers up)
+            for i in range(len(outs)):
+                bc.submit(d_arena.data_ptr(), w.arena_len, outs[i].data_ptr(), stream)
         torch.cuda.synchronize()
         rc = bc.results()
         el_c = timed(bc, args.steps, pipelined)

@@ -23,6 +23,7 @@ OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
 CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)
 ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16, PATH_WAVES, PATH_LANES, PCM_ON_DEVICE, LANES_FUSED, LANES_SPLIT = 1, 2, 4, 8, 16, 32, 64, 128
 K2_LATENCY, K2_THROUGHPUT = 256, 512
+SUBMIT_DEPTH = 4            # CLX_SUBMIT_DEPTH: submissions Batch.submit keeps in flight
 
 
 class ClaxonError(RuntimeError):
@@ -587,8 +588,8 @@ class Batch:
         self.ctx._check(st)
 
     def submit(self, d_arena_ptr, arena_len, d_out_ptr, stream=0):
-        """Pipelined run (clx_batch_submit): the predictor stage overlaps the next submission's Rice stage.  Alternate the
-        output buffers of consecutive submissions; flush() (or results()) before reading them."""
+        """Pipelined run (clx_batch_submit): up to SUBMIT_DEPTH submissions in flight on internal streams.  Rotate over
+        SUBMIT_DEPTH output buffers; flush() (or results()) before reading them."""
         st = lib().clx_batch_submit(self._h, C.c_void_p(d_arena_ptr), arena_len, C.c_void_p(d_out_ptr),
                                     C.c_void_p(stream) if stream else None)
         self.ctx._check(st)

@@ -239,7 +239,6 @@ struct clx_batch {
     clx_ctx* ctx = nullptr;
     int device = 0;
     clx_path_choice choice = { false, true };
-    bool sfd_stale[2] = { true, true };  // d_sfd / d_sfd_alt hold something other than a previous run's descriptors
     clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
     size_t cap[9] = {};              // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits
     size_t n = 0;
@@ -267,16 +266,24 @@ struct clx_batch {
     bool ev_valid = false;
     hipStream_t last_stream = nullptr;
     size_t planned_arena_len = 0;
-    // two-stage software pipeline over consecutive submissions (clx_batch_submit): stage 2 (predictor kernels) of submission i
-    // runs on `stream2` beside stage 1 (Rice / residual kernel) of submission i+1; what stage 1 hands to stage 2 is double-buffered
-    hipStream_t stream2 = nullptr;
-    clx_sf_desc* d_sfd_alt = nullptr;
-    clx_frame_result* d_results_alt = nullptr;
-    hipEvent_t ev_stage1[2] = {}, ev_stage2[2] = {}, ev_gate[2] = {};
-    bool stage2_pending[2] = { false, false };
-    const int32_t* pending_out[2] = { nullptr, nullptr };
+    // Pipelined submissions (clx_batch_submit): up to kDepth submissions in flight, each a whole run (Rice stage, predictor stage,
+    // CRC) on a stream of its own with its own descriptors and results -- the Rice stage of one fills the machine while the
+    // serial chains of another's predictor stage and the tail of a third's Rice stage (its last, partly filled round of waves) run.
+    enum { kDepth = CLX_SUBMIT_DEPTH };
+    struct Flight {
+        hipStream_t stream = nullptr;
+        clx_sf_desc* d_sfd = nullptr;            // flight 0 uses the batch's own d_sfd / d_results
+        clx_frame_result* d_results = nullptr;
+        hipEvent_t ev_in = nullptr, ev_done = nullptr;
+        hipEvent_t ev_rice = nullptr, ev_crc = nullptr;   // with CLX_VERIFY_CRC16: the CRC kernel runs on crc_stream beside the predictor stage
+        bool crc_pending = false, crc_recorded = false;
+        bool pending = false;                    // submitted, nobody has been made to wait for it yet
+        bool sfd_stale = true;                   // d_sfd holds something other than a previous run's descriptors
+        const int32_t* out = nullptr;            // where the pending submission writes
+    } flight[kDepth];
+    hipStream_t crc_stream = nullptr;
     uint64_t n_submitted = 0;
-    int last_slot = -1;              // slot of the most recent pipelined submission (-1: the last run was a plain clx_batch_run)
+    int last_slot = -1;              // flight of the most recent pipelined submission (-1: the last run was a plain clx_batch_run)
 };
 
 namespace {
@@ -339,12 +346,17 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_errkey) (void)hipFree(b->d_errkey);
     if (b->d_endbits) (void)hipFree(b->d_endbits);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
-    for (auto& e : b->ev_stage1) if (e) (void)hipEventDestroy(e);
-    for (auto& e : b->ev_stage2) if (e) (void)hipEventDestroy(e);
-    for (auto& e : b->ev_gate) if (e) (void)hipEventDestroy(e);
-    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
-    if (b->d_sfd_alt) (void)hipFree(b->d_sfd_alt);
-    if (b->d_results_alt) (void)hipFree(b->d_results_alt);
+    if (b->crc_stream) { (void)hipStreamSynchronize(b->crc_stream); (void)hipStreamDestroy(b->crc_stream); }
+    for (int i = 0; i < clx_batch::kDepth; ++i) {
+        clx_batch::Flight& F = b->flight[i];
+        if (F.stream) { (void)hipStreamSynchronize(F.stream); (void)hipStreamDestroy(F.stream); }
+        if (F.ev_in) (void)hipEventDestroy(F.ev_in);
+        if (F.ev_done) (void)hipEventDestroy(F.ev_done);
+        if (F.ev_rice) (void)hipEventDestroy(F.ev_rice);
+        if (F.ev_crc) (void)hipEventDestroy(F.ev_crc);
+        if (i != 0 && F.d_sfd) (void)hipFree(F.d_sfd);
+        if (i != 0 && F.d_results) (void)hipFree(F.d_results);
+    }
     if (b->h_up) (void)hipHostFree(b->h_up);
     delete b;
 }
@@ -404,10 +416,13 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
             !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) return CLX_API_ERROR;
     }
     // (a re-planned batch starts over: nothing of the previous plan may be in flight -- the caller's contract)
-    if (b->d_sfd_alt) { (void)hipFree(b->d_sfd_alt); b->d_sfd_alt = nullptr; }
-    if (b->d_results_alt) { (void)hipFree(b->d_results_alt); b->d_results_alt = nullptr; }
-    b->stage2_pending[0] = b->stage2_pending[1] = false; b->last_slot = -1;
-    b->sfd_stale[0] = b->sfd_stale[1] = true;
+    for (int i = 0; i < clx_batch::kDepth; ++i) {
+        clx_batch::Flight& F = b->flight[i];
+        if (i != 0 && F.d_sfd) (void)hipFree(F.d_sfd);
+        if (i != 0 && F.d_results) (void)hipFree(F.d_results);
+        F.d_sfd = nullptr; F.d_results = nullptr; F.pending = false; F.crc_pending = false; F.sfd_stale = true; F.out = nullptr;   // (crc_recorded stays: the event is still there)
+    }
+    b->last_slot = -1;
     b->planned_arena_len = (size_t)-1;
     b->ev_valid = false;
     return CLX_OK;
@@ -477,6 +492,55 @@ void launch_stage1_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_le
     hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), k1_pad, stream,
                        d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, d_sfd, d_results);
 }
+// K2 (+ K3) behind it: the two-wave (latency) build while the groups of 64 rows are few, the one-wave (throughput) build beyond
+bool k2_latency_build(const clx_batch* b) {
+    const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
+    return (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
+}
+// `crc_beside` (pipelined submissions): the CRC kernel needs the Rice stage's end bits only -- it goes to `crc_stream` behind
+// `ev_rice` and runs beside the predictor stage; `ev_crc` says when it is done
+template <typename Mark>
+bool launch_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
+                  hipStream_t stream, Mark&& mark, hipStream_t crc_stream = nullptr, hipEvent_t ev_rice = nullptr, hipEvent_t ev_crc = nullptr) {
+    if (!mark("clx_k_residual")) return false;
+    launch_stage1_waves(b, d_arena, alloc_len, d_out, d_sfd, d_results, stream);
+    const bool crc_beside = crc_stream != nullptr && (b->flags & CLX_VERIFY_CRC16);
+    if (crc_beside) {
+        if (hipEventRecord(ev_rice, stream) != hipSuccess || hipStreamWaitEvent(crc_stream, ev_rice, 0) != hipSuccess) return false;
+        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, crc_stream, d_arena,
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_results);
+        if (hipEventRecord(ev_crc, crc_stream) != hipSuccess) return false;
+    }
+    const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
+    if (k2_latency_build(b)) {
+        if (!mark("clx_k_predict")) return false;
+        hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, stream, d_out,
+                           (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
+    } else {
+        if (!mark("clx_k_predict_1w")) return false;
+        hipLaunchKernelGGL(clx_k_predict_1w, dim3(groups), dim3(64), 0, stream, d_out,
+                           (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
+        if (!mark("clx_k_predict_1w_hi")) return false;                     // groups with a predictor order above 12
+        hipLaunchKernelGGL(clx_k_predict_1w_hi, dim3(groups), dim3(64), 0, stream, d_out,
+                           (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
+    }
+    if ((b->flags & CLX_VERIFY_CRC16) && !crc_beside) {
+        if (!mark("clx_k_crc16")) return false;
+        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena,
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_results);
+    }
+    return true;
+}
+// make `stream` wait for every pipelined submission that nobody has waited for yet
+int wait_flights(clx_batch* b, hipStream_t stream) {
+    for (auto& F : b->flight)
+        if (F.pending) {
+            HIP_TRY(b->ctx, hipStreamWaitEvent(stream, F.ev_done, 0));
+            if (F.crc_pending) HIP_TRY(b->ctx, hipStreamWaitEvent(stream, F.ev_crc, 0));
+            F.pending = false; F.crc_pending = false;
+        }
+    return CLX_OK;
+}
 }  // namespace
 
 extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, void* stream_) {
@@ -487,10 +551,8 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    if (b->last_slot >= 0) {                                            // pipelined submissions still in flight touch the same buffers
-        for (int s = 0; s < 2; ++s) if (b->stage2_pending[s]) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[s], 0)); b->stage2_pending[s] = false; }
-        b->last_slot = -1;
-    }
+    if (wait_flights(b, stream) != CLX_OK) return CLX_API_ERROR;       // pipelined submissions still in flight touch the same buffers
+    b->last_slot = -1;
     b->last_stream = stream;
     if (upload_plan(b, arena_len, stream) != CLX_OK) return CLX_API_ERROR;
     const uint64_t alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;   // claxon_hip.h: the allocation covers this
@@ -533,26 +595,11 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_errkey, (const uint64_t*)b->d_endbits, (uint32_t)b->n, b->d_results);
     } else {
         // (K1 writes every slot of every frame on every run; the slots that only pad a stereo pair to an even index are cleared once)
-        if (b->sfd_stale[0]) { HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream)); b->sfd_stale[0] = false; }
-        if (!mark("clx_k_residual")) return CLX_API_ERROR;
-        launch_stage1_waves(b, d_arena, alloc_len, d_out, b->d_sfd, b->d_results, stream);
-        // K2: the two-wave (latency) build while the groups of 64 rows are few, the one-wave (throughput) build beyond
-        const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
-        const bool k2_latency = (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
-        if (k2_latency) {
-            if (!mark("clx_k_predict")) return CLX_API_ERROR;
-            hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, stream, d_out,
-                               (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
-        } else {
-            if (!mark("clx_k_predict_1w")) return CLX_API_ERROR;
-            hipLaunchKernelGGL(clx_k_predict_1w, dim3(groups), dim3(64), 0, stream, d_out,
-                               (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
-            if (!mark("clx_k_predict_1w_hi")) return CLX_API_ERROR;         // groups with a predictor order above 12
-            hipLaunchKernelGGL(clx_k_predict_1w_hi, dim3(groups), dim3(64), 0, stream, d_out,
-                               (const clx_sf_desc*)b->d_sfd, (uint32_t)b->n_slots, b->d_dump);
-        }
+        clx_batch::Flight& F0 = b->flight[0];
+        if (F0.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream)); F0.sfd_stale = false; }
+        if (!launch_waves(b, d_arena, alloc_len, d_out, b->d_sfd, b->d_results, stream, mark)) return CLX_API_ERROR;
     }
-    if (b->flags & CLX_VERIFY_CRC16) {
+    if (lanes && (b->flags & CLX_VERIFY_CRC16)) {
         if (!mark("clx_k_crc16")) return CLX_API_ERROR;
         hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, b->d_results);
@@ -562,12 +609,16 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     return CLX_OK;
 }
 
-// Pipelined submission (wave path): the same work as clx_batch_run, but the predictor stage goes to a second, higher-priority
-// stream, so that the NEXT submission's Rice stage -- issue-bound, it fills the machine -- runs beside it: the predictor stage
-// is one serial chain per subframe that occupies a fraction of the SIMDs for its whole duration.  What the stages hand over
-// (subframe descriptors, per-frame results) is double-buffered; the caller keeps consecutive submissions' OUTPUTS apart (a
-// submission whose d_out is still being finished by the previous one waits for it -- correct, not overlapped).
-// clx_batch_flush makes `stream` wait for everything submitted so far; clx_batch_results does so itself.
+// Pipelined submission (wave path): the same work as clx_batch_run, on one of kDepth internal streams in rotation, so that up to
+// kDepth submissions are in flight.  One run alone leaves the machine half idle twice: the Rice stage's last round of waves (10 000
+// one-wave workgroups on 8 192 wave slots) runs at a fraction of the occupancy it needs, and the predictor stage is one serial
+// chain per subframe on a fraction of the SIMDs.  Runs side by side fill both.  (Measured, 10 000 config-3 frames: one at a time
+// 0.41 ms per step; the earlier two-stage form -- predictor stage of submission i on a second stream beside the Rice stage of
+// i+1 -- 0.355; three or four whole runs in flight 0.31-0.33.)
+// Each flight has its own descriptors and results; the caller keeps the OUTPUTS of submissions in flight apart (one whose d_out
+// is still being written by an earlier one waits for it -- correct, not overlapped).  `stream` is where the caller's inputs come
+// from: the submission starts after everything queued on it so far.  clx_batch_flush makes `stream` wait for everything submitted;
+// clx_batch_results does so itself.
 extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, void* stream_) {
     if (!b || !b->ctx) return CLX_API_ERROR;
     clx_ctx* ctx = b->ctx;
@@ -576,53 +627,51 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
     const int lanes = use_lanes(b, arena_len);
     if (lanes < 0) return CLX_API_ERROR;
-    const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
-    const bool k2_latency = (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
-    // the lane kernels are one fused stage, and the one-wave predictor build is chosen when the machine is full anyway.  (Whole
-    // submissions of those side by side on streams of their own were measured -- three in flight, tools/bench_configs.py: no
-    // gain for the two-wave lane build, a loss for the one-wave predictor build -- and are not done.)
-    if (lanes || !k2_latency || b->profiling) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
+    // the lane kernels and the one-wave predictor build are chosen when one run fills the machine anyway.  (Whole submissions of
+    // those side by side were measured -- tools/bench_configs.py: no gain for the two-wave lane build, a loss for the one-wave
+    // predictor build -- and are not done.)
+    if (lanes || !k2_latency_build(b) || b->profiling) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    if (!b->stream2) {
-        int lo = 0, hi = 0;
-        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));                   // (hi is the numerically lowest = highest priority)
-        HIP_TRY(ctx, hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, hi));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_stage1[i], hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_stage2[i], hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_gate[i], hipEventDisableTiming));
+    const int slot = (int)(b->n_submitted % clx_batch::kDepth);
+    clx_batch::Flight& F = b->flight[slot];
+    if (!F.stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&F.stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_in, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_rice, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_crc, hipEventDisableTiming));
+    }
+    const bool crc = (b->flags & CLX_VERIFY_CRC16) != 0;
+    if (crc && !b->crc_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->crc_stream, hipStreamNonBlocking));
+    if (!F.d_sfd) {
+        if (slot == 0) { F.d_sfd = b->d_sfd; F.d_results = b->d_results; }
+        else {
+            const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
+            HIP_TRY(ctx, hipMalloc((void**)&F.d_sfd, ns * sizeof(clx_sf_desc)));
+            HIP_TRY(ctx, hipMalloc((void**)&F.d_results, nf * sizeof(clx_frame_result)));
+            F.sfd_stale = true;
         }
     }
-    if (!b->d_sfd_alt) {
-        const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_sfd_alt, ns * sizeof(clx_sf_desc)));
-        HIP_TRY(ctx, hipMalloc((void**)&b->d_results_alt, nf * sizeof(clx_frame_result)));
-    }
+    // a plan that has to be uploaded again (the arena's length changed) is read by the submissions in flight
+    if (b->planned_arena_len != arena_len && b->planned_arena_len != (size_t)-1 && wait_flights(b, stream) != CLX_OK) return CLX_API_ERROR;
     if (upload_plan(b, arena_len, stream) != CLX_OK) return CLX_API_ERROR;
     const uint64_t alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;
-    const int slot = (int)(b->n_submitted & 1u), other = slot ^ 1;
-    clx_sf_desc* sfd = slot ? b->d_sfd_alt : b->d_sfd;
-    clx_frame_result* results = slot ? b->d_results_alt : b->d_results;
-    // this slot's descriptors are free once the submission before the previous one has been finished ...
-    if (b->stage2_pending[slot]) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[slot], 0)); b->stage2_pending[slot] = false; }
-    // ... and an output buffer that the previous submission is still finishing cannot take new residuals yet
-    if (b->stage2_pending[other] && b->pending_out[other] == d_out) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[other], 0)); b->stage2_pending[other] = false; }
-    // the previous submission's predictor stage goes first: its few workgroups need a large share of a CU each and would trickle
-    // in behind this submission's 10^4 one-wave workgroups if those were dispatched the moment its Rice stage ends.  The gate
-    // event sits right in front of that predictor launch in stream2's queue, so this stream sees it a queue hop later.
-    if (b->stage2_pending[other]) HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_gate[other], 0));
-    if (b->sfd_stale[slot]) { HIP_TRY(ctx, hipMemsetAsync(sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream)); b->sfd_stale[slot] = false; }
-    launch_stage1_waves(b, d_arena, alloc_len, d_out, sfd, results, stream);
-    HIP_TRY(ctx, hipEventRecord(b->ev_stage1[slot], stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(b->stream2, b->ev_stage1[slot], 0));
-    HIP_TRY(ctx, hipEventRecord(b->ev_gate[slot], b->stream2));
-    hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, b->stream2, d_out, (const clx_sf_desc*)sfd, (uint32_t)b->n_slots, b->d_dump);
-    HIP_TRY(ctx, hipEventRecord(b->ev_stage2[slot], b->stream2));
-    if (b->flags & CLX_VERIFY_CRC16)       // needs stage 1's end_bit only: runs beside the predictor stage
-        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, results);
-    b->stage2_pending[slot] = true;
-    b->pending_out[slot] = d_out;
+    HIP_TRY(ctx, hipEventRecord(F.ev_in, stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_in, 0));
+    // (the flight's previous submission is ahead of this one in the same stream) an output buffer that another flight is still
+    // writing cannot take new residuals yet
+    for (auto& G : b->flight)
+        if (&G != &F && G.pending && G.out == d_out) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, G.ev_done, 0));
+    if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
+    // (this flight's previous CRC kernel wrote into the results the Rice stage is about to overwrite)
+    if (F.crc_recorded) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_crc, 0));
+    if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, [](const char*) { return true; },
+                      crc ? b->crc_stream : nullptr, F.ev_rice, F.ev_crc)) return CLX_API_ERROR;
+    HIP_TRY(ctx, hipEventRecord(F.ev_done, F.stream));
+    F.crc_pending = crc; F.crc_recorded = F.crc_recorded || crc;
+    F.pending = true;
+    F.out = d_out;
     b->last_slot = slot;
     b->last_stream = stream;
     ++b->n_submitted;
@@ -636,8 +685,7 @@ extern "C" int clx_batch_flush(clx_batch* b, void* stream_) {
     clx_ctx* ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : (b->last_stream ? b->last_stream : ctx->stream);
-    for (int s = 0; s < 2; ++s) if (b->stage2_pending[s]) { HIP_TRY(ctx, hipStreamWaitEvent(stream, b->ev_stage2[s], 0)); b->stage2_pending[s] = false; }
-    return CLX_OK;
+    return wait_flights(b, stream);
 }
 
 extern "C" int clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void* d_pcm, uint32_t sample_bytes, void* stream_) {
@@ -648,7 +696,7 @@ extern "C" int clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void*
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : (b->last_stream ? b->last_stream : ctx->stream);
     hipLaunchKernelGGL(clx_k_interleave, dim3((unsigned)b->n), dim3(256), 0, stream, d_planar,
-                       (const clx_dev_frame*)b->d_frames, (const clx_frame_result*)(b->last_slot == 1 ? b->d_results_alt : b->d_results), (uint32_t)b->n,
+                       (const clx_dev_frame*)b->d_frames, (const clx_frame_result*)(b->last_slot > 0 ? b->flight[b->last_slot].d_results : b->d_results), (uint32_t)b->n,
                        (uint8_t*)d_pcm, sample_bytes);
     HIP_TRY(ctx, hipGetLastError());
     return CLX_OK;
@@ -661,7 +709,7 @@ extern "C" int clx_batch_results(clx_batch* b, clx_frame_result* results) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = b->last_stream ? b->last_stream : ctx->stream;
     if (clx_batch_flush(b, stream) != CLX_OK) return CLX_API_ERROR;       // (pipelined submissions: the predictor stage too)
-    const clx_frame_result* src = b->last_slot == 1 ? b->d_results_alt : b->d_results;
+    const clx_frame_result* src = b->last_slot > 0 ? b->flight[b->last_slot].d_results : b->d_results;
     HIP_TRY(ctx, hipMemcpyAsync(results, src, b->n * sizeof(clx_frame_result), hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     return CLX_OK;

@@ -254,12 +254,17 @@ int  clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
                       const uint64_t* out_sample_offsets, uint32_t flags, clx_batch** out);
 int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                    int32_t* d_out, void* stream);
-/* Pipelined submission: the same work and the same results as clx_batch_run, as a two-stage software pipeline over
- * CONSECUTIVE submissions -- the predictor stage of submission i runs on a second stream beside the Rice stage of submission
- * i+1 (the reference has no counterpart: one FrameReader decodes one frame at a time, frame.rs:667).  Give consecutive
- * submissions different `d_out` buffers (the same buffer is legal: the submission then waits for the previous one).  Work
- * enqueued on `stream` after clx_batch_flush sees every submission finished; clx_batch_results flushes by itself and
- * returns the LAST submission's results.  Falls back to clx_batch_run for the kernel selections that are one stage. */
+/* Pipelined submission: the same work and the same results as clx_batch_run, with up to CLX_SUBMIT_DEPTH submissions in
+ * flight -- each a whole run on an internal stream of its own, so that the Rice stage of one runs beside the predictor stage
+ * and the draining Rice stage of others (the reference has no counterpart: one FrameReader decodes one frame at a time,
+ * frame.rs:667).  A submission starts after everything queued on `stream` so far.  Give the submissions in flight different
+ * `d_out` buffers, i.e. rotate over CLX_SUBMIT_DEPTH of them (re-using a buffer is legal: the submission then waits for the
+ * earlier one that writes it).  Work enqueued on `stream` after clx_batch_flush sees every submission finished;
+ * clx_batch_results flushes by itself and returns the LAST submission's results.  Falls back to clx_batch_run for the kernel
+ * selections that fill the machine with one run. */
+#ifndef CLX_SUBMIT_DEPTH
+#define CLX_SUBMIT_DEPTH 4
+#endif
 int  clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                       int32_t* d_out, void* stream);
 int  clx_batch_flush(clx_batch* b, void* stream);

@@ -1,7 +1,8 @@
-"""clx_batch_submit / clx_batch_flush: consecutive submissions as a two-stage pipeline (the predictor stage of one beside the Rice
-stage of the next) must give exactly what clx_batch_run gives -- the oracle's samples, statuses and end bits -- whatever the
-caller does with its output buffers: two alternating buffers, the same buffer every time (the library then waits), runs and
-submissions mixed, with the CRC-16 kernel in the step, and for the kernel selections that fall back to plain runs."""
+"""clx_batch_submit / clx_batch_flush: up to SUBMIT_DEPTH submissions in flight (whole runs on internal streams, each with its own
+descriptors and results) must give exactly what clx_batch_run gives -- the oracle's samples, statuses and end bits -- whatever the
+caller does with its output buffers: a rotation over SUBMIT_DEPTH buffers, two alternating buffers or the same buffer every time
+(the library then waits for the earlier writer), runs and submissions mixed, with the CRC-16 kernel in the step, and for the
+kernel selections that fall back to plain runs."""
 import numpy as np
 import pytest
 
@@ -50,14 +51,23 @@ def check(w, out, res, ref, r, crc):
 def test_submit_matches_run(setup, flags, crc):
     import torch
     ctx, w, descs, d_arena, ref, r = setup
-    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(cx.SUBMIT_DEPTH)]
     torch.cuda.synchronize()
     b = ctx.plan(descs, w.out_offs, verify_crc=crc, path=flags)
-    # alternating buffers
-    for i in range(5):
-        b.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr())
+    # a buffer per submission in flight
+    for i in range(2 * cx.SUBMIT_DEPTH + 1):
+        b.submit(d_arena.data_ptr(), w.arena_len, outs[i % cx.SUBMIT_DEPTH].data_ptr())
     res = b.results()                                                          # flushes
     for o in outs:
+        check(w, o, res, ref, r, crc)
+    # two alternating buffers: every submission waits for the one before the previous one
+    for o in outs:
+        o.fill_(0x2b2b2b2b)
+    torch.cuda.synchronize()
+    for i in range(5):
+        b.submit(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr())
+    res = b.results()
+    for o in outs[:2]:
         check(w, o, res, ref, r, crc)
     # the same buffer every time, a plain run in between, then a flush and the narrow stage on the last output
     for o in outs:

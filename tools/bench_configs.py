@@ -2,7 +2,7 @@
 behind the library's choice of kernels (clx_batch_create) and the check that "auto" stays close to the best column.
 usage: python tools/bench_configs.py [sizes [configs]]     e.g.  4000,8000,16000,32000 config4,config5
 Prints one line per (config, size): ms per step for every selection (run = one batch at a time; sub = pipelined submissions,
-two in flight), after a bit-exactness check of each."""
+SUBMIT_DEPTH in flight), after a bit-exactness check of each."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ for name, make in makers:
         w = head(big, n)
         descs = workload_descs(w)
         d_arena = torch.from_numpy(w.arena).cuda()
-        outs = [torch.zeros(w.pcm.size, dtype=torch.int32, device="cuda") for _ in range(2)]
+        outs = [torch.zeros(w.pcm.size, dtype=torch.int32, device="cuda") for _ in range(cx.SUBMIT_DEPTH)]
         ref = torch.from_numpy(w.pcm).cuda()
         cols = []
         for pname, path in paths:
@@ -35,12 +35,12 @@ for name, make in makers:
                 f = batch.run if mode == "run" else batch.submit
                 for o in outs: o.zero_()
                 torch.cuda.synchronize()          # (the library's stream does not wait for torch's)
-                for i in range(2): f(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+                for i in range(len(outs)): f(d_arena.data_ptr(), w.arena_len, outs[i].data_ptr(), stream)
                 batch.flush(stream); torch.cuda.synchronize()
                 ok = bool(np.all(batch.results()["status"] == 0)) and all(bool(torch.equal(o, ref)) for o in outs)
                 reps = 10
                 t = time.perf_counter()
-                for i in range(reps): f(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+                for i in range(reps): f(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
                 batch.flush(stream); torch.cuda.synchronize()
                 res[mode] = ((time.perf_counter() - t) / reps * 1e3, ok)
             batch.set_profiling(True); batch.run(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr(), stream); torch.cuda.synchronize()

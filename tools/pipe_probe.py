@@ -1,17 +1,18 @@
-"""Step time of the wave path when consecutive submissions are pipelined (clx_batch_submit: predictor stage of submission i
-beside the Rice stage of submission i+1) against plain runs; checks both outputs bit for bit.
-usage: python tools/pipe_probe.py [frames] [steps]"""
+"""Step time of the wave path when consecutive submissions are pipelined (clx_batch_submit: up to SUBMIT_DEPTH whole runs in
+flight on internal streams) against plain runs; checks every output buffer bit for bit.
+usage: python tools/pipe_probe.py [frames] [steps] [output buffers]"""
 import sys, time
 import numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import claxon_amd as cx, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+nbuf = int(sys.argv[3]) if len(sys.argv) > 3 else cx.SUBMIT_DEPTH          # output buffers in rotation
 w = synth.config3(n)
 ctx = cx.Context(0, wait_s=120)
 descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
 d_arena = torch.from_numpy(w.arena).cuda()
-outs = [torch.zeros(w.pcm.size, dtype=torch.int32, device="cuda") for _ in range(2)]
+outs = [torch.zeros(w.pcm.size, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
 pcm = torch.from_numpy(w.pcm).cuda()
 stream = torch.cuda.current_stream().cuda_stream
 for crc in (False, True):
@@ -20,10 +21,10 @@ for crc in (False, True):
         f = b.run if mode == "run" else b.submit
         for o in outs: o.zero_()
         torch.cuda.synchronize()          # (the library's stream does not wait for torch's)
-        for i in range(4): f(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+        for i in range(2 * len(outs)): f(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
         b.flush(stream); torch.cuda.synchronize()
         t = time.perf_counter()
-        for i in range(steps): f(d_arena.data_ptr(), w.arena_len, outs[i & 1].data_ptr(), stream)
+        for i in range(steps): f(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
         b.flush(stream); torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
         res = b.results()
