@@ -238,7 +238,8 @@ struct clx_ctx {
 struct clx_batch {
     clx_ctx* ctx = nullptr;
     int device = 0;
-    clx_path_choice choice = { false, true };
+    clx_path_choice choice = { false, true };          // for one run at a time (clx_batch_run)
+    clx_path_choice choice_submit = { false, true };   // for pipelined submissions (clx_batch_submit)
     clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
     size_t cap[9] = {};              // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits
     size_t n = 0;
@@ -398,6 +399,7 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
             all_mono = all_mono && frames[i].n_channels == 1;
         }
         b->choice = clx_select_path(slot, samples, lengths_known ? bytes : 0, 4 * wide >= samples && samples != 0, all_mono);
+        b->choice_submit = clx_select_path(slot, samples, lengths_known ? bytes : 0, 4 * wide >= samples && samples != 0, all_mono, true);
     }
     b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : b->choice.lanes;
     {   // where stores that fall outside a row go (K2 and D2 keep their store instructions unconditional)
@@ -501,7 +503,8 @@ bool k2_latency_build(const clx_batch* b) {
 // `ev_rice` and runs beside the predictor stage; `ev_crc` says when it is done
 template <typename Mark>
 bool launch_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
-                  hipStream_t stream, Mark&& mark, hipStream_t crc_stream = nullptr, hipEvent_t ev_rice = nullptr, hipEvent_t ev_crc = nullptr) {
+                  hipStream_t stream, Mark&& mark, bool k2_latency, hipStream_t crc_stream = nullptr, hipEvent_t ev_rice = nullptr,
+                  hipEvent_t ev_crc = nullptr) {
     if (!mark("clx_k_residual")) return false;
     launch_stage1_waves(b, d_arena, alloc_len, d_out, d_sfd, d_results, stream);
     const bool crc_beside = crc_stream != nullptr && (b->flags & CLX_VERIFY_CRC16);
@@ -512,7 +515,7 @@ bool launch_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int3
         if (hipEventRecord(ev_crc, crc_stream) != hipSuccess) return false;
     }
     const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
-    if (k2_latency_build(b)) {
+    if (k2_latency) {
         if (!mark("clx_k_predict")) return false;
         hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, stream, d_out,
                            (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
@@ -597,7 +600,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         // (K1 writes every slot of every frame on every run; the slots that only pad a stereo pair to an even index are cleared once)
         clx_batch::Flight& F0 = b->flight[0];
         if (F0.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream)); F0.sfd_stale = false; }
-        if (!launch_waves(b, d_arena, alloc_len, d_out, b->d_sfd, b->d_results, stream, mark)) return CLX_API_ERROR;
+        if (!launch_waves(b, d_arena, alloc_len, d_out, b->d_sfd, b->d_results, stream, mark, k2_latency_build(b))) return CLX_API_ERROR;
     }
     if (lanes && (b->flags & CLX_VERIFY_CRC16)) {
         if (!mark("clx_k_crc16")) return CLX_API_ERROR;
@@ -625,12 +628,12 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     if (b->n == 0) return CLX_OK;
     if (!d_arena || !d_out) { ctx->last_error = "null device pointer"; return CLX_API_ERROR; }
     if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
-    const int lanes = use_lanes(b, arena_len);
-    if (lanes < 0) return CLX_API_ERROR;
-    // the lane kernels and the one-wave predictor build are chosen when one run fills the machine anyway.  (Whole submissions of
-    // those side by side were measured -- tools/bench_configs.py: no gain for the two-wave lane build, a loss for the one-wave
-    // predictor build -- and are not done.)
-    if (lanes || !k2_latency_build(b) || b->profiling) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
+    // Which kernels: with several batches in flight the wave kernels (two-wave predictor build) stay ahead of the lane kernels for
+    // longer than one run at a time (clx_select_path, `pipelined`).  Beyond that -- or when the caller asks for the lane kernels or
+    // the one-wave predictor build -- a submission is a plain run: whole runs of those side by side were measured
+    // (tools/bench_configs.py): no gain for the two-wave lane build, a loss for the one-wave predictor build.
+    const bool want_lanes = (b->flags & CLX_PATH_LANES) ? true : (b->flags & CLX_PATH_WAVES) ? false : (b->lanes && b->choice_submit.lanes);
+    if (want_lanes || (b->flags & CLX_K2_THROUGHPUT) || b->profiling) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
     const int slot = (int)(b->n_submitted % clx_batch::kDepth);
@@ -666,7 +669,7 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
     // (this flight's previous CRC kernel wrote into the results the Rice stage is about to overwrite)
     if (F.crc_recorded) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_crc, 0));
-    if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, [](const char*) { return true; },
+    if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, [](const char*) { return true; }, true,
                       crc ? b->crc_stream : nullptr, F.ev_rice, F.ev_crc)) return CLX_API_ERROR;
     HIP_TRY(ctx, hipEventRecord(F.ev_done, F.stream));
     F.crc_pending = crc; F.crc_recorded = F.crc_recorded || crc;

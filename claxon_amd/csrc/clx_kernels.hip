@@ -49,34 +49,39 @@ struct K1Lds {
         } t;
         uint16_t P[CLX_NPOS];      // P[i]: bit position (relative to the span) where code i of the span starts
     } u;
-    // lut[s * 16 + nib]: what four stream bits `nib` (MSB first) do to a walk that meets them in state s, for the Rice
-    // parameter of the partition being decoded (k <= CLX_LUT_KMAX: at most 8 rows; copied from the ROM when k changes).  High nibble: the
-    // state behind the four bits; low nibble: which of the four positions are code starts (bit i = the i-th bit).
-    // Any byte is a valid entry at all times, so a chain of look-ups never leaves the table.
-    uint8_t lut[256];
+    // lut[nib] = {f, g} = {F, G}: what four stream bits `nib` (MSB first) do to a walk, for EVERY state the walk can be in and for the
+    // Rice parameter of the partition being decoded (k <= CLX_LUT_KMAX; copied from the ROM when k changes).  States are carried
+    // multiplied by five (s5 = 5 * state, state <= k + 1 <= 5): field s5 (5 bits wide) of F is 5 * (the state behind the four
+    // bits), of G which of the four positions are code starts (bit i = the i-th bit).  A step of a walk is then ONE v_bfe_u32
+    // with the state as its offset -- no address arithmetic, no LDS access that depends on the state: the table rows of a
+    // chunk's nibbles are fetched ahead of the walks.
+    struct alignas(8) Row { uint32_t f, g; } lut[16];
     uint8_t gent[8];           // entry state of each group of 8 chunks / of each chunk: every lane writes the entries of the
     uint8_t ent[64];           // chains it walks (lanes of a group walk the same chain) and reads back its own
 };
 
-// The transition tables of K1Lds::lut for the Rice parameters that use them (k <= CLX_LUT_KMAX), generated at compile time
-// and kept in constant memory: switching the LDS copy to another parameter is one 4-byte load + store in 28 lanes.
-#ifndef CLX_LUT_KMAX            // (CLX_EXTRA_FLAGS=-DCLX_LUT_KMAX=6u builds the other setting the single exit register allows)
-#define CLX_LUT_KMAX 5u
-#endif
+// The transition tables of K1Lds::lut for the Rice parameters that use them (k <= CLX_LUT_KMAX: k + 2 states of 5 bits each fill
+// a dword), generated at compile time and kept in constant memory: switching the LDS copy to another parameter is one 4-byte
+// load + store in 32 lanes.
+#define CLX_LUT_KMAX 4u
 struct K1LutRom { uint32_t w[CLX_LUT_KMAX + 1u][32]; };
 constexpr K1LutRom clx_make_lut_rom() {
     K1LutRom r{};
     for (uint32_t k = 0; k <= CLX_LUT_KMAX; ++k) {
         const uint32_t SC = k + 1u;
-        for (uint32_t e = 0; e < (k + 2u) * 16u; ++e) {
-            uint32_t st = e >> 4, starts = 0;
-            const uint32_t nib = e & 15u;
-            for (uint32_t i = 0; i < 4u; ++i) {
-                if (st == 0u) starts |= 1u << i;                                   // a code starts at this bit
-                const bool rem = st >= 1u && st <= k;                              // a remainder bit: count it down
-                st = rem ? st - 1u : (((nib >> (3u - i)) & 1u) ? k : SC);          // a one ends the run, a zero continues it
+        for (uint32_t nib = 0; nib < 16u; ++nib) {
+            uint32_t F = 0, G = 0;
+            for (uint32_t s = 0; s <= SC; ++s) {
+                uint32_t st = s, starts = 0;
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    if (st == 0u) starts |= 1u << i;                                   // a code starts at this bit
+                    const bool rem = st >= 1u && st <= k;                              // a remainder bit: count it down
+                    st = rem ? st - 1u : (((nib >> (3u - i)) & 1u) ? k : SC);          // a one ends the run, a zero continues it
+                }
+                F |= (5u * st) << (5u * s);
+                G |= starts << (5u * s);
             }
-            r.w[k][e >> 2] |= ((st << 4) | starts) << (8u * (e & 3u));
+            r.w[k][2u * nib] = F; r.w[k][2u * nib + 1u] = G;
         }
     }
     return r;
@@ -202,8 +207,8 @@ __device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint3
 // Returns the bit position after the last code; *err != 0 on EOF.  Wave-uniform control flow.
 //
 // Per span of 64 lanes x B bits: (1) every lane finds the state in which its chunk is left for every state it may be
-// entered in -- four bits per step through the transition table in LDS for short codes (k <= CLX_LUT_KMAX), a walk of
-// shift / count-leading-zeros / add per code for longer ones; (2) every lane's true entry state: chunks whose exit does
+// entered in -- four bits per step, all states at once, through the transition table in LDS for short codes
+// (k <= CLX_LUT_KMAX), a walk of shift / count-leading-zeros / add per code for longer ones; (2) every lane's true entry state: chunks whose exit does
 // not depend on their entry hand it to their successor directly, the rest follow by DPP wave shifts (table path), or a
 // three-level walk over the 64 chunks' exit tables in LDS (8 groups of 8; long codes); (3) lanes mark the codes that
 // *start* in their chunk, a wave prefix sum gives output indices; (4) the start positions are listed in LDS: a code
@@ -212,17 +217,18 @@ __device__ __forceinline__ uint32_t clx_chunk_exit(uint32_t c, uint32_t B, uint3
 __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32_t k, uint32_t count,
                                        int32_t* dst, uint32_t limit, uint32_t* err, uint32_t& lut_k, int lane CLX_TL_PH_PARAM) {
     // the cursor and the partition's shape are the same in every lane: keep them (and all that follows from them: chunk
-    // width, window tests, loop control) on the scalar unit -- this kernel is bound by VALU issue slots
+    // width, window tests, loop control) on the scalar unit
     pos = clx_uniform(pos); k = clx_uniform(k); count = clx_uniform(count); limit = clx_uniform(limit);
     const uint32_t SC = k + 1u, ns = k + 2u;
     CLX_TL_PHASE(5);                       // everything outside the residual decode: headers, warm-up, descriptors
     // Transition table of the code's bit automaton, four bits at a time: a state m in [1,k] just counts a remainder
     // bit down; at a code start (0) or inside a run (SC) a one ends the run and leaves k remainder bits, a zero
-    // continues it.  With it the exit state of a chunk for one entry state is B/4 dependent LDS look-ups instead of a
-    // walk of shift / count-leading-zeros / add steps per code -- this kernel is bound by VALU issue slots.
+    // continues it.  A table row holds what a nibble does to EVERY state (K1Lds::lut), so the exit states of a chunk for all
+    // entry states are B/4 row fetches that depend on nothing but the chunk, and one v_bfe_u32 per state and step -- instead
+    // of a walk of shift / count-leading-zeros / add steps per code and state.
     const bool use_lut = k <= CLX_LUT_KMAX;                  // wave-uniform.  Longer codes: few per chunk, the walks are short
     if (use_lut && lut_k != k) {
-        if ((uint32_t)lane < 4u * ns) reinterpret_cast<uint32_t*>(L.lut)[lane] = clx_lut_rom.w[k][lane];
+        if (lane < 32) reinterpret_cast<uint32_t*>(L.lut)[lane] = clx_lut_rom.w[k][lane];
         lut_k = k;
         __syncthreads();
     }
@@ -254,79 +260,42 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         // (1) exit-state tables
         const bool sent = B < 32u;                           // wave-uniform
         const uint32_t cs = sent ? (c | (0x80000000u >> B)) : c;
-        uint32_t my_entry;
-#ifdef CLX_K1_PROP_CAP
-        bool need_walk_any = false;
-#endif
+        uint32_t my_entry;                                   // (table path: times five)
         if (use_lut) {
-            const uint32_t nb = B >> 2;
-            // The chunk's exit states stay in a register, a nibble per entry state, as the difference from state 0's
-            // exit: nibbles of states that are not walked (SC, unused) then read as state 0's.
-            static_assert(CLX_LUT_KMAX <= 6u, "the exit states of a chunk are kept in one register: eight nibbles");
-            uint32_t xlo = 0, pat = 0, differs = 0;
-            for (uint32_t g = 0; 4u * g <= k; ++g) {
-                // four entry states at a time, each held as a table entry (state in the high nibble).  The last group may
-                // reach past state k: those rows hold stale but valid entries, their results are masked off below.
-                uint32_t s0 = (4u * g) << 4, s1 = s0 + 16u, s2 = s0 + 32u, s3 = s0 + 48u;
-#pragma unroll 1
-                for (uint32_t j = 0; j < nb; ++j) {
-                    const uint32_t nib = (c >> (28u - 4u * j)) & 15u;
-                    s0 = L.lut[(s0 & 0xf0u) | nib];
-                    s1 = L.lut[(s1 & 0xf0u) | nib];
-                    s2 = L.lut[(s2 & 0xf0u) | nib];
-                    s3 = L.lut[(s3 & 0xf0u) | nib];
-                }
-                if (g == 0u) { pat = (s0 >> 4) * 0x11111111u; xlo = pat; }
-                // the four exit states, squeezed from the high nibbles of four bytes into four adjacent nibbles
-                uint32_t q = ((s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) >> 4) & 0x0f0f0f0fu;
-                q = (q | (q >> 4)) & 0x00ff00ffu;
-                q = (q | (q >> 8)) & 0xffffu;
-                const uint32_t nvalid = k + 1u - 4u * g;                                    // states 4g .. k (wave-uniform)
-                const uint32_t vmask = nvalid >= 4u ? 0xffffu : (0xffffu >> (16u - 4u * nvalid));
-                const uint32_t d = ((q ^ pat) & vmask) << (16u * g);                        // nibble of state 4g
-                xlo ^= d;
-                differs |= d;
-            }
+            // Five walks at once, one per entry state 0 .. 4 (states are carried times five, see K1Lds::lut): a step is the table
+            // row of the next nibble and one v_bfe_u32 per walk.  States above k + 1 do not exist: their walks run through zero
+            // fields and are never looked at.  The steps are unrolled -- this kernel is bound by the number of instructions its
+            // waves issue, scalar loop control included (measured: eight extra s_add per step cost more than eight extra v_add).
+            uint32_t e0 = 0u, e1 = 5u, e2 = 10u, e3 = 15u, e4 = 20u;
+#define CLX_K1_STEP5(i) { const uint32_t F = L.lut[(c >> (28u - 4u * (i))) & 15u].f; \
+                          e0 = clx_bfe(F, e0, 5u); e1 = clx_bfe(F, e1, 5u); e2 = clx_bfe(F, e2, 5u); e3 = clx_bfe(F, e3, 5u); e4 = clx_bfe(F, e4, 5u); }
+            const uint32_t nb = B >> 2;                      // 1 .. 8 (wave-uniform): straight-line steps, a scalar test in front of each
+            CLX_K1_STEP5(0)
+            if (nb > 1u) { CLX_K1_STEP5(1)
+            if (nb > 2u) { CLX_K1_STEP5(2)
+            if (nb > 3u) { CLX_K1_STEP5(3)
+            if (nb > 4u) { CLX_K1_STEP5(4)
+            if (nb > 5u) { CLX_K1_STEP5(5)
+            if (nb > 6u) { CLX_K1_STEP5(6)
+            if (nb > 7u) { CLX_K1_STEP5(7) } } } } } } }
+#undef CLX_K1_STEP5
+            // the chunk's exit states in one register, field s5 = exit for entry state s (the field of SC = k + 1 holds state 0's:
+            // entering inside a run walks exactly like entering at a code start -- its own walk said so for k <= 3, for k = 4 it
+            // is put there)
+            const uint32_t X = (e0 * 0x02000001u) | (e1 << 5) | (e2 << 10) | (e3 << 15) | (e4 << 20);
             CLX_TL_PHASE(1);               // exit tables
             // (2) entry states.  Rice codes resynchronise within a few codes, so for most chunks every entry state leads to
             // the same exit state: such a chunk tells its successor where it starts without knowing its own entry state.
             // What is known is handed to the next lane (DPP wave shift) until every lane knows its entry state: one round
             // plus one per chunk of the longest run of chunks whose exit does depend on their entry -- no LDS traffic.
+            const uint32_t fields = 0xffffffffu >> (22u - 5u * k);                   // the fields of states 0 .. k + 1 (wave-uniform)
+            const bool same = (X & fields) == e0 * (0x02108421u & fields);
             uint32_t ent = (lane == 0) ? 0u : 0xffu;         // a span always begins at a code start; 0xff: not known yet
-            uint32_t outv = (differs == 0u) ? (pat & 15u) : 0xffu;
+            uint32_t outv = same ? e0 : 0xffu;
             CLX_STAT(56, lane == 0);                         // (simulator statistics: spans on the table path, rounds below)
-#ifdef CLX_K1_PROP_CAP
-            // Experiment (not in the default build): at most CLX_K1_PROP_CAP rounds -- none for
-            // k >= CLX_K1_WALK_FROM --, then the exit states go to LDS and the three-level walk below resolves the entries.
-#ifndef CLX_K1_WALK_FROM
-#define CLX_K1_WALK_FROM 99u
-#endif
-            const uint32_t cap = k >= CLX_K1_WALK_FROM ? 0u : (uint32_t)(CLX_K1_PROP_CAP);
-            bool need_walk = cap == 0u;
-            for (uint32_t round = 0; !need_walk; ++round) {
-                CLX_STAT(57, lane == 0);
-                const uint32_t cand = (xlo >> ((ent & 7u) << 2)) & 15u;
-                if (outv == 0xffu && ent != 0xffu) outv = cand;
-                const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)outv, 0x138, 0xF, 0xF, true);   // wave_shr:1
-                if (ent == 0xffu) ent = pv;
-                if (__all(ent != 0xffu)) break;
-                if (round + 1u >= cap) need_walk = true;
-            }
-            my_entry = ent;
-            need_walk_any = need_walk;
-            if (need_walk) {                                 // a byte per entry state, as the arithmetic walks leave them
-                CLX_STAT(59, lane == 0);
-                uint32_t lo4 = xlo & 0xffffu, hi4 = xlo >> 16;
-                lo4 = (lo4 | (lo4 << 8)) & 0x00ff00ffu; lo4 = (lo4 | (lo4 << 4)) & 0x0f0f0f0fu;
-                hi4 = (hi4 | (hi4 << 8)) & 0x00ff00ffu; hi4 = (hi4 | (hi4 << 4)) & 0x0f0f0f0fu;
-                *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][0]) = lo4;
-                *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4]) = hi4;
-            }
-        } else {
-#else
             for (;;) {
                 CLX_STAT(57, lane == 0);
-                const uint32_t cand = (xlo >> ((ent & 7u) << 2)) & 15u;
+                const uint32_t cand = clx_bfe(X, ent, 5u);   // (offset taken mod 32: garbage while ent is unknown, not used then)
                 if (outv == 0xffu && ent != 0xffu) outv = cand;
                 const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)outv, 0x138, 0xF, 0xF, true);   // wave_shr:1
                 if (ent == 0xffu) ent = pv;                  // (lane 0 never takes this)
@@ -334,7 +303,6 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             }
             my_entry = ent;
         } else {
-#endif
         CLX_STAT(58, lane == 0);                             // spans on the arithmetic-walk path
         const uint32_t ex0 = sent ? clx_chunk_exit<true>(cs, B, k, 0u) : clx_chunk_exit<false>(c, B, k, 0u);
         for (uint32_t g = 0; 4u * g < ns; ++g) {
@@ -349,10 +317,6 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
             }
             *reinterpret_cast<uint32_t*>(&L.u.t.tab[lane][4u * g]) = packed;     // states 4g .. 4g+3 (little endian)
         }
-#ifdef CLX_K1_PROP_CAP
-        }
-        if (!use_lut || need_walk_any) {
-#endif
         __syncthreads();
         CLX_TL_PHASE(1);                   // exit tables
         // (2a) group tables: lane (g8, e) walks group g8's 8 chunks for entry states e, e+8, ...
@@ -387,12 +351,19 @@ __device__ uint32_t clx_rice_partition(K1Lds& L, BitSrc& b, uint32_t pos, uint32
         uint32_t S = 0;
         if (use_lut) {
             // the same table, walked once from the true entry state: every step hands over the four start flags of its bits
-            uint32_t v = my_entry << 4;
-#pragma unroll 1
-            for (uint32_t j = 0; j < (B >> 2); ++j) {
-                v = L.lut[(v & 0xf0u) | ((c >> (28u - 4u * j)) & 15u)];
-                S = clx_alignbit(v, S, 4u);                  // (S >> 4) | (flags << 28)
-            }
+            uint32_t st = my_entry;
+#define CLX_K1_STEP1(i) { const K1Lds::Row row = L.lut[(c >> (28u - 4u * (i))) & 15u]; \
+                          S = clx_alignbit(row.g >> st, S, 4u); st = clx_bfe(row.f, st, 5u); }     // S = (S >> 4) | (flags << 28)
+            const uint32_t nb = B >> 2;
+            CLX_K1_STEP1(0)
+            if (nb > 1u) { CLX_K1_STEP1(1)
+            if (nb > 2u) { CLX_K1_STEP1(2)
+            if (nb > 3u) { CLX_K1_STEP1(3)
+            if (nb > 4u) { CLX_K1_STEP1(4)
+            if (nb > 5u) { CLX_K1_STEP1(5)
+            if (nb > 6u) { CLX_K1_STEP1(6)
+            if (nb > 7u) { CLX_K1_STEP1(7) } } } } } } }
+#undef CLX_K1_STEP1
             S >>= (32u - B) & 31u;
         } else {
             uint32_t p = (my_entry == SC) ? 0u : my_entry;
@@ -531,7 +502,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
     h.pos = o + 8u * (uint32_t)fr.header_bytes;
     h.err = CLX_ERR_NONE;
     if (h.pos > h.limit) h.err = CLX_MKERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
-    reinterpret_cast<uint32_t*>(L.lut)[lane] = 0u;                     // every byte of the table is a valid state from the start
+    if (lane < 32) reinterpret_cast<uint32_t*>(L.lut)[lane] = 0u;
     uint32_t lut_k = 0xffffffffu;                                      // the Rice parameter the table is built for: none yet
     clx_window_load(L, b, h.pos < h.limit ? h.pos : o, lane);
 

@@ -97,6 +97,31 @@ def test_baseline_configs_default_selection(oracle, ctx, make, expect, forbid):
     run_and_compare(oracle, ctx, make(), 0, expect, forbid=forbid)
 
 
+def test_pipelined_submissions_keep_the_wave_kernels_for_longer(oracle, ctx):
+    """12 288 config-5 frames with flags 0: one run at a time takes the lane kernels (test above), pipelined submissions the
+    wave kernels (clx_select_path, `pipelined`) -- and a run between submissions the lane kernels again, on the same batch.
+    All of it against the oracle."""
+    import torch
+    w = synth.config5_unique(12288)
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(3)]
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True)
+    torch.cuda.synchronize()
+    batch.submit(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    batch.submit(d_arena.data_ptr(), w.arena_len, outs[1].data_ptr())
+    batch.run(d_arena.data_ptr(), w.arena_len, outs[2].data_ptr())
+    batch.submit(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    res = batch.results()
+    batch.close()
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.array_equal(res["status"], r["statuses"]) and np.all(res["status"] == cx.OK)
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), ref)
+
+
 def test_device_indexer_against_oracle_offsets(oracle, ctx):
     """clx_index_frames_device against the frame starts the ORACLE's reader walks through (oracle.decode_stream), not
     against the product's own host indexer: a 3 MB raw stream of mixed frames, with and without a garbage tail."""

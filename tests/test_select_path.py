@@ -8,11 +8,15 @@ import simlib
 BS = 4096
 
 
-def choose(frames, channels, bits_per_sample, wide=False):
+ARGTYPES = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
+
+
+def choose(frames, channels, bits_per_sample, wide=False, pipelined=False):
     L = simlib.lib()
-    L.sim_select_path.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    L.sim_select_path.argtypes = ARGTYPES
     samples = frames * channels * BS
-    r = L.sim_select_path(frames * channels, samples, int(samples * bits_per_sample / 8), 1 if wide else 0, 1 if channels == 1 else 0)
+    r = L.sim_select_path(frames * channels, samples, int(samples * bits_per_sample / 8), 1 if wide else 0, 1 if channels == 1 else 0,
+                          1 if pipelined else 0)
     return ("lanes" if r & 1 else "waves"), ("split" if r & 2 else "fused")
 
 
@@ -29,8 +33,25 @@ def test_selection_follows_the_measurements():
     assert choose(32000, 2, 9.5) == ("lanes", "fused")                # 1.567 against 1.951
 
 
+def test_selection_with_several_batches_in_flight():
+    """clx_batch_submit (profiles/r02_bench_configs_sweep_c.txt, columns `sub`): whole runs of the wave kernels overlap their
+    neighbours, so they stay the choice for longer than with one run at a time."""
+    p = dict(pipelined=True)
+    assert choose(24000, 1, 5.67, **p)[0] == "waves"                  # config 2: 0.349 (waves) against 0.456 ms
+    assert choose(32000, 1, 5.67, **p)[0] == "lanes"                  # 0.486 against 0.457
+    assert choose(24000, 2, 5.03, **p)[0] == "waves"                  # config 3: 0.737 against 0.933
+    assert choose(32000, 2, 5.03, **p) == ("lanes", "fused")          # 1.023 against 0.987
+    assert choose(8000, 2, 9.8, wide=True, **p)[0] == "waves"         # config 4: 1.094 against 1.287
+    assert choose(16000, 2, 9.8, wide=True, **p) == ("lanes", "split")  # 1.856 against 1.308
+    assert choose(10000, 2, 9.5, **p)[0] == "waves"                   # config 5: 0.823 against 1.135
+    assert choose(16000, 2, 9.5, **p)[0] == "lanes"                   # 1.216 against 1.178
+    for shape in ((10000, 1, 5.67), (10000, 2, 5.03), (32000, 2, 5.03), (2000, 2, 9.8, True), (8000, 2, 9.5), (32000, 2, 9.5)):
+        if choose(*shape, pipelined=True)[0] == "lanes":              # never the lane kernels where one run at a time takes the wave kernels
+            assert choose(*shape)[0] == "lanes"
+
+
 def test_unknown_frame_lengths_take_the_middle():
     L = simlib.lib()
-    L.sim_select_path.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
-    assert L.sim_select_path(20000, 20000 * BS, 0, 0, 0) & 1 == 0     # bytes unknown: 7.5 bits per sample assumed -> 36 000 subframes
-    assert L.sim_select_path(40000, 40000 * BS, 0, 0, 0) & 1 == 1
+    L.sim_select_path.argtypes = ARGTYPES
+    assert L.sim_select_path(20000, 20000 * BS, 0, 0, 0, 0) & 1 == 0  # bytes unknown: 7.5 bits per sample assumed -> 36 000 subframes
+    assert L.sim_select_path(40000, 40000 * BS, 0, 0, 0, 0) & 1 == 1

@@ -57,8 +57,8 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
 }
 
 // the library's kernel selection rule (clx_plan.h), for tests/test_select_path.py: returns lanes | lanes_split << 1
-extern "C" int sim_select_path(uint64_t slots, uint64_t samples, uint64_t bytes, int heavy, int all_mono) {
-    const clx_path_choice c = clx_select_path(slots, samples, bytes, heavy != 0, all_mono != 0);
+extern "C" int sim_select_path(uint64_t slots, uint64_t samples, uint64_t bytes, int heavy, int all_mono, int pipelined) {
+    const clx_path_choice c = clx_select_path(slots, samples, bytes, heavy != 0, all_mono != 0, pipelined != 0);
     return (c.lanes ? 1 : 0) | (c.lanes_split ? 2 : 0);
 }
 
