@@ -974,7 +974,9 @@ __device__ __forceinline__ void clx_predict_unaligned(const K2Slot& S, int32_t* 
 // last one a DMA (every turn, also the first two, whose stores go to the dump area): DMA(i+2), issued in turn
 // i+4-DEPTH, is followed by 8*(DEPTH-4) younger operations when turn i ends.
 
+#ifndef CLX_K2_DEPTH
 #define CLX_K2_DEPTH 12       // tiles in a group's ring (see clx_load_wave for what it has to cover)
+#endif
 
 // what a lane needs to move "its" 16 bytes of every tile: instruction k moves rows 16k .. 16k+15, 4 lanes per row
 struct K2Mover {
