@@ -84,7 +84,7 @@ assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
 
 EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
-    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_frames_multi", "clx_decode_frames_stream", "clx_host_alloc", "clx_host_free", "clx_decode_subframes", "clx_interleave",
+    "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_frames_multi", "clx_decode_frames_stream", "clx_set_stream_chunk", "clx_host_alloc", "clx_host_free", "clx_decode_subframes", "clx_interleave",
     "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
     "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
@@ -153,6 +153,8 @@ def lib():
     L.clx_host_alloc.restype = vp
     L.clx_host_alloc.argtypes = [sz]
     L.clx_host_free.argtypes = [vp]
+    L.clx_set_stream_chunk.argtypes = [vp, sz]
+    L.clx_set_stream_chunk.restype = None
     L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_submit.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_flush.argtypes = [vp, vp]
@@ -503,6 +505,10 @@ class Context:
                                      _np_ptr(res), (VERIFY_CRC16 if verify_crc else 0) | path)
         self._check(st)
         return out, res
+
+    def set_stream_chunk(self, frames_per_chunk):
+        """Frames per chunk of decode_frames_stream (0: the library's rule: a third of the batch, 256 .. 8192)."""
+        lib().clx_set_stream_chunk(self._h, int(frames_per_chunk))
 
     def decode_frames_stream(self, arena, descs, out_offs, out=None, sample_bytes=0, verify_crc=False, path=0, copy_back=True):
         """clx_decode_frames_stream: host-to-host decode, chunks pipelined (upload | decode | download).  sample_bytes 0: planar

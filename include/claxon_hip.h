@@ -229,6 +229,9 @@ int clx_decode_frames_multi(clx_ctx* const* ctxs, size_t n_ctx, const uint8_t* a
 int   clx_decode_frames_stream(clx_ctx* ctx, const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
                                void* out, uint32_t sample_bytes, const uint64_t* out_sample_offsets,
                                clx_frame_result* results, uint32_t flags);
+/* Frames per chunk of clx_decode_frames_stream on this context; 0 (the default) = a third of the batch, 256 .. 8192: a chunk's
+ * decode lasts at least as long as the predictor kernel's serial chain, so few large chunks beat many small ones. */
+void  clx_set_stream_chunk(clx_ctx* ctx, size_t frames_per_chunk);
 void* clx_host_alloc(size_t bytes);      /* pinned host memory (hipHostMalloc); NULL on failure */
 void  clx_host_free(void* p);
 

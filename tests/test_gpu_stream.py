@@ -40,6 +40,7 @@ def test_stream_decode_matches_oracle(oracle):
     pin_in.array[:] = arena
     for pinned in (False, True):
         src = pin_in.array if pinned else arena
+        ctx.set_stream_chunk(0 if pinned else 250)      # the default (three chunks) / eight chunks: every slot is reused inside a call
         for rep in range(2):
             out, res = ctx.decode_frames_stream(src[:w.arena_len], descs, w.out_offs, verify_crc=True)
             assert np.array_equal(res["status"], r["statuses"]) and np.array_equal(res["msg"], r["msgs"])
