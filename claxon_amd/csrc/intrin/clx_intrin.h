@@ -20,16 +20,10 @@ __device__ __forceinline__ int32_t clx_mad24(int32_t a, int32_t b, int32_t c) {
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
-__device__ __forceinline__ int32_t clx_max3(int32_t a, int32_t b, int32_t c) {
-    int32_t d;
-    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ int32_t clx_min3(int32_t a, int32_t b, int32_t c) {
-    int32_t d;
-    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// v_max3_i32 / v_min3_i32: plain C++ that the compiler folds into the three-operand forms (an asm statement each would make it
+// pad the boundaries between dependent statements with s_nop)
+__device__ __forceinline__ int32_t clx_max3(int32_t a, int32_t b, int32_t c) { const int32_t m = a > b ? a : b; return m > c ? m : c; }
+__device__ __forceinline__ int32_t clx_min3(int32_t a, int32_t b, int32_t c) { const int32_t m = a < b ? a : b; return m < c ? m : c; }
 // Dot product of N 24-bit factors pairs as ONE asm statement: acc = sum_j c[j]*h[j], evaluated oldest tap (j = N-1) first
 // so that the newest sample h[0] is needed last.  One statement per chain because hipcc pads every boundary between
 // dependent asm statements with an s_nop (it cannot see what the instruction inside is): a mad per statement costs a
