@@ -269,8 +269,8 @@ struct clx_batch {
     hipStream_t last_stream = nullptr;
     size_t planned_arena_len = 0;
     // Pipelined submissions (clx_batch_submit): up to kDepth submissions in flight, each a whole run (Rice stage, predictor stage,
-    // CRC) on a stream of its own with its own descriptors and results -- the Rice stage of one fills the machine while the
-    // serial chains of another's predictor stage and the tail of a third's Rice stage (its last, partly filled round of waves) run.
+    // CRC) on a stream of its own with its own descriptors and results -- the Rice stages of two submissions share the machine
+    // (neither ends in a partly filled round of waves) and their predictor stages, serial chains, run side by side.
     enum { kDepth = CLX_SUBMIT_DEPTH };
     struct Flight {
         hipStream_t stream = nullptr;

@@ -258,9 +258,9 @@ int  clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
 int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                    int32_t* d_out, void* stream);
 /* Pipelined submission: the same work and the same results as clx_batch_run, with up to CLX_SUBMIT_DEPTH submissions in
- * flight -- each a whole run on an internal stream of its own, so that the Rice stage of one runs beside the predictor stage
- * and the draining Rice stage of others (the reference has no counterpart: one FrameReader decodes one frame at a time,
- * frame.rs:667).  A submission starts after everything queued on `stream` so far.  Give the submissions in flight different
+ * flight -- each a whole run on an internal stream of its own, so that the Rice stages of two submissions share the machine
+ * (neither ends in a half-empty round of waves) and their predictor stages, serial chains on a fraction of the SIMDs, run side by
+ * side (the reference has no counterpart: one FrameReader decodes one frame at a time, frame.rs:667).  A submission starts after everything queued on `stream` so far.  Give the submissions in flight different
  * `d_out` buffers, i.e. rotate over CLX_SUBMIT_DEPTH of them (re-using a buffer is legal: the submission then waits for the
  * earlier one that writes it).  Work enqueued on `stream` after clx_batch_flush sees every submission finished;
  * clx_batch_results flushes by itself and returns the LAST submission's results.  Falls back to clx_batch_run for the kernel
