@@ -25,6 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The library keeps several submissions in flight on internal streams (clx_batch_submit); a hardware queue per stream lets their
+# kernels overlap as intended.  HIP's default is 4 queues for the whole process, which the internal streams then share in pairs
+# (0.33 instead of 0.30 ms per step).  Has to be in the environment before the HIP runtime starts; carried in the JSON line.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -157,7 +161,7 @@ def main():
     # ---- per-kernel durations: HIP events recorded by the library on the launch stream, around each of its kernels (steps one at
     #      a time); they also say which kernels the library selected -- only the wave path with the latency build of the predictor keeps several steps in flight
     kernel_ms = _kernel_ms(torch, batch, lambda: batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
-    pipelined = pipelined and "clx_k_predict" in kernel_ms
+    pipelined = pipelined and "clx_k_predict16" in kernel_ms
 
     elapsed = timed(batch, args.steps, pipelined)
     # whole-job figures: MAX elapsed over ranks, SUM of samples per step, SUM of failed frames (must be 0)
@@ -211,7 +215,7 @@ def main():
            "compressed_bytes_this_rank": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
            "parallelism": "one frame index sharded over %d GPU(s), no collective on the data path" % world, "shard": shard_info,
            "bit_exact": True, "crc16_in_step": False, "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
-           "steps_in_flight": depth if pipelined else 1}
+           "steps_in_flight": depth if pipelined else 1, "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
     out = {
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,8 +231,7 @@ def main():
         cfg["one_step_at_a_time"] = {"value": round(samples_1 / (ms_1 * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_1, 4),
                                      "frac": round(alg_bytes / (ms_1 * 1e-3) / 1e9 / PEAK_GBS, 4),
                                      "note": "clx_batch_run: a batch's latency; `value` is the throughput of consecutive batches with up to %d in flight" % depth}
-    if extras and world == 1 and args.workload == "config3" and 8 * 4 * w.total_samples < 16 * (1 << 30):
-        cfg["deep_queue"] = _deep_queue(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
+    batch.close()                              # (its internal streams give their hardware queues back)
     if not w.bare_subframes and not args.no_extras:
         # ---- the same step with every frame's CRC-16 verified on the device (frame.rs:752-763: the reference always does);
         #      this is the figure that corresponds to the cpu_baseline leg, which also verifies
@@ -248,6 +251,8 @@ def main():
             cfg["with_crc16"] = {"value": round(samples_c / (ms_c * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
                                  "kernel_ms": {k: round(v, 4) for k, v in kc.items()},
                                  "note": "CLX_VERIFY_CRC16: every frame's CRC-16 footer checked on the device inside the step"}
+    if extras and world == 1 and args.workload == "config3" and 8 * 4 * w.total_samples < 16 * (1 << 30):
+        cfg["deep_queue"] = _deep_queue(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
     if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
         cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -241,6 +241,7 @@ struct clx_batch {
     int device = 0;
     clx_path_choice choice = { false, true };          // for one run at a time (clx_batch_run)
     clx_path_choice choice_submit = { false, true };   // for pipelined submissions (clx_batch_submit)
+    bool all_narrow_aligned = false;                   // every frame: bps <= 16, rows 16-byte aligned and a multiple of 4 samples long
     clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
     size_t cap[9] = {};              // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits
     size_t n = 0;
@@ -261,7 +262,7 @@ struct clx_batch {
     uint32_t* d_errkey = nullptr;
     uint64_t* d_endbits = nullptr;
     bool profiling = false;
-    enum { kMaxKernels = 6 };
+    enum { kMaxKernels = 8 };
     hipEvent_t ev[kMaxKernels + 1] = {};
     const char* kname[kMaxKernels] = {};
     int n_kernels = 0;
@@ -277,13 +278,13 @@ struct clx_batch {
         clx_sf_desc* d_sfd = nullptr;            // flight 0 uses the batch's own d_sfd / d_results
         clx_frame_result* d_results = nullptr;
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
-        hipEvent_t ev_rice = nullptr, ev_crc = nullptr;   // with CLX_VERIFY_CRC16: the CRC kernel runs on crc_stream beside the predictor stage
-        bool crc_pending = false, crc_recorded = false;
+        hipEvent_t ev_rice = nullptr, ev_side = nullptr;   // Rice stage done | the submission's kernels on side_stream done
+        bool side_pending = false, side_recorded = false;
         bool pending = false;                    // submitted, nobody has been made to wait for it yet
         bool sfd_stale = true;                   // d_sfd holds something other than a previous run's descriptors
         const int32_t* out = nullptr;            // where the pending submission writes
     } flight[kDepth];
-    hipStream_t crc_stream = nullptr;
+    hipStream_t side_stream = nullptr;                 // CRC and left-over predictor kernels of the submissions in flight (launch_waves)
     uint64_t n_submitted = 0;
     int last_slot = -1;              // flight of the most recent pipelined submission (-1: the last run was a plain clx_batch_run)
 };
@@ -348,14 +349,14 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_errkey) (void)hipFree(b->d_errkey);
     if (b->d_endbits) (void)hipFree(b->d_endbits);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
-    if (b->crc_stream) { (void)hipStreamSynchronize(b->crc_stream); (void)hipStreamDestroy(b->crc_stream); }
+    if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
     for (int i = 0; i < clx_batch::kDepth; ++i) {
         clx_batch::Flight& F = b->flight[i];
         if (F.stream) { (void)hipStreamSynchronize(F.stream); (void)hipStreamDestroy(F.stream); }
         if (F.ev_in) (void)hipEventDestroy(F.ev_in);
         if (F.ev_done) (void)hipEventDestroy(F.ev_done);
         if (F.ev_rice) (void)hipEventDestroy(F.ev_rice);
-        if (F.ev_crc) (void)hipEventDestroy(F.ev_crc);
+        if (F.ev_side) (void)hipEventDestroy(F.ev_side);
         if (i != 0 && F.d_sfd) (void)hipFree(F.d_sfd);
         if (i != 0 && F.d_results) (void)hipFree(F.d_results);
     }
@@ -391,14 +392,16 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
     if (!b->ev[0]) for (auto& e : b->ev) if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) return CLX_API_ERROR;
     // path: explicit flag, else by the batch's shape and content (clx_select_path, clx_plan.h)
     {
-        uint64_t samples = 0, wide = 0, bytes = 0; bool all_mono = true, lengths_known = true;
+        uint64_t samples = 0, wide = 0, bytes = 0; bool all_mono = true, lengths_known = true, na = true;
         for (size_t i = 0; i < n; ++i) {
             const uint64_t sm = (uint64_t)frames[i].n_channels * frames[i].block_size;
+            na = na && frames[i].bps <= 16 && (frames[i].block_size & 3u) == 0u && (out_sample_offsets[i] & 3ull) == 0ull;
             samples += sm;
             if (frames[i].bps > 16) wide += sm;
             if (frames[i].max_bytes >= (1u << 24)) lengths_known = false; else bytes += frames[i].max_bytes;
             all_mono = all_mono && frames[i].n_channels == 1;
         }
+        b->all_narrow_aligned = na;
         b->choice = clx_select_path(slot, samples, lengths_known ? bytes : 0, 4 * wide >= samples && samples != 0, all_mono);
         b->choice_submit = clx_select_path(slot, samples, lengths_known ? bytes : 0, 4 * wide >= samples && samples != 0, all_mono, true);
     }
@@ -423,7 +426,7 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
         clx_batch::Flight& F = b->flight[i];
         if (i != 0 && F.d_sfd) (void)hipFree(F.d_sfd);
         if (i != 0 && F.d_results) (void)hipFree(F.d_results);
-        F.d_sfd = nullptr; F.d_results = nullptr; F.pending = false; F.crc_pending = false; F.sfd_stale = true; F.out = nullptr;   // (crc_recorded stays: the event is still there)
+        F.d_sfd = nullptr; F.d_results = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.out = nullptr;   // (side_recorded stays: the event is still there)
     }
     b->last_slot = -1;
     b->planned_arena_len = (size_t)-1;
@@ -500,39 +503,55 @@ bool k2_latency_build(const clx_batch* b) {
     const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
     return (b->flags & CLX_K2_LATENCY) ? true : (b->flags & CLX_K2_THROUGHPUT) ? false : groups <= CLX_K2_LATENCY_GROUPS;
 }
-// `crc_beside` (pipelined submissions): the CRC kernel needs the Rice stage's end bits only -- it goes to `crc_stream` behind
-// `ev_rice` and runs beside the predictor stage; `ev_crc` says when it is done
+// `side` (pipelined submissions): a second stream for what needs the Rice stage's output only and is small -- the CRC kernel
+// (the end bits) and the predictor kernels for the groups clx_k_predict16 leaves (usually none: the kernels find nothing to do,
+// and in the submission's own stream each of them would still hold up what is queued behind it).  They start behind `ev_rice`
+// and run beside the predictor stage; `ev_side` says when they are done.
 template <typename Mark>
 bool launch_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
-                  hipStream_t stream, Mark&& mark, bool k2_latency, hipStream_t crc_stream = nullptr, hipEvent_t ev_rice = nullptr,
-                  hipEvent_t ev_crc = nullptr) {
+                  hipStream_t stream, Mark&& mark, bool k2_latency, hipStream_t side = nullptr, hipEvent_t ev_rice = nullptr,
+                  hipEvent_t ev_side = nullptr) {
     if (!mark("clx_k_residual")) return false;
     launch_stage1_waves(b, d_arena, alloc_len, d_out, d_sfd, d_results, stream);
-    const bool crc_beside = crc_stream != nullptr && (b->flags & CLX_VERIFY_CRC16);
-    if (crc_beside) {
-        if (hipEventRecord(ev_rice, stream) != hipSuccess || hipStreamWaitEvent(crc_stream, ev_rice, 0) != hipSuccess) return false;
-        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, crc_stream, d_arena,
-                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_results);
-        if (hipEventRecord(ev_crc, crc_stream) != hipSuccess) return false;
+    hipStream_t rest = stream;                     // where the CRC kernel and the left-over predictor kernels go
+    if (side != nullptr) {
+        if (hipEventRecord(ev_rice, stream) != hipSuccess || hipStreamWaitEvent(side, ev_rice, 0) != hipSuccess) return false;
+        rest = side;
     }
     const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
     if (k2_latency) {
-        if (!mark("clx_k_predict")) return false;
-        hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, stream, d_out,
+        // The groups of 64 rows that are all aligned, of 16-bit audio and of at most 8 taps go to clx_k_predict16: workgroups of
+        // four waves with half the registers and a quarter of the LDS of the general kernel's, so that the predictor stages of
+        // several submissions in flight are resident side by side.  The rest go to the general kernel -- unless the plan says
+        // that only a predictor order above 8 can put a group there (every frame 16-bit and aligned): then to the one-wave
+        // kernels, whose workgroups find room on a busy machine at once.
+        if (!mark("clx_k_predict16")) return false;
+        hipLaunchKernelGGL(clx_k_predict16, dim3(groups), dim3(256), 0, stream, d_out,
                            (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
+        if (b->all_narrow_aligned) {
+            if (!mark("clx_k_predict_1w")) return false;
+            hipLaunchKernelGGL(clx_k_predict_1w, dim3(groups), dim3(64), 0, rest, d_out, (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump, 1u);
+            if (!mark("clx_k_predict_1w_hi")) return false;
+            hipLaunchKernelGGL(clx_k_predict_1w_hi, dim3(groups), dim3(64), 0, rest, d_out, (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump, 1u);
+        } else {
+            if (!mark("clx_k_predict")) return false;
+            hipLaunchKernelGGL(clx_k_predict, dim3((groups + 1) / 2), dim3(512), 0, rest, d_out,
+                               (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
+        }
     } else {
         if (!mark("clx_k_predict_1w")) return false;
         hipLaunchKernelGGL(clx_k_predict_1w, dim3(groups), dim3(64), 0, stream, d_out,
-                           (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
+                           (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump, 0u);
         if (!mark("clx_k_predict_1w_hi")) return false;                     // groups with a predictor order above 12
         hipLaunchKernelGGL(clx_k_predict_1w_hi, dim3(groups), dim3(64), 0, stream, d_out,
-                           (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump);
+                           (const clx_sf_desc*)d_sfd, (uint32_t)b->n_slots, b->d_dump, 0u);
     }
-    if ((b->flags & CLX_VERIFY_CRC16) && !crc_beside) {
+    if (b->flags & CLX_VERIFY_CRC16) {
         if (!mark("clx_k_crc16")) return false;
-        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena,
+        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, rest, d_arena,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_results);
     }
+    if (side != nullptr && hipEventRecord(ev_side, side) != hipSuccess) return false;
     return true;
 }
 // make `stream` wait for every pipelined submission that nobody has waited for yet
@@ -540,8 +559,8 @@ int wait_flights(clx_batch* b, hipStream_t stream) {
     for (auto& F : b->flight)
         if (F.pending) {
             HIP_TRY(b->ctx, hipStreamWaitEvent(stream, F.ev_done, 0));
-            if (F.crc_pending) HIP_TRY(b->ctx, hipStreamWaitEvent(stream, F.ev_crc, 0));
-            F.pending = false; F.crc_pending = false;
+            if (F.side_pending) HIP_TRY(b->ctx, hipStreamWaitEvent(stream, F.ev_side, 0));
+            F.pending = false; F.side_pending = false;
         }
     return CLX_OK;
 }
@@ -616,9 +635,11 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
 // Pipelined submission (wave path): the same work as clx_batch_run, on one of kDepth internal streams in rotation, so that up to
 // kDepth submissions are in flight.  One run alone leaves the machine half idle twice: the Rice stage's last round of waves (10 000
 // one-wave workgroups on 8 192 wave slots) runs at a fraction of the occupancy it needs, and the predictor stage is one serial
-// chain per subframe on a fraction of the SIMDs.  Runs side by side fill both.  (Measured, 10 000 config-3 frames: one at a time
-// 0.41 ms per step; the earlier two-stage form -- predictor stage of submission i on a second stream beside the Rice stage of
-// i+1 -- 0.355; three or four whole runs in flight 0.31-0.33.)
+// chain per subframe on a fraction of the SIMDs.  With several submissions in flight the Rice stages share the machine and the
+// predictor stages -- small workgroups (clx_k_predict16) -- are resident side by side; the CRC kernel and the predictor kernels
+// for what clx_k_predict16 leaves go to one more stream (launch_waves).  Measured, 10 000 config-3 frames per step: one at a time
+// 0.40 ms; four in flight 0.30 ms with a hardware queue per stream (GPU_MAX_HW_QUEUES=8 in the environment; HIP's default of
+// 4 makes the internal streams share two: 0.33 ms), CRC-16 included at no extra time.
 // Each flight has its own descriptors and results; the caller keeps the OUTPUTS of submissions in flight apart (one whose d_out
 // is still being written by an earlier one waits for it -- correct, not overlapped).  `stream` is where the caller's inputs come
 // from: the submission starts after everything queued on it so far.  clx_batch_flush makes `stream` wait for everything submitted;
@@ -644,10 +665,9 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_in, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_done, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_rice, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_crc, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_side, hipEventDisableTiming));
     }
-    const bool crc = (b->flags & CLX_VERIFY_CRC16) != 0;
-    if (crc && !b->crc_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->crc_stream, hipStreamNonBlocking));
+    if (!b->side_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
     if (!F.d_sfd) {
         if (slot == 0) { F.d_sfd = b->d_sfd; F.d_results = b->d_results; }
         else {
@@ -666,14 +686,17 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     // (the flight's previous submission is ahead of this one in the same stream) an output buffer that another flight is still
     // writing cannot take new residuals yet
     for (auto& G : b->flight)
-        if (&G != &F && G.pending && G.out == d_out) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, G.ev_done, 0));
+        if (&G != &F && G.pending && G.out == d_out) {
+            HIP_TRY(ctx, hipStreamWaitEvent(F.stream, G.ev_done, 0));
+            if (G.side_pending) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, G.ev_side, 0));      // (its side-stream kernels write there too)
+        }
     if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
-    // (this flight's previous CRC kernel wrote into the results the Rice stage is about to overwrite)
-    if (F.crc_recorded) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_crc, 0));
+    // (this flight's previous side-stream kernels used the descriptors and results the Rice stage is about to overwrite)
+    if (F.side_recorded) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_side, 0));
     if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, [](const char*) { return true; }, true,
-                      crc ? b->crc_stream : nullptr, F.ev_rice, F.ev_crc)) return CLX_API_ERROR;
+                      b->side_stream, F.ev_rice, F.ev_side)) return CLX_API_ERROR;
     HIP_TRY(ctx, hipEventRecord(F.ev_done, F.stream));
-    F.crc_pending = crc; F.crc_recorded = F.crc_recorded || crc;
+    F.side_pending = true; F.side_recorded = true;
     F.pending = true;
     F.out = d_out;
     b->last_slot = slot;

@@ -31,11 +31,12 @@ struct clx_dev_frame {
     uint8_t  flags;          // bit0: bare subframe (no CRC-16 footer)
 };
 
+#define CLX_SF_NARROW 1u
 struct clx_sf_desc {
     uint64_t out_base;       // sample index of this subframe's first sample in `out`
     uint16_t n;              // block size; 0 = empty slot / frame failed before this subframe was parsed
     uint8_t  lim_log2;       // 0..23: K1 proved |s| <= 2^lim_log2 makes 32-bit/24-bit-factor evaluation exact; 0xff: use i64
-    uint8_t  reserved;
+    uint8_t  flags;          // CLX_SF_NARROW: the frame's samples are at most 16 bits wide (the side channel has one more)
     uint8_t  order;          // IIR taps (0: constant/verbatim/fixed-0; fixed 1..4; lpc 1..32)
     uint8_t  shift;          // qlp shift (0 for fixed predictors)
     uint8_t  wasted;         // wasted bits per sample: final left shift (subframe.rs:216-225)
@@ -46,9 +47,9 @@ struct clx_sf_desc {
 #ifdef __cplusplus
 static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
 static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
-// K1 writes the 16 bytes in front of `coef` as one store: {out_base | n, lim_log2, reserved | order, shift, wasted, decor}
+// K1 writes the 16 bytes in front of `coef` as one store: {out_base | n, lim_log2, flags | order, shift, wasted, decor}
 static_assert(offsetof(clx_sf_desc, out_base) == 0 && offsetof(clx_sf_desc, n) == 8 && offsetof(clx_sf_desc, lim_log2) == 10 &&
-              offsetof(clx_sf_desc, reserved) == 11 && offsetof(clx_sf_desc, order) == 12 && offsetof(clx_sf_desc, shift) == 13 &&
+              offsetof(clx_sf_desc, flags) == 11 && offsetof(clx_sf_desc, order) == 12 && offsetof(clx_sf_desc, shift) == 13 &&
               offsetof(clx_sf_desc, wasted) == 14 && offsetof(clx_sf_desc, decor) == 15 && offsetof(clx_sf_desc, coef) == 16, "clx_sf_desc layout");
 
 // Debug aid (tools/timeline.py): with -DCLX_TIMELINE every wave of an instrumented kernel records when it started and

@@ -642,7 +642,7 @@ void clx_k_residual(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
                 const uint64_t base = fr.out_off + (uint64_t)ch * bs;
                 uint4 hdr16;
                 hdr16.x = (uint32_t)base; hdr16.y = (uint32_t)(base >> 32);
-                hdr16.z = (bs & 0xffffu) | ((ll < 23u ? ll : 23u) << 16);                                  // n, lim_log2, reserved = 0
+                hdr16.z = (bs & 0xffffu) | ((ll < 23u ? ll : 23u) << 16) | ((fr.bps <= 16u ? CLX_SF_NARROW : 0u) << 24);   // n, lim_log2, flags
                 hdr16.w = ((kind >= 2u) ? order : 0u) | (qshift << 8) | (wasted << 16) | (ca << 24);       // order, shift, wasted, decor
                 *reinterpret_cast<uint4*>(d) = hdr16;
             }
@@ -769,7 +769,8 @@ __device__ __forceinline__ void clx_dot2_block_any(const int32_t (&x)[CLX_BLK], 
 //            lim16 = min(lim, 2^15) -- 16-bit audio, the common case (mid is 16 bits wide; side is 17 but small)
 //   24-bit : v_mad_i32_i24 chain: every sample inside [-lim, lim), lim <= 2^23 with sum|c| * lim < 2^31 (from K1)
 //   exact  : v_mad_i64_i32, any input -- garbage in, the reference's garbage out
-template <int OMAX>
+// LEAN: without the 24-bit evaluation (16-bit, else exact): what the kernel for 16-bit audio uses -- fewer values live at once.
+template <int OMAX, bool LEAN = false>
 struct K2Predictor {
     static constexpr bool HAS16 = OMAX <= 12;
     int32_t c[OMAX], hist[OMAX];
@@ -815,7 +816,7 @@ struct K2Predictor {
             }
             h16_ok = in16;             // the lanes that left the range sit out until their history is back inside (below)
         }
-        if (__all(h_ok)) {
+        if (!LEAN && __all(h_ok)) {
             hooked = true;
             int32_t h0[OMAX];
 #pragma unroll
@@ -994,10 +995,9 @@ struct K2Mover {
     }
 };
 
-template <int OMAX>
+template <int OMAX, int DEPTH = CLX_K2_DEPTH, bool LEAN = false>
 __device__ __forceinline__ void clx_predict_wave(int4 (*ring)[4][64], const K2Slot& S, uint32_t nblk, int lane CLX_TL_PARAM) {
-    constexpr int DEPTH = CLX_K2_DEPTH;
-    K2Predictor<OMAX> P; P.init(S);
+    K2Predictor<OMAX, LEAN> P; P.init(S);
     const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // this lane's row swizzle (lane = row view)
     auto fetch = [&](int32_t (&x)[CLX_BLK], uint32_t blk) __attribute__((always_inline)) {
         const int4* tile = &ring[blk % DEPTH][0][0];
@@ -1040,10 +1040,9 @@ __device__ __forceinline__ void clx_predict_wave(int4 (*ring)[4][64], const K2Sl
 // stores): block j, requested in turn j+3-DEPTH, is followed by the DEPTH-5 younger blocks (4 loads each) when the turn before
 // the predictor's read of it ends.  (One wave that mixes stores and DMAs under a counted vmcnt decoded wrongly under load with
 // less than ~3 us between request and use.)
-template <int MODE>
+template <int MODE, int DEPTH = CLX_K2_DEPTH>
 __device__ __forceinline__ void clx_finish_wave_alt(int4 (*ring)[4][64], int32_t* __restrict__ out, const K2Slot& S, const K2Finisher& F,
                                                     int32_t* __restrict__ dump, uint32_t nblk, uint32_t parity, int lane CLX_TL_PARAM) {
-    constexpr int DEPTH = CLX_K2_DEPTH;
     K2Mover M; M.init(out, S, lane);
     const uint32_t sw = ((uint32_t)lane >> 2) & 3u;                               // lane = row view
     clx_wg_barrier();                          // = the predictor's first barrier: tiles 0 and 1 are there
@@ -1080,9 +1079,9 @@ __device__ __forceinline__ void clx_finish_wave_alt(int4 (*ring)[4][64], int32_t
     while (done < nturn) { CLX_TL_WAIT(clx_wg_barrier()); ++done; }
 }
 
+template <int DEPTH = CLX_K2_DEPTH>
 __device__ __forceinline__ void clx_load_wave(int4 (*ring)[4][64], const int32_t* __restrict__ out, const K2Slot& S, uint32_t nblk, int lane CLX_TL_PARAM) {
-    constexpr int DEPTH = CLX_K2_DEPTH;
-    static_assert(4 * DEPTH < 64, "vmcnt is a 6-bit counter: the whole ring is requested at once at the start");
+    static_assert(DEPTH >= 6 && 4 * DEPTH < 64, "vmcnt is a 6-bit counter: the whole ring is requested at once at the start");
     K2Mover M; M.init(out, S, lane);
     auto dma = [&](uint32_t blk) __attribute__((always_inline)) {
         const uint32_t t = blk * CLX_BLK + 4u * M.pc;
@@ -1176,27 +1175,38 @@ __device__ __forceinline__ void clx_predict_single_mode(int4 (*ring)[4][64], int
 // SIMDs in cyclic order: waves w and w+4 share one.  The predictors (waves 0, 1), whose chains decide the kernel's duration,
 // share theirs with the loaders (waves 4, 5: a handful of instructions per turn); the finishers (2, 3, 6, 7) share the other two.
 // The groups share nothing but the barrier.
-extern "C" __global__ __launch_bounds__(512)
-void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+// Two kernels.  Every wave of a kernel is given the registers its hungriest role and path needs -- 203 with the unaligned rows,
+// the 24-bit and exact evaluations of up to 32 taps -- and while a workgroup of the general kernel sits on a CU its eight waves
+// keep them: 1 600 of the CU's 2 048 vector registers and 96 KB of its LDS, one workgroup per CU.  clx_k_predict16 takes the
+// groups of 64 rows that are all 16-byte aligned, of 16-bit audio (K1's flag in the descriptor) and of at most 8 taps -- what a
+// 16-bit stream is made of -- with the 16-bit evaluation and the exact one behind it, one group = four waves per workgroup and a
+// 7-tile ring: 102 registers per wave, 28 KB per workgroup.  The predictor stages of several submissions in flight
+// (clx_batch_submit) then are resident side by side, four or five workgroups to a CU, instead of queueing for whole CUs.
+// clx_k_predict takes every other group with everything; both leave the other's groups alone.
+#define CLX_K2_DEPTH16 7
+template <bool FAST, int DEPTH, int GROUPS>
+__device__ __forceinline__ void clx_predict_groups(int4 (*ring2)[DEPTH][4][64], int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd,
+                                                   uint32_t n_slots, int32_t* __restrict__ dump_all) {
     CLX_TL_BEGIN();
-    __shared__ int4 ring2[2][CLX_K2_DEPTH][4][64];    // per group 48 KiB: 12 tiles x 64 B of each of its 64 rows
     const int lane = (int)threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t pair = wave & 1u;
-    const uint32_t role = wave >> 1;               // 0: predictor, 1: finisher of the even tiles, 2: loader, 3: finisher of the odd tiles
+    const uint32_t pair = GROUPS == 2 ? (wave & 1u) : 0u;
+    const uint32_t role = GROUPS == 2 ? (wave >> 1) : wave;   // 0: predictor, 1: finisher of the even tiles, 2: loader, 3: finisher of the odd tiles
     const bool finisher = (role & 1u) != 0u;       // wave-uniform
     int4 (*ring)[4][64] = ring2[pair];
-    const uint32_t group = blockIdx.x * 2u + pair;
+    const uint32_t group = blockIdx.x * (uint32_t)GROUPS + pair;
     const uint32_t slot = group * 64u + (uint32_t)lane;
     K2Slot S;
     S.d = &sfd[slot < n_slots ? slot : 0];
     S.n = 0; S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0;
     uint64_t base = 0;
+    uint32_t narrow = 1u;                          // the slot's samples are at most 16 bits wide (K1's flag; empty slots do not object)
     if (slot < n_slots) {
         S.n = S.d->n; S.order = S.d->order; S.shift = S.d->shift; S.wasted = S.d->wasted; S.decor = S.d->decor; base = S.d->out_base;
         S.lim_log2 = S.d->lim_log2;
+        narrow = S.d->flags & CLX_SF_NARROW;
     }
-    if (S.n == 0u) { S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0; base = 0; }
+    if (S.n == 0u) { S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0; base = 0; narrow = 1u; }
     S.row = out + base;
     // a decorrelated pair is only formed when both of its subframes decoded (same block size, same mode)
     const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.n, 0xB1, 0xF, 0xF, false);
@@ -1216,22 +1226,28 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
     if (nmax == 0u || !__any(work)) return;
     // 16-byte row accesses need 16-byte aligned rows whose length is a multiple of 4 samples
     const bool al = (S.n == 0u) || ((((uintptr_t)S.row) & 15u) == 0u && (S.n & 3u) == 0u);
-    if (__all(al)) {
+    const bool all_al = __all(al);
+    if ((all_al && omax <= 8u && __all(narrow != 0u)) != FAST) return;      // the other kernel's group
+    if (all_al) {
         const uint32_t nblk = (nmax + CLX_BLK - 1u) / CLX_BLK;
         if (finisher) {
             K2Finisher F; F.init(S, lane);
             const int mode = F.mode();
             const uint32_t parity = role >> 1;
-            if (mode == 0)      clx_finish_wave_alt<0>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
-            else if (mode == 1) clx_finish_wave_alt<1>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
-            else                clx_finish_wave_alt<2>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
+            if (mode == 0)      clx_finish_wave_alt<0, DEPTH>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
+            else if (mode == 1) clx_finish_wave_alt<1, DEPTH>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
+            else                clx_finish_wave_alt<2, DEPTH>(ring, out, S, F, dump, nblk, parity, lane CLX_TL_ARG);
         }
-        else if (role == 2u)  clx_load_wave(ring, out, S, nblk, lane CLX_TL_ARG);
-        else if (omax <= 4u)  clx_predict_wave<4>(ring, S, nblk, lane CLX_TL_ARG);
-        else if (omax <= 8u)  clx_predict_wave<8>(ring, S, nblk, lane CLX_TL_ARG);
-        else if (omax <= 12u) clx_predict_wave<12>(ring, S, nblk, lane CLX_TL_ARG);
-        else                  clx_predict_wave<32>(ring, S, nblk, lane CLX_TL_ARG);
-    } else if (role == 0u) {
+        else if (role == 2u)  clx_load_wave<DEPTH>(ring, out, S, nblk, lane CLX_TL_ARG);
+        else if (FAST) {
+            if (omax <= 4u)   clx_predict_wave<4, DEPTH, true>(ring, S, nblk, lane CLX_TL_ARG);
+            else              clx_predict_wave<8, DEPTH, true>(ring, S, nblk, lane CLX_TL_ARG);
+        }
+        else if (omax <= 4u)  clx_predict_wave<4, DEPTH>(ring, S, nblk, lane CLX_TL_ARG);
+        else if (omax <= 8u)  clx_predict_wave<8, DEPTH>(ring, S, nblk, lane CLX_TL_ARG);
+        else if (omax <= 12u) clx_predict_wave<12, DEPTH>(ring, S, nblk, lane CLX_TL_ARG);
+        else                  clx_predict_wave<32, DEPTH>(ring, S, nblk, lane CLX_TL_ARG);
+    } else if (!FAST && role == 0u) {
         if (omax <= 4u)       clx_predict_unaligned<4>(S, dump, nmax, lane);
         else if (omax <= 8u)  clx_predict_unaligned<8>(S, dump, nmax, lane);
         else if (omax <= 12u) clx_predict_unaligned<12>(S, dump, nmax, lane);
@@ -1239,12 +1255,24 @@ void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sf
     }
     CLX_TL_END(1, blockIdx.x * 8u + (threadIdx.x >> 6));
 }
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_predict16(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    __shared__ int4 ring2[1][CLX_K2_DEPTH16][4][64];  // 28 KiB: 7 tiles x 64 B of each of the group's 64 rows
+    clx_predict_groups<true, CLX_K2_DEPTH16, 1>(ring2, out, sfd, n_slots, dump_all);
+}
+extern "C" __global__ __launch_bounds__(512)
+void clx_k_predict(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    __shared__ int4 ring2[2][CLX_K2_DEPTH][4][64];    // per group 48 KiB: 12 tiles x 64 B of each of its 64 rows
+    clx_predict_groups<false, CLX_K2_DEPTH, 2>(ring2, out, sfd, n_slots, dump_all);
+}
 
 // K2, throughput build (see clx_predict_single): one wave per 64 rows, picked by the host for large batches.
 // Two kernels: groups whose highest predictor order is <= 12, and the rest.  The 32-tap predictor needs ~190 VGPRs; in a
 // kernel of its own it does not halve the occupancy of the common case.
+// `skip_fast`: the groups clx_k_predict16 takes (it ran before) are left alone.
 template <bool HI>
-__device__ __forceinline__ void clx_predict_1w_groups(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+__device__ __forceinline__ void clx_predict_1w_groups(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all,
+                                                      uint32_t skip_fast) {
     constexpr int DEPTH = 3;
     __shared__ int4 ring[DEPTH][4][64];           // 12 KiB
     const int lane = (int)threadIdx.x;
@@ -1254,11 +1282,13 @@ __device__ __forceinline__ void clx_predict_1w_groups(int32_t* __restrict__ out,
     S.d = &sfd[slot < n_slots ? slot : 0];
     S.n = 0; S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0;
     uint64_t base = 0;
+    uint32_t narrow = 1u;
     if (slot < n_slots) {
         S.n = S.d->n; S.order = S.d->order; S.shift = S.d->shift; S.wasted = S.d->wasted; S.decor = S.d->decor; base = S.d->out_base;
         S.lim_log2 = S.d->lim_log2;
+        narrow = S.d->flags & CLX_SF_NARROW;
     }
-    if (S.n == 0u) { S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0; base = 0; }
+    if (S.n == 0u) { S.order = 0; S.shift = 0; S.wasted = 0; S.decor = 0; S.lim_log2 = 0; base = 0; narrow = 1u; }
     S.row = out + base;
     const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.n, 0xB1, 0xF, 0xF, false);
     const uint32_t pd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S.decor, 0xB1, 0xF, 0xF, false);
@@ -1274,6 +1304,7 @@ __device__ __forceinline__ void clx_predict_1w_groups(int32_t* __restrict__ out,
     if (nmax == 0u || !__any(work)) return;
     if ((omax > 12u) != HI) return;                // the other kernel's group
     const bool al = (S.n == 0u) || ((((uintptr_t)S.row) & 15u) == 0u && (S.n & 3u) == 0u);
+    if (skip_fast != 0u && __all(al) && omax <= 8u && __all(narrow != 0u)) return;       // clx_k_predict16's group
     if (__all(al)) {
         const uint32_t nblk = (nmax + CLX_BLK - 1u) / CLX_BLK;
         if (HI)               clx_predict_single_mode<32, DEPTH>(ring, out, S, dump, nblk, lane);
@@ -1288,12 +1319,12 @@ __device__ __forceinline__ void clx_predict_1w_groups(int32_t* __restrict__ out,
     }
 }
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_predict_1w(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
-    clx_predict_1w_groups<false>(out, sfd, n_slots, dump_all);
+void clx_k_predict_1w(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all, uint32_t skip_fast) {
+    clx_predict_1w_groups<false>(out, sfd, n_slots, dump_all, skip_fast);
 }
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_predict_1w_hi(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all) {
-    clx_predict_1w_groups<true>(out, sfd, n_slots, dump_all);
+void clx_k_predict_1w_hi(int32_t* __restrict__ out, const clx_sf_desc* __restrict__ sfd, uint32_t n_slots, int32_t* __restrict__ dump_all, uint32_t skip_fast) {
+    clx_predict_1w_groups<true>(out, sfd, n_slots, dump_all, skip_fast);
 }
 
 // ------------------------------------------------------------------------------------------------

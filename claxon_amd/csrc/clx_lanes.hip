@@ -1135,7 +1135,7 @@ __device__ __forceinline__ void clx_l2_publish(clx_sf_desc* d, const LaneState<3
     d->n = (uint16_t)n;
     d->order = (uint8_t)((n != 0u && h.kind >= 2u) ? h.order : 0u);
     d->wasted = (uint8_t)h.wasted;
-    d->reserved = 0; d->decor = 0; d->out_base = 0;
+    d->flags = 0; d->decor = 0; d->out_base = 0;
     if (!with_coefs) {
         // until the transition nothing is predicted: no taps, and a range limit that lets warm-up samples through
         d->shift = 0; d->lim_log2 = 23;

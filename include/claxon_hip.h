@@ -258,9 +258,12 @@ int  clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
 int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                    int32_t* d_out, void* stream);
 /* Pipelined submission: the same work and the same results as clx_batch_run, with up to CLX_SUBMIT_DEPTH submissions in
- * flight -- each a whole run on an internal stream of its own, so that the Rice stages of two submissions share the machine
- * (neither ends in a half-empty round of waves) and their predictor stages, serial chains on a fraction of the SIMDs, run side by
- * side (the reference has no counterpart: one FrameReader decodes one frame at a time, frame.rs:667).  A submission starts after everything queued on `stream` so far.  Give the submissions in flight different
+ * flight -- each a whole run on an internal stream of its own, so that the Rice stages of the submissions share the machine
+ * (none ends in a half-empty round of waves) and their predictor stages, serial chains in small workgroups, are resident side by
+ * side; the CRC kernel runs on one more stream beside them (the reference has no counterpart: one FrameReader decodes one frame
+ * at a time, frame.rs:667).  The internal streams want a hardware queue each: set GPU_MAX_HW_QUEUES=8 in the environment before
+ * the HIP runtime starts (its default of 4 makes them share two queues: 0.33 instead of 0.30 ms per 10 000 frames).
+ * A submission starts after everything queued on `stream` so far.  Give the submissions in flight different
  * `d_out` buffers, i.e. rotate over CLX_SUBMIT_DEPTH of them (re-using a buffer is legal: the submission then waits for the
  * earlier one that writes it).  Work enqueued on `stream` after clx_batch_flush sees every submission finished;
  * clx_batch_results flushes by itself and returns the LAST submission's results.  Falls back to clx_batch_run for the kernel

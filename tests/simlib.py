@@ -11,7 +11,7 @@ _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wavesim")
 _SO = os.path.join(_DIR, "libwavesim.so")
 _CSRC = os.path.join(os.path.dirname(_DIR), "..", "claxon_amd", "csrc")
 
-SF_DESC_DTYPE = np.dtype([("out_base", "<u8"), ("n", "<u2"), ("lim_log2", "u1"), ("reserved", "u1"), ("order", "u1"), ("shift", "u1"), ("wasted", "u1"),
+SF_DESC_DTYPE = np.dtype([("out_base", "<u8"), ("n", "<u2"), ("lim_log2", "u1"), ("flags", "u1"), ("order", "u1"), ("shift", "u1"), ("wasted", "u1"),
                           ("decor", "u1"), ("coef", "<i2", (32,))])
 assert SF_DESC_DTYPE.itemsize == 80
 

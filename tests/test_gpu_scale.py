@@ -3,6 +3,8 @@ agree with the oracle -- status, message, end_bit and every sample (not only the
 
   * above 512 groups of predictor slots the wave path switches to the one-wave K2 builds (clx_k_predict_1w, and
     clx_k_predict_1w_hi for groups with a predictor order above 12)          -- subframe.rs:524-614
+  * below, groups of aligned 16-bit rows of at most 8 taps go to clx_k_predict16, the rest to clx_k_predict (or to the one-wave
+    kernels when the plan knows that every frame is 16-bit and aligned)
   * from 52 000 subframes of this shape (content dependent: clx_select_path, clx_plan.h) the default path is the lane
     kernels, fused build above 40 000 subframes                                  -- frame.rs:705-742
   * BASELINE configs 2 / 4 / 5 at >= 8 000 frames with flags 0: the selection the measurements ask for (tools/bench_configs.py)
@@ -69,7 +71,7 @@ def test_auto_wave_path_one_wave_predictor(oracle, ctx, big3):
     the one-wave predictor builds; the order-32 frames make clx_k_predict_1w_hi do real work."""
     w = synth.concat("config3 x 20480 + config4 x 640", [pc.head(big3, 20480), synth.config4(640)])
     run_and_compare(oracle, ctx, w, 0, ["clx_k_residual", "clx_k_predict_1w", "clx_k_predict_1w_hi", "clx_k_crc16"],
-                    forbid=["clx_k_predict", "clx_k_lanes"])
+                    forbid=["clx_k_predict", "clx_k_predict16", "clx_k_lanes"])
 
 
 def test_auto_lane_path_fused(oracle, ctx, big3):
@@ -81,16 +83,20 @@ def test_auto_lane_path_fused(oracle, ctx, big3):
 def test_forced_builds_at_scale(oracle, ctx, big3):
     """The builds the thresholds would not pick at this size, forced by flag on the same 12 288 frames."""
     w = pc.head(big3, 12288)
-    run_and_compare(oracle, ctx, w, cx.PATH_WAVES | cx.K2_LATENCY, ["clx_k_residual", "clx_k_predict"])
+    # (every frame 16-bit and aligned: what clx_k_predict16 leaves -- nothing here -- goes to the one-wave kernels, not to clx_k_predict)
+    run_and_compare(oracle, ctx, w, cx.PATH_WAVES | cx.K2_LATENCY, ["clx_k_residual", "clx_k_predict16", "clx_k_predict_1w"], forbid=["clx_k_predict"])
+    # 24-bit frames in the batch: the general multi-wave kernel takes their groups
+    wm = synth.concat("config3 x 2048 + config4 x 512", [pc.head(big3, 2048), synth.config4(512)])
+    run_and_compare(oracle, ctx, wm, cx.PATH_WAVES | cx.K2_LATENCY, ["clx_k_residual", "clx_k_predict16", "clx_k_predict"], forbid=["clx_k_predict_1w"])
     run_and_compare(oracle, ctx, w, cx.PATH_WAVES | cx.K2_THROUGHPUT, ["clx_k_residual", "clx_k_predict_1w"])
     run_and_compare(oracle, ctx, w, cx.PATH_LANES | cx.LANES_SPLIT, ["clx_k_lanes2"])
     run_and_compare(oracle, ctx, w, cx.PATH_LANES | cx.LANES_FUSED, ["clx_k_lanes"])
 
 
 @pytest.mark.parametrize("make,expect,forbid", [
-    (lambda: synth.config2(8192), ["clx_k_residual", "clx_k_predict"], ["clx_k_lanes", "clx_k_lanes2"]),     # 8 192 mono subframes, 5.7 bits/sample
+    (lambda: synth.config2(8192), ["clx_k_residual", "clx_k_predict16"], ["clx_k_lanes", "clx_k_lanes2"]),     # 8 192 mono subframes, 5.7 bits/sample
     (lambda: synth.config4(8192), ["clx_k_lanes2"], ["clx_k_residual"]),                                      # 24-bit: lane kernels, two-wave build
-    (lambda: synth.config5_unique(8192), ["clx_k_residual", "clx_k_predict"], ["clx_k_lanes", "clx_k_lanes2"]),  # 16 384 subframes at 9.5 bits/sample
+    (lambda: synth.config5_unique(8192), ["clx_k_residual", "clx_k_predict16"], ["clx_k_lanes", "clx_k_lanes2"]),  # 16 384 subframes at 9.5 bits/sample
     (lambda: synth.config5_unique(12288), ["clx_k_lanes2"], ["clx_k_residual"]),                              # 24 576 of them: lane kernels
 ], ids=["config2", "config4", "config5", "config5-more"])
 def test_baseline_configs_default_selection(oracle, ctx, make, expect, forbid):

@@ -45,12 +45,21 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
     if (sfd_out) memcpy(sfd_out, sfd.data(), n_slots * sizeof(clx_sf_desc));
     if (flags & 0x100u) return CLX_OK;     // stop after K1 (residual inspection)
     std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
-    // both builds of K2 are exercised: the two-wave one for even slot counts, the one-wave one for odd ones
+    // every build of K2 is exercised: the one-wave one for odd slot counts, the multi-wave ones for even ones
     if (n_slots & 1) {
-        SIM_LAUNCH(clx_k_predict_1w, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data());
-        SIM_LAUNCH(clx_k_predict_1w_hi, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data());
+        SIM_LAUNCH(clx_k_predict_1w, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 0u);
+        SIM_LAUNCH(clx_k_predict_1w_hi, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 0u);
     }
-    else SIM_LAUNCH(clx_k_predict, (n_slots + 127) / 128, 512, out, sfd.data(), (uint32_t)n_slots, dump.data());
+    else {
+        // the fast kernel first; what it leaves goes to the general kernel, or (slot counts 2 mod 4) to the one-wave kernels
+        // told to skip its groups -- the library does the latter when every frame is 16-bit and aligned
+        SIM_LAUNCH(clx_k_predict16, (n_slots + 63) / 64, 256, out, sfd.data(), (uint32_t)n_slots, dump.data());
+        if (n_slots & 2) {
+            SIM_LAUNCH(clx_k_predict_1w, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 1u);
+            SIM_LAUNCH(clx_k_predict_1w_hi, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 1u);
+        }
+        else SIM_LAUNCH(clx_k_predict, (n_slots + 127) / 128, 512, out, sfd.data(), (uint32_t)n_slots, dump.data());
+    }
     if (flags & CLX_VERIFY_CRC16)
         SIM_LAUNCH(clx_k_crc16, (n + 3) / 4, 256, arena, dev.data(), (uint32_t)n, results);
     return CLX_OK;

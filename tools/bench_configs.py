@@ -4,6 +4,8 @@ usage: python tools/bench_configs.py [sizes [configs]]     e.g.  4000,8000,16000
 Prints one line per (config, size): ms per step for every selection (run = one batch at a time; sub = pipelined submissions,
 SUBMIT_DEPTH in flight), after a bit-exactness check of each."""
 import os, sys, time
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # a hardware queue per internal stream of clx_batch_submit (bench.py does the same)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -38,7 +40,7 @@ for name, make in makers:
                 for i in range(len(outs)): f(d_arena.data_ptr(), w.arena_len, outs[i].data_ptr(), stream)
                 batch.flush(stream); torch.cuda.synchronize()
                 ok = bool(np.all(batch.results()["status"] == 0)) and all(bool(torch.equal(o, ref)) for o in outs)
-                reps = 10
+                reps = 40
                 t = time.perf_counter()
                 for i in range(reps): f(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
                 batch.flush(stream); torch.cuda.synchronize()
