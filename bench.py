@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 # The library keeps several submissions in flight on internal streams (clx_batch_submit); a hardware queue per stream lets their
 # kernels overlap as intended.  HIP's default is 4 queues for the whole process, which the internal streams then share in pairs
 # (0.33 instead of 0.30 ms per step).  Has to be in the environment before the HIP runtime starts; carried in the JSON line.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 
@@ -38,8 +38,8 @@ PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config3")
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU for config2/3/4 (BASELINE: 10000)")
     ap.add_argument("--total-frames", type=int, default=1000000, help="config5: frames of the whole job")
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="time steps that do not overlap (clx_batch_run instead of clx_batch_submit)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (CRC-16 step, host-buffer rates)")
-    ap.add_argument("--path", choices=["auto", "waves", "lanes"], default="auto", help="kernel path (default: library's choice)")
+    ap.add_argument("--path", choices=["auto", "waves", "lanes", "lanes-fused"], default="auto", help="kernel path (default: library's choice)")
     args = ap.parse_args()
 
     import torch
@@ -111,14 +111,13 @@ def main():
 
     d_arena = torch.from_numpy(w.arena).to(dev)
     d_out = torch.zeros(w.total_samples, dtype=torch.int32, device=dev)
-    # consecutive steps are submitted with up to cx.SUBMIT_DEPTH of them in flight (clx_batch_submit: each step a whole run on an
-    # internal stream of the library, the Rice stage of one beside the predictor stage and the draining Rice stage of others), so
-    # they rotate over that many output buffers -- when there is room for them
-    depth = cx.SUBMIT_DEPTH
-    pipelined = (not args.no_pipeline) and depth * 4 * w.total_samples < 64 * (1 << 30)
-    outs = [d_out] + ([torch.zeros(w.total_samples, dtype=torch.int32, device=dev) for _ in range(depth - 1)] if pipelined else [])
-    path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES}[args.path]
+    path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES, "lanes-fused": cx.PATH_LANES | cx.LANES_FUSED}[args.path]
     batch = ctx.plan(descs, w.out_offs, verify_crc=False, path=path)
+    # consecutive steps are submitted with up to batch.submit_depth of them in flight (clx_batch_submit: each step a whole run on
+    # an internal stream of the library), so they rotate over that many output buffers -- when there is room for them
+    depth = batch.submit_depth
+    pipelined = (not args.no_pipeline) and depth > 1 and depth * 4 * w.total_samples < 64 * (1 << 30)
+    outs = [d_out] + ([torch.zeros(w.total_samples, dtype=torch.int32, device=dev) for _ in range(depth - 1)] if pipelined else [])
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def barrier():
@@ -161,7 +160,15 @@ def main():
     # ---- per-kernel durations: HIP events recorded by the library on the launch stream, around each of its kernels (steps one at
     #      a time); they also say which kernels the library selected -- only the wave path with the latency build of the predictor keeps several steps in flight
     kernel_ms = _kernel_ms(torch, batch, lambda: batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
-    pipelined = pipelined and "clx_k_predict16" in kernel_ms
+    kernel_ms_run = dict(kernel_ms)            # what clx_batch_run selects (config.one_step_at_a_time)
+    path_tag = ""
+    if pipelined and batch.submit_lanes and "clx_k_lanes" not in kernel_ms:
+        # the pipelined steps run the fused lane kernels while one run at a time takes the wave kernels: the roofline block is
+        # about the kernels of the TIMED steps, so their durations are taken from a batch forced onto them
+        bl = ctx.plan(descs, w.out_offs, verify_crc=False, path=cx.PATH_LANES | cx.LANES_FUSED)
+        kernel_ms = _kernel_ms(torch, bl, lambda: bl.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
+        bl.close()
+        path_tag = "_lanes"
 
     elapsed = timed(batch, args.steps, pipelined)
     # whole-job figures: MAX elapsed over ranks, SUM of samples per step, SUM of failed frames (must be 0)
@@ -184,12 +191,13 @@ def main():
     # never less than max(kernel), never more than their sum when steps do not overlap
     t_path_ms = ms_per_step if pipelined else path_ms
     achieved = alg_bytes / (t_path_ms * 1e-3) / 1e9
-    traffic, traffic_src = _pmc_traffic(args.workload, w.n)
+    traffic, traffic_src = _pmc_traffic(args.workload + path_tag, w.n)
     roofline = {"bound": "hbm", "kernel": "+".join(kernel_ms.keys()), "achieved": round(achieved, 1), "peak": PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "path_ms": round(t_path_ms, 4), "path_ms_basis": ("ms_per_step of the pipelined steps (kernels of consecutive steps overlap)" if pipelined
                                                                   else "sum of the path's kernel durations"),
                 "kernel_ms_sum_unpipelined": round(path_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                "kernel_ms_one_step_at_a_time": {k: round(v, 4) for k, v in kernel_ms_run.items()},
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "dominant_kernel": {"name": dom_name, "ms": round(kernel_ms[dom_name], 4),
                                     "note": "one of the path's kernels; the path's bytes over its time alone would overstate it"},
@@ -230,7 +238,7 @@ def main():
         ms_1 = 1e3 * el_1 / args.steps
         cfg["one_step_at_a_time"] = {"value": round(samples_1 / (ms_1 * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_1, 4),
                                      "frac": round(alg_bytes / (ms_1 * 1e-3) / 1e9 / PEAK_GBS, 4),
-                                     "note": "clx_batch_run: a batch's latency; `value` is the throughput of consecutive batches with up to %d in flight" % depth}
+                                     "note": "clx_batch_run (the kernels it selects: roofline.kernel_ms_one_step_at_a_time): a batch's latency; `value` is the throughput of consecutive batches with up to %d in flight" % depth}
     batch.close()                              # (its internal streams give their hardware queues back)
     if not w.bare_subframes and not args.no_extras:
         # ---- the same step with every frame's CRC-16 verified on the device (frame.rs:752-763: the reference always does);
@@ -244,7 +252,12 @@ def main():
         rc = bc.results()
         el_c = timed(bc, args.steps, pipelined)
         el_c, samples_c, bad_c = shard.reduce_job(dist if world > 1 else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=dev)
-        kc = _kernel_ms(torch, bc, lambda: bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
+        if pipelined and bc.submit_lanes and path_tag:      # (as above: the kernels of the timed steps)
+            bcl = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED)
+            kc = _kernel_ms(torch, bcl, lambda: bcl.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
+            bcl.close()
+        else:
+            kc = _kernel_ms(torch, bc, lambda: bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
         bc.close()
         if bad_c == 0:
             ms_c = 1e3 * el_c / args.steps

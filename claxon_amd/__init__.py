@@ -23,7 +23,7 @@ OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
 CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)
 ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16, PATH_WAVES, PATH_LANES, PCM_ON_DEVICE, LANES_FUSED, LANES_SPLIT = 1, 2, 4, 8, 16, 32, 64, 128
 K2_LATENCY, K2_THROUGHPUT = 256, 512
-SUBMIT_DEPTH = 4            # CLX_SUBMIT_DEPTH: submissions Batch.submit keeps in flight
+SUBMIT_DEPTH = 8            # CLX_SUBMIT_DEPTH: the most submissions a Batch keeps in flight (Batch.submit_depth: this batch's)
 
 
 class ClaxonError(RuntimeError):
@@ -85,7 +85,7 @@ assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
 EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
     "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_frames_multi", "clx_decode_frames_stream", "clx_set_stream_chunk", "clx_host_alloc", "clx_host_free", "clx_decode_subframes", "clx_interleave",
-    "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
+    "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_submit_depth", "clx_batch_submit_lanes", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
     "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
     "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames", "clx_index_frames_device",
@@ -158,6 +158,8 @@ def lib():
     L.clx_batch_run.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_submit.argtypes = [vp, vp, sz, vp, vp]
     L.clx_batch_flush.argtypes = [vp, vp]
+    L.clx_batch_submit_depth.argtypes = [vp]
+    L.clx_batch_submit_lanes.argtypes = [vp]
     L.clx_batch_results.argtypes = [vp, vp]
     L.clx_batch_interleave.argtypes = [vp, vp, vp, C.c_uint32, vp]
     L.clx_index_frames_device.argtypes = [vp, vp, sz, sz, vp, vp, sz, C.POINTER(sz), C.POINTER(sz), C.c_uint32]
@@ -599,6 +601,16 @@ class Batch:
         st = lib().clx_batch_submit(self._h, C.c_void_p(d_arena_ptr), arena_len, C.c_void_p(d_out_ptr),
                                     C.c_void_p(stream) if stream else None)
         self.ctx._check(st)
+
+    @property
+    def submit_depth(self):
+        """Submissions this batch keeps in flight = output buffers to rotate over (clx_batch_submit_depth)."""
+        return int(lib().clx_batch_submit_depth(self._h))
+
+    @property
+    def submit_lanes(self):
+        """True when this batch's pipelined submissions run the fused lane kernels (clx_batch_submit_lanes)."""
+        return bool(lib().clx_batch_submit_lanes(self._h))
 
     def flush(self, stream=0):
         self.ctx._check(lib().clx_batch_flush(self._h, C.c_void_p(stream) if stream else None))

@@ -254,7 +254,8 @@ struct clx_batch {
     clx_frame_result* d_results = nullptr;
     int32_t* d_dump = nullptr;       // wave path: 64 bytes per predictor lane for out-of-row stores
     // lane path
-    bool lanes = false;
+    bool lanes = false;              // clx_batch_run uses the lane kernels
+    bool lanes_planned = false;      // their plan data (d_slot_frame, d_multi, scratch) exists: run or submit may use them
     uint32_t* d_slot_frame = nullptr;
     uint32_t* d_multi = nullptr;
     size_t n_multi = 0;
@@ -272,11 +273,12 @@ struct clx_batch {
     // Pipelined submissions (clx_batch_submit): up to kDepth submissions in flight, each a whole run (Rice stage, predictor stage,
     // CRC) on a stream of its own with its own descriptors and results -- the Rice stages of two submissions share the machine
     // (neither ends in a partly filled round of waves) and their predictor stages, serial chains, run side by side.
-    enum { kDepth = CLX_SUBMIT_DEPTH };
+    enum { kDepth = CLX_SUBMIT_DEPTH, kDepthWaves = 4, kDepthLanes = CLX_SUBMIT_DEPTH };
     struct Flight {
         hipStream_t stream = nullptr;
-        clx_sf_desc* d_sfd = nullptr;            // flight 0 uses the batch's own d_sfd / d_results
+        clx_sf_desc* d_sfd = nullptr;            // flight 0 uses the batch's own buffers
         clx_frame_result* d_results = nullptr;
+        uint32_t* d_sf_start = nullptr; uint32_t* d_errkey = nullptr; uint64_t* d_endbits = nullptr;   // lane kernels' scratch
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
         hipEvent_t ev_rice = nullptr, ev_side = nullptr;   // Rice stage done | the submission's kernels on side_stream done
         bool side_pending = false, side_recorded = false;
@@ -359,6 +361,9 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
         if (F.ev_side) (void)hipEventDestroy(F.ev_side);
         if (i != 0 && F.d_sfd) (void)hipFree(F.d_sfd);
         if (i != 0 && F.d_results) (void)hipFree(F.d_results);
+        if (i != 0 && F.d_sf_start) (void)hipFree(F.d_sf_start);
+        if (i != 0 && F.d_errkey) (void)hipFree(F.d_errkey);
+        if (i != 0 && F.d_endbits) (void)hipFree(F.d_endbits);
     }
     if (b->h_up) (void)hipHostFree(b->h_up);
     delete b;
@@ -410,7 +415,9 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!grow(ctx, &b->d_dump, &b->cap[3], lanes64 * 16 * sizeof(int32_t), "hipMalloc dump")) return CLX_API_ERROR;
     }
-    if (b->lanes) {
+    // (the lane kernels' plan data: when either a run or a pipelined submission may use them)
+    b->lanes_planned = b->lanes || ((flags & CLX_PATH_WAVES) == 0 && b->choice_submit.lanes);
+    if (b->lanes_planned) {
         std::vector<uint32_t> slot_frame(ns), multi(nf);
         b->n_multi = clx_plan_lanes(b->h_frames.data(), n, slot, slot_frame.data(), multi.data());
         if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
@@ -426,7 +433,10 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
         clx_batch::Flight& F = b->flight[i];
         if (i != 0 && F.d_sfd) (void)hipFree(F.d_sfd);
         if (i != 0 && F.d_results) (void)hipFree(F.d_results);
-        F.d_sfd = nullptr; F.d_results = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.out = nullptr;   // (side_recorded stays: the event is still there)
+        if (i != 0 && F.d_sf_start) (void)hipFree(F.d_sf_start);
+        if (i != 0 && F.d_errkey) (void)hipFree(F.d_errkey);
+        if (i != 0 && F.d_endbits) (void)hipFree(F.d_endbits);
+        F.d_sfd = nullptr; F.d_results = nullptr; F.d_sf_start = nullptr; F.d_errkey = nullptr; F.d_endbits = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.out = nullptr;   // (side_recorded stays: the event is still there)
     }
     b->last_slot = -1;
     b->planned_arena_len = (size_t)-1;
@@ -489,6 +499,42 @@ int use_lanes(clx_batch* b, size_t arena_len) {
         return 0;
     }
     return 1;
+}
+// The lane kernels of one run: scan (where the later channels of multi-channel frames start), the decode (one or two waves per 64
+// subframes), the per-frame results, the CRC.  `sf_start`, `errkey`, `endbits`: the run's scratch (a set per flight in flight).
+template <typename Mark>
+bool launch_lanes(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, uint32_t* sf_start, uint32_t* errkey, uint64_t* endbits,
+                  clx_frame_result* d_results, bool split, hipStream_t stream, Mark&& mark) {
+    clx_ctx* ctx = b->ctx;
+    if (!hip_ok(ctx, hipMemsetAsync(errkey, 0xff, b->n * sizeof(uint32_t), stream), "memset errkey") ||
+        !hip_ok(ctx, hipMemsetAsync(sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream), "memset sf_start")) return false;
+    if (b->n_multi) {
+        if (!mark("clx_k_scan")) return false;
+        hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi, sf_start, errkey);
+    }
+    if (!mark(split ? "clx_k_lanes2" : "clx_k_lanes")) return false;       // (clx_k_lanes: + clx_k_lanes_hi, its order > 12 twin)
+    if (!split) {
+        hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump);
+        hipLaunchKernelGGL(clx_k_lanes_hi, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump);
+    }
+    else
+        hipLaunchKernelGGL(clx_k_lanes2, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_arena, alloc_len,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump);
+    if (!mark("clx_k_finalize")) return false;
+    hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
+                       (const clx_dev_frame*)b->d_frames, (const uint32_t*)errkey, (const uint64_t*)endbits, (uint32_t)b->n, d_results);
+    if (b->flags & CLX_VERIFY_CRC16) {
+        if (!mark("clx_k_crc16")) return false;
+        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena,
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_results);
+    }
+    return true;
 }
 void launch_stage1_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
                          hipStream_t stream) {
@@ -589,43 +635,15 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     const int lanes = use_lanes(b, arena_len);
     if (lanes < 0) return CLX_API_ERROR;
     if (lanes) {
-        HIP_TRY(ctx, hipMemsetAsync(b->d_errkey, 0xff, b->n * sizeof(uint32_t), stream));
-        HIP_TRY(ctx, hipMemsetAsync(b->d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream));
-        if (b->n_multi) {
-            if (!mark("clx_k_scan")) return CLX_API_ERROR;
-            hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi,
-                               b->d_sf_start, b->d_errkey);
-        }
         // the two-wave (latency) build while its workgroups get a CU each (0.50 ms against 1.00 ms at 20k subframes), the fused
         // single-wave (throughput) build beyond (1.28 against 1.34 ms at 48k subframes); CLX_LANES_FUSED / CLX_LANES_SPLIT force one
         const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false : b->choice.lanes_split;
-        if (!mark(split ? "clx_k_lanes2" : "clx_k_lanes")) return CLX_API_ERROR;     // (clx_k_lanes: + clx_k_lanes_hi, its order > 12 twin)
-        if (!split) {
-            hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits, b->d_dump);
-            hipLaunchKernelGGL(clx_k_lanes_hi, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits, b->d_dump);
-        }
-        else
-            hipLaunchKernelGGL(clx_k_lanes2, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_arena, alloc_len,
-                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                               (const uint32_t*)b->d_sf_start, d_out, b->d_errkey, b->d_endbits, b->d_dump);
-        if (!mark("clx_k_finalize")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_errkey, (const uint64_t*)b->d_endbits, (uint32_t)b->n, b->d_results);
+        if (!launch_lanes(b, d_arena, alloc_len, d_out, b->d_sf_start, b->d_errkey, b->d_endbits, b->d_results, split, stream, mark)) return CLX_API_ERROR;
     } else {
         // (K1 writes every slot of every frame on every run; the slots that only pad a stereo pair to an even index are cleared once)
         clx_batch::Flight& F0 = b->flight[0];
         if (F0.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(b->d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), stream)); F0.sfd_stale = false; }
         if (!launch_waves(b, d_arena, alloc_len, d_out, b->d_sfd, b->d_results, stream, mark, k2_latency_build(b))) return CLX_API_ERROR;
-    }
-    if (lanes && (b->flags & CLX_VERIFY_CRC16)) {
-        if (!mark("clx_k_crc16")) return CLX_API_ERROR;
-        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena,
-                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, b->d_results);
     }
     if (b->profiling) { if (!mark(nullptr)) return CLX_API_ERROR; b->n_kernels = nk - 1; b->ev_valid = true; }
     HIP_TRY(ctx, hipGetLastError());
@@ -644,21 +662,42 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
 // is still being written by an earlier one waits for it -- correct, not overlapped).  `stream` is where the caller's inputs come
 // from: the submission starts after everything queued on it so far.  clx_batch_flush makes `stream` wait for everything submitted;
 // clx_batch_results does so itself.
+namespace {
+// which kernels a pipelined submission uses, and how many submissions it keeps in flight
+bool submit_wants_lanes(const clx_batch* b) {
+    return (b->flags & CLX_PATH_LANES) ? true : (b->flags & CLX_PATH_WAVES) ? false : (b->lanes_planned && b->choice_submit.lanes);
+}
+}  // namespace
+
+extern "C" int clx_batch_submit_lanes(const clx_batch* b) { return b && !b->profiling && submit_wants_lanes(b) && !(b->flags & CLX_LANES_SPLIT) ? 1 : 0; }
+
+extern "C" int clx_batch_submit_depth(const clx_batch* b) {
+    if (!b) return 1;
+    if (b->profiling) return 1;
+    if (submit_wants_lanes(b)) return (b->flags & CLX_LANES_SPLIT) ? 1 : clx_batch::kDepthLanes;
+    return (b->flags & CLX_K2_THROUGHPUT) ? 1 : clx_batch::kDepthWaves;
+}
+
 extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, void* stream_) {
     if (!b || !b->ctx) return CLX_API_ERROR;
     clx_ctx* ctx = b->ctx;
     if (b->n == 0) return CLX_OK;
     if (!d_arena || !d_out) { ctx->last_error = "null device pointer"; return CLX_API_ERROR; }
     if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
-    // Which kernels: with several batches in flight the wave kernels (two-wave predictor build) stay ahead of the lane kernels for
-    // longer than one run at a time (clx_select_path, `pipelined`).  Beyond that -- or when the caller asks for the lane kernels or
-    // the one-wave predictor build -- a submission is a plain run: whole runs of those side by side were measured
-    // (tools/bench_configs.py): no gain for the two-wave lane build, a loss for the one-wave predictor build.
-    const bool want_lanes = (b->flags & CLX_PATH_LANES) ? true : (b->flags & CLX_PATH_WAVES) ? false : (b->lanes && b->choice_submit.lanes);
-    if (want_lanes || (b->flags & CLX_K2_THROUGHPUT) || b->profiling) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
+    // Which kernels (clx_select_path, `pipelined`): the wave kernels with the multi-wave predictor build, four submissions in
+    // flight; or the lane kernels, fused build, eight in flight -- a run of those is one serial chain per subframe on a fraction of
+    // the machine's registers, and eight of them side by side fill it.  The two-wave lane build and the one-wave predictor build
+    // gain nothing from company (measured, tools/bench_configs.py): forced by flag they are plain runs.
+    bool want_lanes = submit_wants_lanes(b);
+    if (want_lanes && (uint64_t)arena_len + 32ull >= (1ull << 32)) {      // (the lane kernels address the arena with 32 bits)
+        if (b->flags & CLX_PATH_LANES) { ctx->last_error = "CLX_PATH_LANES needs arena_len < 4 GiB"; return CLX_API_ERROR; }
+        want_lanes = false;
+    }
+    const int depth = clx_batch_submit_depth(b);
+    if (depth <= 1) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    const int slot = (int)(b->n_submitted % clx_batch::kDepth);
+    const int slot = (int)(b->n_submitted % (uint64_t)depth);
     clx_batch::Flight& F = b->flight[slot];
     if (!F.stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&F.stream, hipStreamNonBlocking));
@@ -667,14 +706,25 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_rice, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_side, hipEventDisableTiming));
     }
-    if (!b->side_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
-    if (!F.d_sfd) {
-        if (slot == 0) { F.d_sfd = b->d_sfd; F.d_results = b->d_results; }
-        else {
-            const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
-            HIP_TRY(ctx, hipMalloc((void**)&F.d_sfd, ns * sizeof(clx_sf_desc)));
-            HIP_TRY(ctx, hipMalloc((void**)&F.d_results, nf * sizeof(clx_frame_result)));
-            F.sfd_stale = true;
+    const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
+    if (!F.d_results) {
+        if (slot == 0) F.d_results = b->d_results;
+        else HIP_TRY(ctx, hipMalloc((void**)&F.d_results, nf * sizeof(clx_frame_result)));
+    }
+    if (want_lanes) {
+        if (!F.d_sf_start) {
+            if (slot == 0) { F.d_sf_start = b->d_sf_start; F.d_errkey = b->d_errkey; F.d_endbits = b->d_endbits; }
+            else {
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_sf_start, ns * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_errkey, nf * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_endbits, nf * sizeof(uint64_t)));
+            }
+        }
+    } else {
+        if (!b->side_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+        if (!F.d_sfd) {
+            if (slot == 0) F.d_sfd = b->d_sfd;
+            else { HIP_TRY(ctx, hipMalloc((void**)&F.d_sfd, ns * sizeof(clx_sf_desc))); F.sfd_stale = true; }
         }
     }
     // a plan that has to be uploaded again (the arena's length changed) is read by the submissions in flight
@@ -690,13 +740,18 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
             HIP_TRY(ctx, hipStreamWaitEvent(F.stream, G.ev_done, 0));
             if (G.side_pending) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, G.ev_side, 0));      // (its side-stream kernels write there too)
         }
-    if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
-    // (this flight's previous side-stream kernels used the descriptors and results the Rice stage is about to overwrite)
+    // (this flight's previous side-stream kernels used the descriptors and results that are about to be overwritten)
     if (F.side_recorded) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_side, 0));
-    if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, [](const char*) { return true; }, true,
-                      b->side_stream, F.ev_rice, F.ev_side)) return CLX_API_ERROR;
+    const auto no_mark = [](const char*) { return true; };
+    if (want_lanes) {
+        if (!launch_lanes(b, d_arena, alloc_len, d_out, F.d_sf_start, F.d_errkey, F.d_endbits, F.d_results, false, F.stream, no_mark)) return CLX_API_ERROR;
+        F.side_pending = false;
+    } else {
+        if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, ns * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
+        if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, no_mark, true, b->side_stream, F.ev_rice, F.ev_side)) return CLX_API_ERROR;
+        F.side_pending = true; F.side_recorded = true;
+    }
     HIP_TRY(ctx, hipEventRecord(F.ev_done, F.stream));
-    F.side_pending = true; F.side_recorded = true;
     F.pending = true;
     F.out = d_out;
     b->last_slot = slot;

@@ -48,10 +48,12 @@ static inline long clx_plan_frames(const clx_frame_desc* frames, size_t n, const
 //   16-bit, ~5 bits per sample (configs 2 and 3)                                     lanes from ~52 000 subframes (28 000 when mono:
 //                                                                                    no scan pass for the later channels)
 // and between the two lane builds the two-wave one while its workgroups still get a CU each (longer for 24-bit audio).
-// `pipelined`: the batch is one of several in flight (clx_batch_submit).  Whole runs of the wave kernels overlap their neighbours
-// -- the Rice stage of one beside the serial predictor chains of another --, runs of the lane kernels do not (one run fills the
-// machine), so the wave path stays ahead for longer: 24-bit audio up to ~22 000 subframes, ~9.5 bits per sample up to ~30 000,
-// ~5 bits per sample up to ~56 000 (mono: 28 000 as before).
+// `pipelined`: the batch is one of several in flight (clx_batch_submit).  There a run of the fused lane kernels -- one serial chain
+// per subframe on a fraction of the machine's registers, 0.85-1.3 ms however few subframes -- has seven others beside it, and
+// the question is throughput: the lane kernels (fused build) unless the batches are small AND of short codes, where the wave
+// kernels' four in flight are ahead (measured with a hardware queue per stream, profiles/r02_bench_configs_sweep_d.txt):
+//   24-bit audio, or >= ~8.5 compressed bits per sample                               lanes always
+//   ~5 bits per sample (configs 2 and 3)                                              lanes from ~10 000 subframes (5 000 when mono)
 // `bytes` = sum of the frames' max_bytes when those are real frame lengths (0 = unknown, e.g. "to the end of the stream").
 struct clx_path_choice { bool lanes, lanes_split; };
 static inline clx_path_choice clx_select_path(uint64_t slots, uint64_t samples, uint64_t bytes, bool heavy, bool all_mono, bool pipelined = false) {
@@ -59,11 +61,11 @@ static inline clx_path_choice clx_select_path(uint64_t slots, uint64_t samples, 
     double rate = (samples && bytes) ? 8.0 * (double)bytes / (double)samples : 7.5;      // compressed bits per sample
     if (rate > 32.0) rate = 7.5;                                                          // not frame lengths: unknown
     double threshold;
-    if (heavy) threshold = pipelined ? 22000.0 : 3000.0;   // (a quarter or more of the samples are wider than 16 bits)
+    if (heavy) threshold = pipelined ? 0.0 : 3000.0;       // (a quarter or more of the samples are wider than 16 bits)
     else {
         // at <= 6.5 / >= 8.5 bits per sample
-        const double lo = all_mono ? 28000.0 : pipelined ? 56000.0 : 52000.0;
-        const double hi = all_mono ? (pipelined ? 18000.0 : 14000.0) : pipelined ? 30000.0 : 20000.0;
+        const double lo = pipelined ? (all_mono ? 5000.0 : 10000.0) : (all_mono ? 28000.0 : 52000.0);
+        const double hi = pipelined ? 0.0 : (all_mono ? 14000.0 : 20000.0);
         const double t = rate <= 6.5 ? 0.0 : rate >= 8.5 ? 1.0 : (rate - 6.5) / 2.0;
         threshold = lo + (hi - lo) * t;
     }

@@ -269,10 +269,15 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  * clx_batch_results flushes by itself and returns the LAST submission's results.  Falls back to clx_batch_run for the kernel
  * selections that fill the machine with one run. */
 #ifndef CLX_SUBMIT_DEPTH
-#define CLX_SUBMIT_DEPTH 4
+#define CLX_SUBMIT_DEPTH 8      /* the most submissions any batch keeps in flight */
 #endif
 int  clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                       int32_t* d_out, void* stream);
+/* How many submissions THIS batch keeps in flight, i.e. how many output buffers to rotate over: 4 for the wave kernels, 8 for the
+ * lane kernels (a run of those is one serial chain per subframe on a fraction of the machine's registers: eight side by side fill
+ * it), 1 where a submission is a plain run. */
+int  clx_batch_submit_depth(const clx_batch* b);
+int  clx_batch_submit_lanes(const clx_batch* b);      /* 1: its pipelined submissions run the fused lane kernels */
 int  clx_batch_flush(clx_batch* b, void* stream);
 /* Blocks until the last run finished, then copies the per-frame results to host. */
 int  clx_batch_results(clx_batch* b, clx_frame_result* results);

@@ -34,20 +34,17 @@ def test_selection_follows_the_measurements():
 
 
 def test_selection_with_several_batches_in_flight():
-    """clx_batch_submit (profiles/r02_bench_configs_sweep_c.txt, columns `sub`): whole runs of the wave kernels overlap their
-    neighbours, so they stay the choice for longer than with one run at a time."""
+    """clx_batch_submit (profiles/r02_bench_configs_sweep_d.txt, columns `sub`): eight runs of the fused lane kernels side by side
+    fill the machine, so they are the choice unless the batches are small and of short codes."""
     p = dict(pipelined=True)
-    assert choose(24000, 1, 5.67, **p)[0] == "waves"                  # config 2: 0.349 (waves) against 0.456 ms
-    assert choose(32000, 1, 5.67, **p)[0] == "lanes"                  # 0.486 against 0.457
-    assert choose(24000, 2, 5.03, **p)[0] == "waves"                  # config 3: 0.737 against 0.933
-    assert choose(32000, 2, 5.03, **p) == ("lanes", "fused")          # 1.023 against 0.987
-    assert choose(8000, 2, 9.8, wide=True, **p)[0] == "waves"         # config 4: 1.094 against 1.287
-    assert choose(16000, 2, 9.8, wide=True, **p) == ("lanes", "split")  # 1.856 against 1.308
-    assert choose(10000, 2, 9.5, **p)[0] == "waves"                   # config 5: 0.823 against 1.135
-    assert choose(16000, 2, 9.5, **p)[0] == "lanes"                   # 1.216 against 1.178
-    for shape in ((10000, 1, 5.67), (10000, 2, 5.03), (32000, 2, 5.03), (2000, 2, 9.8, True), (8000, 2, 9.5), (32000, 2, 9.5)):
-        if choose(*shape, pipelined=True)[0] == "lanes":              # never the lane kernels where one run at a time takes the wave kernels
-            assert choose(*shape)[0] == "lanes"
+    assert choose(2500, 1, 5.67, **p)[0] == "waves"                   # config 2: 0.082 (waves) against 0.109 ms
+    assert choose(10000, 1, 5.67, **p)[0] == "lanes"                  # 0.167 against 0.129
+    assert choose(2500, 2, 5.03, **p)[0] == "waves"                   # config 3: 0.136 against 0.171
+    assert choose(10000, 2, 5.03, **p)[0] == "lanes"                  # 0.303 against 0.230
+    assert choose(1250, 2, 9.8, wide=True, **p)[0] == "lanes"         # config 4: 0.566 against 0.353
+    assert choose(10000, 2, 9.8, wide=True, **p)[0] == "lanes"        # 1.340 against 0.707
+    assert choose(1250, 2, 9.5, **p)[0] == "lanes"                    # config 5: 0.404 against 0.217
+    assert choose(10000, 2, 9.5, **p)[0] == "lanes"                   # 0.779 against 0.307
 
 
 def test_unknown_frame_lengths_take_the_middle():

@@ -5,7 +5,7 @@ Prints one line per (config, size): ms per step for every selection (run = one b
 SUBMIT_DEPTH in flight), after a bit-exactness check of each."""
 import os, sys, time
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # a hardware queue per internal stream of clx_batch_submit (bench.py does the same)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # a hardware queue per internal stream of clx_batch_submit (bench.py does the same)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

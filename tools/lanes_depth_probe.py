@@ -1,7 +1,7 @@
 """Whole runs of the lane kernels (fused build) in flight on streams of their own: ms per step over the number in flight.
 usage: GPU_MAX_HW_QUEUES=8 python tools/lanes_depth_probe.py [frames] [depths...]"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import claxon_amd as cx, synth

@@ -3,7 +3,7 @@ flight on internal streams) against plain runs; checks every output buffer bit f
 usage: python tools/pipe_probe.py [frames] [steps] [output buffers]"""
 import sys, time
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # a hardware queue per internal stream of clx_batch_submit (bench.py does the same)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # a hardware queue per internal stream of clx_batch_submit (bench.py does the same)
 import numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import claxon_amd as cx, synth

@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for NAME in $NAMES; do
   case $NAME in
     config5) ARGS="--workload config5 --total-frames 80000 --unique 4096 --shard-of 8 --shard-rank 3";;
+    config3_lanes) ARGS="--workload config3 --frames 10000 --path lanes-fused";;      # the fused lane kernels (what pipelined submissions run)
     *)       ARGS="--workload $NAME --frames 10000";;
   esac
   OUT=$REPO/gpurun_out/prof_r02_$NAME
