@@ -23,7 +23,7 @@ OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
 CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)
 ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16, PATH_WAVES, PATH_LANES, PCM_ON_DEVICE, LANES_FUSED, LANES_SPLIT = 1, 2, 4, 8, 16, 32, 64, 128
 K2_LATENCY, K2_THROUGHPUT = 256, 512
-SUBMIT_DEPTH = 8            # CLX_SUBMIT_DEPTH: the most submissions a Batch keeps in flight (Batch.submit_depth: this batch's)
+SUBMIT_DEPTH = 12           # CLX_SUBMIT_DEPTH: the most submissions a Batch keeps in flight (Batch.submit_depth: this batch's)
 
 
 class ClaxonError(RuntimeError):

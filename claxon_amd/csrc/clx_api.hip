@@ -685,8 +685,8 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     if (!d_arena || !d_out) { ctx->last_error = "null device pointer"; return CLX_API_ERROR; }
     if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
     // Which kernels (clx_select_path, `pipelined`): the wave kernels with the multi-wave predictor build, four submissions in
-    // flight; or the lane kernels, fused build, eight in flight -- a run of those is one serial chain per subframe on a fraction of
-    // the machine's registers, and eight of them side by side fill it.  The two-wave lane build and the one-wave predictor build
+    // flight; or the lane kernels, fused build, twelve in flight -- a run of those is one serial chain per subframe on a fraction of
+    // the machine's registers, and a dozen of them side by side fill it.  The two-wave lane build and the one-wave predictor build
     // gain nothing from company (measured, tools/bench_configs.py): forced by flag they are plain runs.
     bool want_lanes = submit_wants_lanes(b);
     if (want_lanes && (uint64_t)arena_len + 32ull >= (1ull << 32)) {      // (the lane kernels address the arena with 32 bits)

@@ -49,7 +49,7 @@ static inline long clx_plan_frames(const clx_frame_desc* frames, size_t n, const
 //                                                                                    no scan pass for the later channels)
 // and between the two lane builds the two-wave one while its workgroups still get a CU each (longer for 24-bit audio).
 // `pipelined`: the batch is one of several in flight (clx_batch_submit).  There a run of the fused lane kernels -- one serial chain
-// per subframe on a fraction of the machine's registers, 0.85-1.3 ms however few subframes -- has seven others beside it, and
+// per subframe on a fraction of the machine's registers, 0.85-1.3 ms however few subframes -- has eleven others beside it, and
 // the question is throughput: the lane kernels (fused build) unless the batches are small AND of short codes, where the wave
 // kernels' four in flight are ahead (measured with a hardware queue per stream, profiles/r02_bench_configs_sweep_d.txt):
 //   24-bit audio, or >= ~8.5 compressed bits per sample                               lanes always
