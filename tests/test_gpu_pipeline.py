@@ -1,5 +1,5 @@
-"""clx_batch_submit / clx_batch_flush: up to SUBMIT_DEPTH submissions in flight (whole runs on internal streams, each with its own
-descriptors and results) must give exactly what clx_batch_run gives -- the oracle's samples, statuses and end bits -- whatever the
+"""clx_batch_submit / clx_batch_flush: several submissions in flight (whole runs on internal streams, each with its own scratch
+buffers and results: four of the wave kernels, twelve of the fused lane kernels) must give exactly what clx_batch_run gives -- the oracle's samples, statuses and end bits -- whatever the
 caller does with its output buffers: a rotation over SUBMIT_DEPTH buffers, two alternating buffers or the same buffer every time
 (the library then waits for the earlier writer), runs and submissions mixed, with the CRC-16 kernel in the step, and for the
 kernel selections that fall back to plain runs."""
@@ -46,8 +46,9 @@ def check(w, out, res, ref, r, crc):
 
 
 @pytest.mark.parametrize("flags,crc", [(cx.PATH_WAVES | cx.K2_LATENCY, False), (cx.PATH_WAVES | cx.K2_LATENCY, True), (0, True),
-                                       (cx.PATH_WAVES | cx.K2_THROUGHPUT, True), (cx.PATH_LANES | cx.LANES_SPLIT, True)],
-                         ids=["waves", "waves-crc", "auto-crc", "waves-1w-crc", "lanes-crc"])
+                                       (cx.PATH_WAVES | cx.K2_THROUGHPUT, True), (cx.PATH_LANES | cx.LANES_SPLIT, True),
+                                       (cx.PATH_LANES | cx.LANES_FUSED, True), (cx.PATH_LANES | cx.LANES_FUSED, False)],
+                         ids=["waves", "waves-crc", "auto-crc", "waves-1w-crc", "lanes-crc", "lanes-fused-crc", "lanes-fused"])
 def test_submit_matches_run(setup, flags, crc):
     import torch
     ctx, w, descs, d_arena, ref, r = setup
