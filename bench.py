@@ -264,8 +264,8 @@ def main():
             cfg["with_crc16"] = {"value": round(samples_c / (ms_c * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
                                  "kernel_ms": {k: round(v, 4) for k, v in kc.items()},
                                  "note": "CLX_VERIFY_CRC16: every frame's CRC-16 footer checked on the device inside the step"}
-    if extras and world == 1 and args.workload == "config3" and 8 * 4 * w.total_samples < 16 * (1 << 30):
-        cfg["deep_queue"] = _deep_queue(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
+    if extras and world == 1 and args.workload == "config3" and w.pcm is not None and path_tag:
+        cfg["wave_kernels_pipelined"] = _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
     if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
         cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -311,34 +311,31 @@ def _kernel_ms(torch, batch, step, steps):
     return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
-def _deep_queue(torch, ctx, cx, w, descs, d_arena, dev, steps, depth=6):
-    """Throughput with `depth` independent batches of this workload in flight (one planned batch, stream and output buffer each),
-    decoded by the lane-per-subframe kernels: the instruction-efficient kernels, whose duration is one lane's serial chain, fill
-    the machine once enough subframes are in flight -- what a service that decodes many such batches at once would see.  Not
-    `value`: that keeps to consecutive batches of one caller."""
+def _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, steps):
+    """The same steps forced onto the OTHER kernel family: the wave-per-frame kernels, pipelined with their own depth (four in
+    flight).  What small batches of short codes run by default; here for comparison with `value`."""
     try:
+        b = ctx.plan(descs, w.out_offs, path=cx.PATH_WAVES)
+        depth = b.submit_depth
         outs = [torch.zeros(w.total_samples, dtype=torch.int32, device=dev) for _ in range(depth)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-        batches = [ctx.plan(descs, w.out_offs, path=cx.PATH_LANES | cx.LANES_FUSED) for _ in range(depth)]
+        stream = torch.cuda.current_stream(dev).cuda_stream
         torch.cuda.synchronize()
 
         def go(k):
             for i in range(k):
-                j = i % depth
-                batches[j].run(d_arena.data_ptr(), w.arena_len, outs[j].data_ptr(), streams[j].cuda_stream)
-        go(depth); torch.cuda.synchronize()
+                b.submit(d_arena.data_ptr(), w.arena_len, outs[i % depth].data_ptr(), stream)
+            b.flush(stream); torch.cuda.synchronize()
+        go(2 * depth)
         ref = torch.from_numpy(w.pcm).to(dev)
-        ok = all(bool(torch.equal(o, ref)) for o in outs) and all(bool(np.all(b.results()["status"] == 0)) for b in batches)
+        ok = all(bool(torch.equal(o, ref)) for o in outs) and bool(np.all(b.results()["status"] == 0))
         del ref
-        n = max(steps, 4 * depth)
-        t = time.perf_counter(); go(n); torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
-        for b in batches:
-            b.close()
+        t = time.perf_counter(); go(steps); dt = (time.perf_counter() - t) / steps
+        b.close()
         if not ok:
             return {"error": "not bit-exact"}
         return {"value": round(w.total_samples / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 4), "steps_in_flight": depth,
-                "kernels": "clx_k_scan + clx_k_lanes (+ clx_k_lanes_hi) + clx_k_finalize", "frac": round(w.algorithmic_bytes / dt / 1e9 / PEAK_GBS, 4),
-                "note": "%d batches of the step's workload in flight on %d streams, lane-per-subframe kernels; each batch alone takes ~0.9 ms" % (depth, depth)}
+                "kernels": "clx_k_residual + clx_k_predict16 (+ what it leaves, clx_k_predict_1w / _1w_hi / clx_k_predict)",
+                "frac": round(w.algorithmic_bytes / dt / 1e9 / PEAK_GBS, 4)}
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
