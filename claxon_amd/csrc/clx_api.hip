@@ -305,6 +305,10 @@ extern "C" void clx_batch_destroy(clx_batch* b);
 extern "C" int clx_create(int device, clx_ctx** out) {
     if (!out) return CLX_API_ERROR;
     *out = nullptr;
+    // A hardware queue per internal stream of clx_batch_submit (HIP's default of 4 per process makes them share).  The variable is
+    // read when the HIP runtime starts: this helps a process whose first HIP call is this one and changes nothing otherwise; a
+    // value that is already set is left alone.
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CLX_API_ERROR;
     hipDeviceProp_t prop;

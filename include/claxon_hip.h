@@ -264,7 +264,8 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  * occupies a fraction of the machine's registers for 0.9-1.3 ms, and a dozen of them side by side fill it --; the wave kernels,
  * four in flight, for small batches of short codes.  The internal streams want a hardware queue each: set
  * GPU_MAX_HW_QUEUES=16 in the environment before the HIP runtime starts (its default of 4 makes them share queues:
- * 0.32 instead of 0.18 ms per 10 000 stereo frames).
+ * 0.32 instead of 0.18 ms per 10 000 stereo frames; clx_create sets it when it is unset, which helps when clx_create is the
+ * process's first HIP call).
  * A submission starts after everything queued on `stream` so far.  Give the submissions in flight different `d_out` buffers,
  * i.e. rotate over clx_batch_submit_depth(b) of them (re-using a buffer is legal: the submission then waits for the earlier
  * one that writes it).  Work enqueued on `stream` after clx_batch_flush sees every submission finished; clx_batch_results
