@@ -596,8 +596,8 @@ class Batch:
         self.ctx._check(st)
 
     def submit(self, d_arena_ptr, arena_len, d_out_ptr, stream=0):
-        """Pipelined run (clx_batch_submit): up to SUBMIT_DEPTH submissions in flight on internal streams.  Rotate over
-        SUBMIT_DEPTH output buffers; flush() (or results()) before reading them."""
+        """Pipelined run (clx_batch_submit): up to self.submit_depth submissions in flight on internal streams.  Rotate over
+        that many output buffers; flush() (or results()) before reading them."""
         st = lib().clx_batch_submit(self._h, C.c_void_p(d_arena_ptr), arena_len, C.c_void_p(d_out_ptr),
                                     C.c_void_p(stream) if stream else None)
         self.ctx._check(st)
