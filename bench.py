@@ -48,9 +48,21 @@ def main():
     ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="time steps that do not overlap (clx_batch_run instead of clx_batch_submit)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (CRC-16 step, host-buffer rates)")
-    ap.add_argument("--path", choices=["auto", "waves", "lanes", "lanes-fused"], default="auto", help="kernel path (default: library's choice)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (unverified step, host-buffer rates)")
+    ap.add_argument("--no-crc", action="store_true", help="time the step WITHOUT the CRC-16 check (secondary figure; `value` verifies by default)")
+    ap.add_argument("--path", choices=["auto", "waves", "lanes", "lanes-fused", "lanes-general"], default="auto",
+                    help="kernel path (default: library's choice); lanes-general = the fused lane build without the 16-bit tier clx_k_lean")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process group backend for the barrier and the MAX / SUM reductions (nccl = RCCL)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no decode: only the launcher, the rank plan and the cross-rank reductions (CPU, gloo); prints a line with value null")
     args = ap.parse_args()
+
+    # `--gpus N` by itself starts the N ranks (one process per GPU); under an external launcher (torchrun: WORLD_SIZE is set)
+    # this process is one of its ranks already
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.shard_of:
+        sys.exit(_spawn_ranks(args.gpus))
+    if args.launcher_selftest:
+        return _launcher_selftest(args)
 
     import torch
     import claxon_amd as cx
@@ -67,7 +79,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     ctx = cx.Context(local_rank, wait_s=120)   # waits for the device to appear; raises if there is none
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -75,34 +90,7 @@ def main():
     # ---- this rank's share of the job's frame index
     t_gen = time.time()
     sh_world, sh_rank = (args.shard_of, args.shard_rank) if (args.shard_of and world == 1) else (world, rank)
-    shard_info = {"ranks": sh_world, "rank": sh_rank}
-    expected = None                                  # (unique pcm on the device, index of each local frame's unique frame)
-    if args.workload == "config5":
-        ts = synth.config5_tiled(args.total_frames, args.unique)
-        ranges = shard.balanced_ranges(ts.weights(), sh_world)
-        lo, hi = ranges[sh_rank]
-        w = ts.slice(lo, hi)
-        wsum = [int(ts.weights()[a:b].sum()) for a, b in ranges]
-        shard_info.update({"plan": "shard.balanced_ranges over algorithmic bytes of %d frames (%d unique)" % (ts.total, ts.unique.n),
-                           "range": [int(lo), int(hi)], "imbalance": round(max(wsum) / (sum(wsum) / len(wsum)) - 1.0, 5)})
-        workload_name = ("BASELINE configs[4]: %d mixed real-world-shaped stereo 16-bit frames (orders 0-12, all channel modes, "
-                         "%d unique frames tiled with distinct frame numbers / CRCs), rank share %d frames"
-                         % (ts.total, ts.unique.n, hi - lo))
-        scaling = "strong"
-    else:
-        lo, hi = sh_rank * args.frames, (sh_rank + 1) * args.frames
-        gen = {"config2": synth.config2, "config3": synth.config3, "config4": synth.config4}[args.workload]
-        w = _seeded(synth, gen, args.frames, lo)
-        # the ranges are what balanced_ranges gives for the job's index: every frame of these shapes has the same decoded size
-        # and (to within a percent) the same compressed size; the check below makes that an assertion, not a belief
-        shard_info.update({"plan": "contiguous ranges of %d frames of one index of %d (frame g seeded by g)" % (args.frames, sh_world * args.frames),
-                           "range": [int(lo), int(hi)]})
-        workload_name = {
-            "config2": "BASELINE configs[1]: %d mono 16-bit subframes/GPU, bs 4096, FIXED order 2, Rice k=4, one partition",
-            "config3": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 (coefficient precision 12-14), Rice partition order 4, optimal k",
-            "config4": "BASELINE configs[3]: %d stereo 24-bit frames/GPU, bs 4096, LPC order 32, mixed partition orders 0-7, Rice2, wasted bits",
-        }[args.workload] % args.frames
-        scaling = "weak"
+    w, ts, shard_info, workload_name, scaling = _rank_share(args, synth, shard, sh_world, sh_rank)
     gen_s = time.time() - t_gen
     if w.bare_subframes:
         descs = cx.descs_for_subframes(w.offs, w.block_sizes, w.bps)
@@ -111,13 +99,20 @@ def main():
 
     d_arena = torch.from_numpy(w.arena).to(dev)
     d_out = torch.zeros(w.total_samples, dtype=torch.int32, device=dev)
-    path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES, "lanes-fused": cx.PATH_LANES | cx.LANES_FUSED}[args.path]
-    batch = ctx.plan(descs, w.out_offs, verify_crc=False, path=path)
+    path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES, "lanes-fused": cx.PATH_LANES | cx.LANES_FUSED,
+            "lanes-general": cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL}[args.path]
+    # `value` is the VERIFIED step: every frame's CRC-16 footer is checked on the device inside it, as the reference does for every
+    # frame it decodes (frame.rs:752-763) and as the cpu_baseline leg does; bare subframes (config 2) have no footer
+    with_crc = (not w.bare_subframes) and not args.no_crc
+    batch = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=path)
     # consecutive steps are submitted with up to batch.submit_depth of them in flight (clx_batch_submit: each step a whole run on
     # an internal stream of the library), so they rotate over that many output buffers -- when there is room for them
     depth = batch.submit_depth
     pipelined = (not args.no_pipeline) and depth > 1 and depth * 4 * w.total_samples < 64 * (1 << 30)
     outs = [d_out] + ([torch.zeros(w.total_samples, dtype=torch.int32, device=dev) for _ in range(depth - 1)] if pipelined else [])
+    # the steps in flight read DISTINCT copies of the compressed input (same bytes, different addresses), so that no step finds the
+    # input of its neighbour in a cache: every step's compressed bytes come from HBM, as roofline.achieved assumes
+    arenas = [d_arena] + ([d_arena.clone() for _ in range(depth - 1)] if pipelined and depth * w.arena.size < 8 * (1 << 30) else [])
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def barrier():
@@ -130,7 +125,7 @@ def main():
         t0 = time.perf_counter()
         if pipe:
             for i in range(steps):
-                b.submit(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
+                b.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
             b.flush(stream)
         else:
             for _ in range(steps):
@@ -140,21 +135,21 @@ def main():
 
     for i in range(max(args.warmup, len(outs) if pipelined else 0)):
         if pipelined:
-            batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
+            batch.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
         else:
             batch.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
     batch.flush(stream)
     torch.cuda.synchronize()
 
     # ---- parity gate before anything is timed: statuses OK and bit-exact vs the source PCM (every output buffer in use)
+    def outputs_exact(bufs):
+        if w.pcm is not None:
+            ref_pcm = torch.from_numpy(w.pcm).to(dev)
+            return all(bool(torch.equal(o, ref_pcm)) for o in bufs)
+        return all(_tiled_equal(torch, o, w, ts.unique, dev) for o in bufs)
+
     res = batch.results()
-    if w.pcm is not None:
-        ref_pcm = torch.from_numpy(w.pcm).to(dev)
-        same = all(bool(torch.equal(o, ref_pcm)) for o in outs)
-        del ref_pcm
-    else:
-        same = all(_tiled_equal(torch, o, w, ts.unique, dev) for o in outs)
-    if not (bool(np.all(res["status"] == 0)) and same):
+    if not (bool(np.all(res["status"] == 0)) and outputs_exact(outs)):
         raise SystemExit("bench: decode is not bit-exact; refusing to report a number")
 
     # ---- per-kernel durations: HIP events recorded by the library on the launch stream, around each of its kernels (steps one at
@@ -165,24 +160,31 @@ def main():
     if pipelined and batch.submit_lanes and "clx_k_lanes" not in kernel_ms:
         # the pipelined steps run the fused lane kernels while one run at a time takes the wave kernels: the roofline block is
         # about the kernels of the TIMED steps, so their durations are taken from a batch forced onto them
-        bl = ctx.plan(descs, w.out_offs, verify_crc=False, path=cx.PATH_LANES | cx.LANES_FUSED)
+        bl = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=cx.PATH_LANES | cx.LANES_FUSED)
         kernel_ms = _kernel_ms(torch, bl, lambda: bl.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
         bl.close()
         path_tag = "_lanes"
 
-    elapsed = timed(batch, args.steps, pipelined)
+    # the timed steps write into buffers that were cleared after the gate: what is compared afterwards is what THEY wrote
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    elapsed_local = elapsed = timed(batch, args.steps, pipelined)
     # whole-job figures: MAX elapsed over ranks, SUM of samples per step, SUM of failed frames (must be 0)
     res = batch.results()
+    if not outputs_exact(outs[:min(len(outs), args.steps)]):
+        raise SystemExit("bench: a timed step did not reproduce the source PCM; refusing to report a number")
     elapsed, samples_all, n_bad = shard.reduce_job(dist if world > 1 else None, elapsed, w.total_samples,
                                                    int((res["status"] != 0).sum()), device=dev)
     if n_bad:
         raise SystemExit("bench: %d frames failed to decode in the timed region" % n_bad)
     ms_per_step = 1e3 * elapsed / args.steps
     value = samples_all / (ms_per_step * 1e-3) / 1e6
-    if world > 1:      # how even the shares were (algorithmic bytes): max over ranks / mean
-        t = torch.tensor([float(w.algorithmic_bytes)], dtype=torch.float64, device=dev)
-        mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        shard_info["imbalance"] = round(float(mx.item()) / (float(t.item()) / world) - 1.0, 5)
+    # every rank's own step time and share (all_gather of three numbers): how even the ranks were
+    per_rank = _gather_floats(dist if world > 1 else None, [1e3 * elapsed_local / args.steps, float(w.algorithmic_bytes), float(w.n)], world, device=dev)
+    if world > 1:      # algorithmic bytes: max over ranks / mean
+        algs = [r[1] for r in per_rank]
+        shard_info["imbalance"] = round(max(algs) / (sum(algs) / len(algs)) - 1.0, 5)
 
     path_ms = float(sum(kernel_ms.values()))             # all kernels of the path, one after the other (SURVEY section 8d's t_kernel)
     dom_name = max(kernel_ms, key=kernel_ms.get)
@@ -222,8 +224,13 @@ def main():
     cfg = {"workload": workload_name, "frames_this_rank": w.n, "samples_per_step": samples_all,
            "compressed_bytes_this_rank": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
            "parallelism": "one frame index sharded over %d GPU(s), no collective on the data path" % world, "shard": shard_info,
-           "bit_exact": True, "crc16_in_step": False, "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
-           "steps_in_flight": depth if pipelined else 1, "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
+           "per_rank": [{"rank": i, "ms_per_step": round(r[0], 4), "frames": int(r[2])} for i, r in enumerate(per_rank)],
+           "process_group": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None, "world_size": world},
+           "launcher": os.environ.get("CLX_BENCH_LAUNCHER", "external (WORLD_SIZE in the environment)" if world > 1 else "single process"),
+           "bit_exact": True, "bit_exact_checked": "every output buffer vs the source PCM before the timed steps, and again -- on buffers cleared in between -- after them",
+           "crc16_in_step": bool(with_crc), "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
+           "steps_in_flight": depth if pipelined else 1, "distinct_input_copies_in_flight": len(arenas),
+           "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
     out = {
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -240,30 +247,22 @@ def main():
                                      "frac": round(alg_bytes / (ms_1 * 1e-3) / 1e9 / PEAK_GBS, 4),
                                      "note": "clx_batch_run (the kernels it selects: roofline.kernel_ms_one_step_at_a_time): a batch's latency; `value` is the throughput of consecutive batches with up to %d in flight" % depth}
     batch.close()                              # (its internal streams give their hardware queues back)
-    if not w.bare_subframes and not args.no_extras:
-        # ---- the same step with every frame's CRC-16 verified on the device (frame.rs:752-763: the reference always does);
-        #      this is the figure that corresponds to the cpu_baseline leg, which also verifies
-        bc = ctx.plan(descs, w.out_offs, verify_crc=True, path=path)
+    if with_crc and not args.no_extras:
+        # ---- the same step WITHOUT the CRC-16 check (what earlier rounds reported as `value`): secondary
+        bc = ctx.plan(descs, w.out_offs, verify_crc=False, path=path)
         bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
         if pipelined:                          # (the first submissions set the internal streams and buffers up)
             for i in range(len(outs)):
-                bc.submit(d_arena.data_ptr(), w.arena_len, outs[i].data_ptr(), stream)
+                bc.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, outs[i].data_ptr(), stream)
         torch.cuda.synchronize()
         rc = bc.results()
         el_c = timed(bc, args.steps, pipelined)
         el_c, samples_c, bad_c = shard.reduce_job(dist if world > 1 else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=dev)
-        if pipelined and bc.submit_lanes and path_tag:      # (as above: the kernels of the timed steps)
-            bcl = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED)
-            kc = _kernel_ms(torch, bcl, lambda: bcl.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
-            bcl.close()
-        else:
-            kc = _kernel_ms(torch, bc, lambda: bc.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
         bc.close()
         if bad_c == 0:
             ms_c = 1e3 * el_c / args.steps
-            cfg["with_crc16"] = {"value": round(samples_c / (ms_c * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
-                                 "kernel_ms": {k: round(v, 4) for k, v in kc.items()},
-                                 "note": "CLX_VERIFY_CRC16: every frame's CRC-16 footer checked on the device inside the step"}
+            cfg["without_crc16"] = {"value": round(samples_c / (ms_c * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
+                                    "note": "the same steps with the CRC-16 footer check left out (BENCH_r01 / r02's `value`); `value` verifies"}
     if extras and world == 1 and args.workload == "config3" and w.pcm is not None and path_tag:
         cfg["wave_kernels_pipelined"] = _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
     if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
@@ -275,6 +274,136 @@ def main():
     batch.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _rank_share(args, synth, shard, sh_world, sh_rank, generate=True):
+    """This rank's share of the job's ONE frame index: (workload or None, tiled stream or None, shard_info, workload name,
+    scaling).  `generate=False` (the launcher self-test) plans without encoding any frame of config2/3/4."""
+    shard_info = {"ranks": sh_world, "rank": sh_rank}
+    ts = None
+    if args.workload == "config5":
+        ts = synth.config5_tiled(args.total_frames, args.unique)
+        ranges = shard.balanced_ranges(ts.weights(), sh_world)
+        lo, hi = ranges[sh_rank]
+        w = ts.slice(lo, hi) if generate else None
+        wsum = [int(ts.weights()[a:b].sum()) for a, b in ranges]
+        shard_info.update({"plan": "shard.balanced_ranges over algorithmic bytes of %d frames (%d unique)" % (ts.total, ts.unique.n),
+                           "range": [int(lo), int(hi)], "imbalance": round(max(wsum) / (sum(wsum) / len(wsum)) - 1.0, 5)})
+        workload_name = ("BASELINE configs[4]: %d mixed real-world-shaped stereo 16-bit frames (orders 0-12, all channel modes, "
+                         "%d unique frames tiled with distinct frame numbers / CRCs), rank share %d frames"
+                         % (ts.total, ts.unique.n, hi - lo))
+        scaling = "strong"
+    else:
+        lo, hi = sh_rank * args.frames, (sh_rank + 1) * args.frames
+        gen = {"config2": synth.config2, "config3": synth.config3, "config4": synth.config4}[args.workload]
+        w = _seeded(synth, gen, args.frames, lo) if generate else None
+        # the ranges are what balanced_ranges gives for the job's index: every frame of these shapes has the same decoded size
+        # and (to within a percent) the same compressed size; the measured imbalance is carried in the line
+        shard_info.update({"plan": "contiguous ranges of %d frames of one index of %d (frame g seeded by g)" % (args.frames, sh_world * args.frames),
+                           "range": [int(lo), int(hi)]})
+        workload_name = {
+            "config2": "BASELINE configs[1]: %d mono 16-bit subframes/GPU, bs 4096, FIXED order 2, Rice k=4, one partition",
+            "config3": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 (coefficient precision 12-14), Rice partition order 4, optimal k",
+            "config4": "BASELINE configs[3]: %d stereo 24-bit frames/GPU, bs 4096, LPC order 32, mixed partition orders 0-7, Rice2, wasted bits",
+        }[args.workload] % args.frames
+        scaling = "weak"
+    return w, ts, shard_info, workload_name, scaling
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start one process per GPU (rank r on device r), each a copy of this
+    command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment -- exactly what
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` would hand them.  Rank 0 prints the JSON line on
+    this process's stdout; the other ranks' stdout goes to stderr.  Returns the first non-zero exit code (the others are stopped)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": os.environ.get("MASTER_ADDR", "127.0.0.1"), "MASTER_PORT": port,
+                    "CLX_BENCH_LAUNCHER": "bench.py --gpus %d (self-spawned)" % n})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:           # a failed rank would leave the others waiting at a barrier
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def _launcher_selftest(args):
+    """The N-rank bookkeeping of this file without any decode (CPU; `--backend gloo`): the launcher's environment, the rank plan
+    (`_rank_share`), the barrier, the MAX / SUM reductions and the imbalance figure, with made-up elapsed times (1 + rank ms per
+    step) and the planned sample counts.  Prints a line shaped like the bench line with `value` null and `selftest` true."""
+    import torch
+    import torch.distributed as dist
+    import synth
+    from claxon_amd import shard
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, ts, shard_info, workload_name, scaling = _rank_share(args, synth, shard, world, rank, generate=(args.workload == "config5"))
+    lo, hi = shard_info["range"]
+    if w is not None:
+        samples, alg = w.total_samples, w.algorithmic_bytes
+    else:
+        ch = 1 if args.workload == "config2" else 2
+        samples, alg = (hi - lo) * ch * 4096, (hi - lo) * ch * 4096 * 4
+    if world > 1:
+        dist.barrier()
+    elapsed, samples_all, n_bad = shard.reduce_job(dist if world > 1 else None, 1e-3 * (1 + rank) * args.steps, samples, 0)
+    per_rank = _gather_floats(dist if world > 1 else None, [1.0 + rank, float(alg), float(lo), float(hi)], world)
+    algs = [r[1] for r in per_rank]
+    shard_info["imbalance"] = round(max(algs) / (sum(algs) / len(algs)) - 1.0, 5)
+    if rank == 0:
+        print(json.dumps({"metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames", "value": None, "selftest": True,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                          "scaling": scaling, "config": {"workload": workload_name, "samples_per_step": samples_all, "shard": shard_info,
+                                                         "per_rank": [{"rank": i, "ms_per_step": r[0], "range": [int(r[2]), int(r[3])]} for i, r in enumerate(per_rank)],
+                                                         "process_group": {"backend": "gloo", "world_size": world},
+                                                         "launcher": os.environ.get("CLX_BENCH_LAUNCHER", "external (WORLD_SIZE in the environment)" if world > 1 else "single process")}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def _gather_floats(dist, vals, world, device=None):
+    """Every rank's list of floats, on every rank: [[rank 0's], [rank 1's], ...] (all_gather of one small tensor)."""
+    import torch
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    if dist is None or world == 1:
+        return [t.tolist()]
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
 
 
 def _seeded(synth, gen, n, first):
@@ -520,7 +649,7 @@ def _cpu_baseline(w):
             "sample": "the first %d frames of the step's workload (%.1f Msamples per pass), `passes` passes per run (>= 0.5 s timed each); "
                       "pooled, pre-warmed threads that take 4 frames at a time off a shared counter (first_pass_value: the single calibration "
                       "pass before it; cgroup_throttled_ms: CPU time the container's quota withheld during the run); includes Claxon's per-byte CRC-16 and "
-                      "the CRC-8 / CRC-16 checks -- compare with config.with_crc16 (the GPU step that verifies too)" % (n, sample_msamples)}
+                      "the CRC-8 / CRC-16 checks, like `value` (config.crc16_in_step)" % (n, sample_msamples)}
 
 
 def _pmc_traffic(workload, frames):

@@ -23,6 +23,7 @@ OK, IO_ERROR, FORMAT_ERROR, UNSUPPORTED, END_OF_STREAM, API_ERROR = range(6)
 CH_INDEPENDENT, CH_LEFT_SIDE, CH_RIGHT_SIDE, CH_MID_SIDE = range(4)
 ARENA_ON_DEVICE, OUT_ON_DEVICE, VERIFY_CRC16, PATH_WAVES, PATH_LANES, PCM_ON_DEVICE, LANES_FUSED, LANES_SPLIT = 1, 2, 4, 8, 16, 32, 64, 128
 K2_LATENCY, K2_THROUGHPUT = 256, 512
+LANES_GENERAL = 1024        # the fused lane build without clx_k_lean (the 16-bit tier): every group through the general kernels
 SUBMIT_DEPTH = 12           # CLX_SUBMIT_DEPTH: the most submissions a Batch keeps in flight (Batch.submit_depth: this batch's)
 
 
@@ -95,7 +96,7 @@ EXPORTS = [
 
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_lanes.hip", "clx_device.h", "clx_plan.h",
+    srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_lanes.hip", "clx_lean.hip", "clx_device.h", "clx_plan.h",
                                             os.path.join("intrin", "clx_intrin.h"), os.path.join("intrin", "clx_k2_dot2.h"), os.path.join("host", "claxon.hpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "claxon_hip.h"))
     if (not force and os.path.exists(LIB_PATH)

@@ -7,6 +7,7 @@
 // in this library: without a usable HIP device every decode entry point fails with CLX_API_ERROR.
 #include "clx_kernels.hip"
 #include "clx_lanes.hip"
+#include "clx_lean.hip"
 
 #include <algorithm>
 #include <cstdio>
@@ -243,7 +244,8 @@ struct clx_batch {
     clx_path_choice choice_submit = { false, true };   // for pipelined submissions (clx_batch_submit)
     bool all_narrow_aligned = false;                   // every frame: bps <= 16, rows 16-byte aligned and a multiple of 4 samples long
     clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
-    size_t cap[9] = {};              // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits
+    hipEvent_t ev_up = nullptr; bool up_in_flight = false; // recorded behind the staging's H2D copy: the staging is rewritten only after it
+    size_t cap[10] = {};             // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits, d_taken
     size_t n = 0;
     uint64_t n_slots = 0;
     uint32_t flags = 0;
@@ -262,6 +264,7 @@ struct clx_batch {
     uint32_t* d_sf_start = nullptr;
     uint32_t* d_errkey = nullptr;
     uint64_t* d_endbits = nullptr;
+    uint32_t* d_taken = nullptr;     // per group of 64 slots: the generation number of the run in which clx_k_lean decoded it
     bool profiling = false;
     enum { kMaxKernels = 8 };
     hipEvent_t ev[kMaxKernels + 1] = {};
@@ -279,6 +282,7 @@ struct clx_batch {
         clx_sf_desc* d_sfd = nullptr;            // flight 0 uses the batch's own buffers
         clx_frame_result* d_results = nullptr;
         uint32_t* d_sf_start = nullptr; uint32_t* d_errkey = nullptr; uint64_t* d_endbits = nullptr;   // lane kernels' scratch
+        uint32_t* d_taken = nullptr; uint32_t gen = 0;     // groups clx_k_lean took (marked with the run's generation number, never cleared)
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
         hipEvent_t ev_rice = nullptr, ev_side = nullptr;   // Rice stage done | the submission's kernels on side_stream done
         bool side_pending = false, side_recorded = false;
@@ -305,10 +309,6 @@ extern "C" void clx_batch_destroy(clx_batch* b);
 extern "C" int clx_create(int device, clx_ctx** out) {
     if (!out) return CLX_API_ERROR;
     *out = nullptr;
-    // A hardware queue per internal stream of clx_batch_submit (HIP's default of 4 per process makes them share).  The variable is
-    // read when the HIP runtime starts: this helps a process whose first HIP call is this one and changes nothing otherwise; a
-    // value that is already set is left alone.
-    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CLX_API_ERROR;
     hipDeviceProp_t prop;
@@ -354,6 +354,7 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_sf_start) (void)hipFree(b->d_sf_start);
     if (b->d_errkey) (void)hipFree(b->d_errkey);
     if (b->d_endbits) (void)hipFree(b->d_endbits);
+    if (b->d_taken) (void)hipFree(b->d_taken);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
     for (int i = 0; i < clx_batch::kDepth; ++i) {
@@ -368,7 +369,9 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
         if (i != 0 && F.d_sf_start) (void)hipFree(F.d_sf_start);
         if (i != 0 && F.d_errkey) (void)hipFree(F.d_errkey);
         if (i != 0 && F.d_endbits) (void)hipFree(F.d_endbits);
+        if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
     }
+    if (b->ev_up) { (void)hipEventSynchronize(b->ev_up); (void)hipEventDestroy(b->ev_up); }
     if (b->h_up) (void)hipHostFree(b->h_up);
     delete b;
 }
@@ -384,7 +387,13 @@ template <typename T> bool grow(clx_ctx* ctx, T** p, size_t* cap, size_t need, c
     return true;
 }
 // (Re)plan `b` for a list of frames: host-side planning, kernel selection, device buffers (reused when they are large enough).
+int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags);
 int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
+    const int st = batch_plan_(b, frames, n, out_sample_offsets, flags);
+    if (st != CLX_OK) { b->n = 0; b->n_slots = 0; b->n_multi = 0; b->planned_arena_len = (size_t)-1; }      // a failed plan leaves an empty batch, not a half-updated one
+    return st;
+}
+int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
     clx_ctx* ctx = b->ctx;
     b->n = n; b->flags = flags;
     b->h_descs.assign(frames, frames + n);
@@ -429,6 +438,8 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
             !grow(ctx, &b->d_sf_start, &b->cap[6], ns * sizeof(uint32_t), "hipMalloc sf_start") ||
             !grow(ctx, &b->d_errkey, &b->cap[7], nf * sizeof(uint32_t), "hipMalloc errkey") ||
             !grow(ctx, &b->d_endbits, &b->cap[8], nf * sizeof(uint64_t), "hipMalloc endbits") ||
+            !grow(ctx, &b->d_taken, &b->cap[9], ((ns + 63) / 64) * sizeof(uint32_t), "hipMalloc taken") ||
+            !hip_ok(ctx, hipMemset(b->d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "memset taken") ||
             !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
             !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) return CLX_API_ERROR;
     }
@@ -440,6 +451,8 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
         if (i != 0 && F.d_sf_start) (void)hipFree(F.d_sf_start);
         if (i != 0 && F.d_errkey) (void)hipFree(F.d_errkey);
         if (i != 0 && F.d_endbits) (void)hipFree(F.d_endbits);
+        if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
+        F.d_taken = nullptr; F.gen = 0;
         F.d_sfd = nullptr; F.d_results = nullptr; F.d_sf_start = nullptr; F.d_errkey = nullptr; F.d_endbits = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.out = nullptr;   // (side_recorded stays: the event is still there)
     }
     b->last_slot = -1;
@@ -482,15 +495,20 @@ int upload_plan(clx_batch* b, size_t arena_len, hipStream_t stream) {
     // staged in pinned memory that lives with the batch: the copy is asynchronous and nothing has to be waited for here (the
     // next re-plan of this batch comes after the caller has waited for its stream: clx_batch_run's contract)
     if (b->up_cap < b->n) {
+        if (b->up_in_flight) { HIP_TRY(ctx, hipEventSynchronize(b->ev_up)); b->up_in_flight = false; }
         if (b->h_up) (void)hipHostFree(b->h_up);
         b->h_up = nullptr; b->up_cap = 0;
         HIP_TRY(ctx, hipHostMalloc((void**)&b->h_up, (b->n + b->n / 4 + 1) * sizeof(clx_dev_frame), hipHostMallocDefault));
         b->up_cap = b->n + b->n / 4 + 1;
     }
-    if (b->planned_arena_len != (size_t)-1) HIP_TRY(ctx, hipStreamSynchronize(stream));      // (a copy of the staging may be in flight)
+    // (a copy out of the staging may still be in flight -- on whichever stream the previous upload went to)
+    if (b->up_in_flight) { HIP_TRY(ctx, hipEventSynchronize(b->ev_up)); b->up_in_flight = false; }
     std::memcpy(b->h_up, b->h_frames.data(), b->n * sizeof(clx_dev_frame));
     clx_plan_limits(b->h_descs.data(), b->n, arena_len, b->h_up);
     HIP_TRY(ctx, hipMemcpyAsync(b->d_frames, b->h_up, b->n * sizeof(clx_dev_frame), hipMemcpyHostToDevice, stream));
+    if (!b->ev_up) HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(b->ev_up, stream));
+    b->up_in_flight = true;
     b->planned_arena_len = arena_len;
     return CLX_OK;
 }
@@ -508,7 +526,7 @@ int use_lanes(clx_batch* b, size_t arena_len) {
 // subframes), the per-frame results, the CRC.  `sf_start`, `errkey`, `endbits`: the run's scratch (a set per flight in flight).
 template <typename Mark>
 bool launch_lanes(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, uint32_t* sf_start, uint32_t* errkey, uint64_t* endbits,
-                  clx_frame_result* d_results, bool split, hipStream_t stream, Mark&& mark) {
+                  clx_frame_result* d_results, bool split, hipStream_t stream, Mark&& mark, uint32_t* taken, uint32_t gen) {
     clx_ctx* ctx = b->ctx;
     if (!hip_ok(ctx, hipMemsetAsync(errkey, 0xff, b->n * sizeof(uint32_t), stream), "memset errkey") ||
         !hip_ok(ctx, hipMemsetAsync(sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream), "memset sf_start")) return false;
@@ -517,19 +535,29 @@ bool launch_lanes(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int3
         hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi, sf_start, errkey);
     }
-    if (!mark(split ? "clx_k_lanes2" : "clx_k_lanes")) return false;       // (clx_k_lanes: + clx_k_lanes_hi, its order > 12 twin)
     if (!split) {
+        // the 16-bit tier first: it marks the groups it decodes with this run's generation number, the general kernels skip them
+        const bool lean = !(b->flags & CLX_LANES_GENERAL) && taken != nullptr;
+        if (lean) {
+            if (!mark("clx_k_lean")) return false;
+            hipLaunchKernelGGL(clx_k_lean, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
+                               (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump, taken, gen);
+        }
+        if (!mark("clx_k_lanes")) return false;             // (+ clx_k_lanes_hi, its order > 12 twin)
         hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump);
+                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump, (const uint32_t*)(lean ? taken : nullptr), gen);
         hipLaunchKernelGGL(clx_k_lanes_hi, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump);
+                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump, (const uint32_t*)(lean ? taken : nullptr), gen);
     }
-    else
+    else {
+        if (!mark("clx_k_lanes2")) return false;
         hipLaunchKernelGGL(clx_k_lanes2, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_arena, alloc_len,
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
                            (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump);
+    }
     if (!mark("clx_k_finalize")) return false;
     hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
                        (const clx_dev_frame*)b->d_frames, (const uint32_t*)errkey, (const uint64_t*)endbits, (uint32_t)b->n, d_results);
@@ -642,7 +670,9 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         // the two-wave (latency) build while its workgroups get a CU each (0.50 ms against 1.00 ms at 20k subframes), the fused
         // single-wave (throughput) build beyond (1.28 against 1.34 ms at 48k subframes); CLX_LANES_FUSED / CLX_LANES_SPLIT force one
         const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false : b->choice.lanes_split;
-        if (!launch_lanes(b, d_arena, alloc_len, d_out, b->d_sf_start, b->d_errkey, b->d_endbits, b->d_results, split, stream, mark)) return CLX_API_ERROR;
+        clx_batch::Flight& F0 = b->flight[0];
+        if (++F0.gen == 0u) { HIP_TRY(ctx, hipMemsetAsync(b->d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), stream)); F0.gen = 1u; }
+        if (!launch_lanes(b, d_arena, alloc_len, d_out, b->d_sf_start, b->d_errkey, b->d_endbits, b->d_results, split, stream, mark, b->d_taken, F0.gen)) return CLX_API_ERROR;
     } else {
         // (K1 writes every slot of every frame on every run; the slots that only pad a stereo pair to an even index are cleared once)
         clx_batch::Flight& F0 = b->flight[0];
@@ -724,6 +754,13 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
                 HIP_TRY(ctx, hipMalloc((void**)&F.d_endbits, nf * sizeof(uint64_t)));
             }
         }
+        if (!F.d_taken) {
+            if (slot == 0) F.d_taken = b->d_taken;
+            else {
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_taken, ((ns + 63) / 64) * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMemset(F.d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)));
+            }
+        }
     } else {
         if (!b->side_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
         if (!F.d_sfd) {
@@ -748,7 +785,8 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     if (F.side_recorded) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_side, 0));
     const auto no_mark = [](const char*) { return true; };
     if (want_lanes) {
-        if (!launch_lanes(b, d_arena, alloc_len, d_out, F.d_sf_start, F.d_errkey, F.d_endbits, F.d_results, false, F.stream, no_mark)) return CLX_API_ERROR;
+        if (++F.gen == 0u) { HIP_TRY(ctx, hipMemsetAsync(F.d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t), F.stream)); F.gen = 1u; }
+        if (!launch_lanes(b, d_arena, alloc_len, d_out, F.d_sf_start, F.d_errkey, F.d_endbits, F.d_results, false, F.stream, no_mark, F.d_taken, F.gen)) return CLX_API_ERROR;
         F.side_pending = false;
     } else {
         if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, ns * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
@@ -781,6 +819,7 @@ extern "C" int clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void*
     if (!d_planar || !d_pcm || sample_bytes < 1u || sample_bytes > 4u) { ctx->last_error = "clx_batch_interleave: bad argument"; return CLX_API_ERROR; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : (b->last_stream ? b->last_stream : ctx->stream);
+    if (wait_flights(b, stream) != CLX_OK) return CLX_API_ERROR;       // pipelined submissions still writing d_planar / their results (no-op when none)
     hipLaunchKernelGGL(clx_k_interleave, dim3((unsigned)b->n), dim3(256), 0, stream, d_planar,
                        (const clx_dev_frame*)b->d_frames, (const clx_frame_result*)(b->last_slot > 0 ? b->flight[b->last_slot].d_results : b->d_results), (uint32_t)b->n,
                        (uint8_t*)d_pcm, sample_bytes);
@@ -987,7 +1026,7 @@ extern "C" int clx_decode_frames_stream(clx_ctx* ctx, const uint8_t* arena, size
             offs[i - lo] = out_sample_offsets[i] - o0;
         }
         if (batch_plan(S.b, d.data(), nc, offs.data(), flags) != CLX_OK) { st = CLX_API_ERROR; break; }
-        const size_t arena_alloc = ((span + 15) & ~(size_t)15) + 32, out_n = (size_t)(o1 - o0);
+        const size_t arena_alloc = ((span + 15) & ~(size_t)15) + 48, out_n = (size_t)(o1 - o0);      // (>= 48: the tail cleared below lies inside it also when no frame has a readable byte)
         if (!grow(ctx, &S.d_arena, &S.arena_cap, arena_alloc, "hipMalloc arena") ||
             !grow(ctx, &S.d_out, &S.out_cap, std::max<size_t>(out_n, 1) * sizeof(int32_t), "hipMalloc out") ||
             (sample_bytes && !grow(ctx, &S.d_pcm, &S.pcm_cap, std::max<size_t>(out_n, 1) * sample_bytes, "hipMalloc pcm"))) { st = CLX_API_ERROR; break; }

@@ -1031,8 +1031,10 @@ __device__ __forceinline__ void clx_lanes_fused(const uint8_t* __restrict__ aren
                  const clx_dev_frame* __restrict__ frames,
                  const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
                  const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all) {
+                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
+                 const uint32_t* __restrict__ taken, uint32_t gen) {
     __shared__ LanesLds L;
+    if (taken != nullptr && taken[blockIdx.x] == gen) return;        // clx_k_lean (clx_lean.hip) decoded this group in this run
     CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
@@ -1101,14 +1103,16 @@ __device__ __forceinline__ void clx_lanes_fused(const uint8_t* __restrict__ aren
 extern "C" __global__ __launch_bounds__(64)
 void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
                  const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all) {
-    clx_lanes_fused<false>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all);
+                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
+                 const uint32_t* __restrict__ taken, uint32_t gen) {
+    clx_lanes_fused<false>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all, taken, gen);
 }
 extern "C" __global__ __launch_bounds__(64)
 void clx_k_lanes_hi(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
                     const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                    uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all) {
-    clx_lanes_fused<true>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all);
+                    uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
+                    const uint32_t* __restrict__ taken, uint32_t gen) {
+    clx_lanes_fused<true>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all, taken, gen);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,526 @@
+// clx_lean.hip -- the lean build of the fused lane kernel (D): what 16-bit audio is made of, and nothing else.
+//
+//   DL clx_k_lean   one lane per subframe like clx_k_lanes (clx_lanes.hip), for the waves of 64 subframes in which every live
+//                   lane decodes a Rice-coded FIXED / LPC subframe of at most 12 taps of <= 16-bit audio (the side channel has
+//                   17), in 16-byte aligned rows of one common block size that is a multiple of 16.  Such a wave marks its group
+//                   as taken; clx_k_lanes / clx_k_lanes_hi skip taken groups and decode every other one as before.
+//
+// Why a second build: clx_k_lanes carries every tier of every case in one register allocation (195 VGPRs: two waves per SIMD) and
+// spends ~40 instructions per sample.  This one keeps ONE fast tier and one slow one:
+//   * lean turn, 16 samples: four register windows of four Rice codes each (one LDS read per window, funnel shifts between
+//     the codes); the predictor on 16-bit packed history, two taps per v_dot2_i32_i16 (subframe.rs:559-582's loop; exact while
+//     every history sample lies in [-2^15, 2^15) and sum|c| * 2^15 < 2^31 -- checked on the data per turn, not assumed);
+//     mid/side etc. through DPP; the turn's 64 x 16 samples leave as 64-byte row segments, 16 rows per store instruction.
+//     It decodes first and asks afterwards: one wave vote per turn.
+//   * slow turn, 16 samples: a rolled per-sample loop over the generic reader with the i64 predictor (subframe.rs:586-614's
+//     arithmetic), which handles every rare case in line -- partition edges inside a four, escape codes, codes longer than
+//     32 bits, the end of the frame, history outside the 16-bit range.  The wave returns to lean turns as soon as every
+//     lane's history is back inside.
+// The history lives in ONE register array that holds packed pairs (lean) or i32 samples (slow), converted where the tier
+// changes; coefficients stay packed (the slow tier unpacks them per tap).  Per-lane LDS: a ring of CLN_RING stream dwords
+// (+ 4 mirrored) and the 64-byte output stage.
+//
+// Mirrors the reference read for read like clx_k_lanes: subframe.rs:29-91, 184-228, 236-380, 492-516, 651-721; frame.rs:319-389.
+#ifndef CLN_RING
+#define CLN_RING 24u                    // stream dwords per lane in the ring (a multiple of 4)
+#endif
+#define CLN_ROW (CLN_RING + 4u)         // slots RING .. RING+3 mirror slots 0 .. 3: a window of five dwords never wraps
+
+struct LeanLds {
+    uint32_t ring[64][CLN_ROW];
+    int4 stage[64][4];                  // the turn's 64 x 16 output samples (int4 [row][piece ^ swizzle], as in K2)
+};
+
+// s in [0, 2 * RING) -> s mod RING
+__device__ __forceinline__ uint32_t cln_wrap(uint32_t s) {
+    if ((CLN_RING & (CLN_RING - 1u)) == 0u) return s & (CLN_RING - 1u);
+    const uint32_t t = s - CLN_RING;
+    return t < s ? t : s;
+}
+
+struct LRing {
+    uint32_t origin;        // byte offset of the lane's 16-byte aligned stream origin in the arena
+    uint32_t fill, fs;      // stream dwords [fill - RING, fill) are in the ring; fs = fill mod RING (the slot `fill` goes to)
+    uint32_t np;            // granules requested at the last pump (0..2), in pa / pb
+    uint4 pa, pb;
+};
+__device__ __forceinline__ void cln_put(uint32_t* row, uint32_t s, const uint4 v) {
+    const uint4 b = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+    *reinterpret_cast<uint4*>(row + s) = b;
+    if (s == 0u) *reinterpret_cast<uint4*>(row + CLN_RING) = b;
+}
+// synchronous fill from the granule that holds dword `d` (the start of the steady state, and after a slow turn)
+__device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t* row, uint32_t d) {
+    const uint32_t f0 = d & ~3u;
+    const uint32_t s0 = f0 % CLN_RING;
+#pragma unroll
+    for (uint32_t h = 0; h < CLN_RING / 4u; h += 3u) {          // three granules at a time: the loads' registers are short-lived
+        uint4 t[3];
+#pragma unroll
+        for (uint32_t q = 0; q < 3u; ++q) if (h + q < CLN_RING / 4u) t[q] = clx_buf_load16(buf, g.origin + 4u * (f0 + 4u * (h + q)));
+#pragma unroll
+        for (uint32_t q = 0; q < 3u; ++q) if (h + q < CLN_RING / 4u) cln_put(row, cln_wrap(s0 + 4u * (h + q)), t[q]);
+    }
+    g.fill = f0 + CLN_RING; g.fs = s0; g.np = 0;
+}
+// once per turn: land what was requested a turn ago, request what fits now (two granules: 16 bits per code sustained)
+__device__ __forceinline__ void cln_pump(const clx_buf& buf, LRing& g, uint32_t* row, uint32_t p) {
+    if (g.np >= 1u) { cln_put(row, g.fs, g.pa); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    if (g.np >= 2u) { cln_put(row, g.fs, g.pb); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    const uint32_t d = (p - 1u) >> 5;                                   // the oldest dword a window may still read
+    const int32_t room = (int32_t)(CLN_RING + d - g.fill);                // slots that hold dwords before d
+    g.np = 0;
+    if (room >= 4) { g.pa = clx_buf_load16(buf, g.origin + 4u * g.fill); g.np = 1u; }
+    if (room >= 8) { g.pb = clx_buf_load16(buf, g.origin + 4u * g.fill + 16u); g.np = 2u; }
+}
+// slot of stream dword d, for d in [fill - RING, fill)
+__device__ __forceinline__ uint32_t cln_slot(const LRing& g, uint32_t d) {
+    const uint32_t t = g.fs + d - g.fill;                                 // fs - (fill - d), negative (wrapped) when it wraps
+    const uint32_t t2 = t + CLN_RING;
+    return t2 < t ? t2 : t;                                               // (unsigned: exactly one of them is in range)
+}
+// 32 bits at bit position p (p >= 1), left aligned, for the partition parameters
+__device__ __forceinline__ uint32_t cln_peek32(const uint32_t* row, const LRing& g, uint32_t p) {
+    const uint32_t s = cln_slot(g, (p - 1u) >> 5);
+    return clx_alignbit(row[s], row[s + 1u], 0u - p);
+}
+
+// the part of the subframe's state the turns work on
+struct LCur { uint32_t p, k, pcnt, next, parts; };
+// (the lean turn also carries c1 = 31 - k, kept opaque so that 31 - k - z stays one subtraction per code)
+
+// What a lane does in the steady state (fixed once the prologue is over): Rice codes, verbatim fields (subframe.rs:397-415) or a
+// constant (382-394).  The three kinds share one instruction stream; the masks that make them do so are compiled in only for
+// waves that hold a lane of the rarer kinds (MODE 1: constants, MODE 2: verbatim fields).
+struct LKind {
+    bool rice, verb;
+    uint32_t bitmask;        // all ones where the lane consumes bits (Rice, verbatim), 0 for a constant
+    uint32_t ricemask;       // all ones for Rice lanes: only their codes can outgrow the window register
+    uint32_t cor;            // the constant, OR-ed in for constant lanes
+    uint32_t vsh;            // 32 - (width of a verbatim field)
+};
+
+// One sample's raw value the careful way (generic reader over global memory; every rare case in line): partition parameters
+// (subframe.rs:314-319 / 362-367), Rice codes of any length, the end of the frame; a verbatim field; the constant.  Steady state
+// only (after the transition).
+__device__ __forceinline__ int32_t cln_careful_code(LaneReader& r, LCur& c, uint32_t per, uint32_t rice2, const LKind& K) {
+    r.pos = c.p;
+    if (!K.rice) {
+        int32_t x = (int32_t)K.cor;
+        if (K.verb) { x = clx_lread_signed(r, 32u - K.vsh); c.p = r.pos; }
+        return x;
+    }
+    while (!r.err && c.pcnt == 0u && c.parts != 0u) {
+        c.k = clx_lread_rice_param(r, rice2); c.parts -= 1u; c.pcnt = c.next; c.next = per;
+    }
+    int32_t x = 0;
+    if (!r.err) {
+        const uint32_t v = clx_lpeek32(r, r.pos);
+        const uint32_t z = (uint32_t)__clz((int)v);
+        const uint32_t nb = z + c.k + 1u;
+        uint32_t u;
+        if (v != 0u && nb <= 32u) {
+            const uint32_t rem = (v >> ((32u - nb) & 31u)) & ((1u << c.k) - 1u);
+            u = (z << c.k) | rem;
+            r.pos += nb;
+            if (r.pos > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+        } else u = clx_lrice_slow(r, c.k);
+        x = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);                      // rice_to_signed (subframe.rs:157-170)
+        c.pcnt -= 1u;
+    }
+    c.p = r.pos;
+    return x;
+}
+
+// what a lane needs to move "its" 16 bytes of every turn's tile: store k moves rows 16k .. 16k+15, four lanes per row
+struct LMover {
+    int32_t* rq[4];            // row start + this lane's piece (or the dump slot of a row that does not exist)
+    uint32_t adv;              // bit k: rq[k] is a real row (the turn's sample index is added), else a dump slot
+    bool all_real;             // wave-uniform: every row of the wave exists
+};
+__device__ __forceinline__ void cln_store_tile(const int4* tile, const LMover& M, uint32_t t0, int lane) {
+    clx_wave_sync();
+    const int4 w0 = tile[lane], w1 = tile[64 + lane], w2 = tile[128 + lane], w3 = tile[192 + lane];
+    if (M.all_real) {
+        *reinterpret_cast<int4*>(M.rq[0] + t0) = w0; *reinterpret_cast<int4*>(M.rq[1] + t0) = w1;
+        *reinterpret_cast<int4*>(M.rq[2] + t0) = w2; *reinterpret_cast<int4*>(M.rq[3] + t0) = w3;
+    } else {
+        *reinterpret_cast<int4*>(M.rq[0] + ((M.adv & 1u) ? t0 : 0u)) = w0; *reinterpret_cast<int4*>(M.rq[1] + ((M.adv & 2u) ? t0 : 0u)) = w1;
+        *reinterpret_cast<int4*>(M.rq[2] + ((M.adv & 4u) ? t0 : 0u)) = w2; *reinterpret_cast<int4*>(M.rq[3] + ((M.adv & 8u) ? t0 : 0u)) = w3;
+    }
+    clx_wave_sync();
+}
+
+// j-th coefficient (applies to s[i-1-j]) out of the packed form: C[q] = (c[2q] << 16) | (c[2q+1] & 0xffff)
+template <int NP>
+__device__ __forceinline__ int32_t cln_coef(const uint32_t (&C)[NP], int j) {
+    return (j & 1) ? (int32_t)(int16_t)(C[j >> 1] & 0xffffu) : ((int32_t)C[j >> 1] >> 16);
+}
+
+// stereo decorrelation of the turn's sixteen samples (clx_lfinish, clx_lanes.hip) into the stage
+__device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finish& F, int4* tile, int lane, uint32_t sw) {
+    if (F.all_ms) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
+            int32_t y[4];
+            clx_ms_pair4(m, y, F.sgn, F.sgn & 1u, 1u);
+            tile[(uint32_t)lane * 4u + ((uint32_t)b ^ sw)] = make_int4(y[0], y[1], y[2], y[3]);
+        }
+    } else if (F.any_decor) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int32_t y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int32_t mine = s[4 * b + i];
+                const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);       // lane ^ 1
+                const uint32_t P = (uint32_t)(F.p_other ? other : mine);
+                const uint32_t R = (uint32_t)(F.r_other ? other : mine) & F.rmask;
+                const uint32_t mm = (P << F.s1) | (R & F.bit);
+                y[i] = (int32_t)(mm + ((R ^ F.sg) - F.sg)) >> F.s1;
+            }
+            tile[(uint32_t)lane * 4u + ((uint32_t)b ^ sw)] = make_int4(y[0], y[1], y[2], y[3]);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) tile[(uint32_t)lane * 4u + ((uint32_t)b ^ sw)] = make_int4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
+    }
+}
+
+// ---- the lean turn -------------------------------------------------------------------------------------------------------
+// H on entry: packed pairs, H[j] = (lo: s[t0-2-j], hi: s[t0-1-j]) for j = 0 .. 2NP-2.  Returns the wave's vote; on success the
+// cursor and H are advanced by sixteen samples (live lanes) and the tile is in the stage.
+template <int NP, int MODE>
+__device__ __forceinline__ bool cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[2 * NP], const uint32_t (&C)[NP],
+                                              uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2, uint32_t limit, bool live, const LKind& K,
+                                              const Finish& F, int4* tile, int lane, uint32_t sw) {
+    constexpr int NH = 2 * NP - 1;                    // pairs carried from turn to turn
+    uint32_t P[NH + 16];                              // P[NH + m] = pair that ends at sample m of the turn (m = -NH .. 15)
+#pragma unroll
+    for (int j = 0; j < NH; ++j) P[NH - 1 - j] = H[j];
+    LCur c = cur;
+    if (MODE == 0 ? !live : !(live && K.rice)) c.pcnt = 0x7fffff00u;      // (lanes without Rice codes never meet a partition edge)
+    uint32_t c1 = 31u - c.k;
+    CLX_OPAQUE(c1);
+    bool bad = false;
+    int32_t msh = 0;                                  // the smallest "bits left of the window after the code" -- negative: a code > 32 bits
+    int32_t hi = -0x7fffffff - 1, lo = 0x7fffffff;
+    uint32_t pw = c.p;
+    int32_t S16[16];
+    const uint32_t pb = 4u + rice2, esc = rice2 ? 31u : 15u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        // a partition that starts exactly here: its parameter comes first (subframe.rs:314-319 / 362-367)
+        const bool at = c.pcnt == 0u;
+        if (clx_any(at)) {
+            const uint32_t pv = cln_peek32(row, g, c.p);
+            if (at) {
+                c.k = pv >> (32u - pb);
+                bad = bad || c.k == esc || c.parts == 0u || c.next == 0u;
+                c.p += pb; c.parts -= 1u; c.pcnt = c.next; c.next = per;
+                c1 = 31u - c.k;
+            }
+            CLX_OPAQUE(c1);
+        }
+        bad = bad || c.pcnt < 4u;                     // (a partition edge inside the four codes: the slow turn's)
+        c.pcnt -= 4u;
+        const uint32_t kk = c.k & 31u;
+        // register window: 128 bits from bit c.p on
+        pw = c.p;
+        uint32_t wa, wb, wc, wd;
+        {
+            const uint32_t s = cln_slot(g, (c.p - 1u) >> 5);
+            const uint32_t w0 = row[s], w1 = row[s + 1u], w2 = row[s + 2u], w3 = row[s + 3u], w4 = row[s + 4u];
+            const uint32_t sh = 0u - c.p;             // v_alignbit takes the low five bits: (32 - p % 32) % 32
+            wa = clx_alignbit(w0, w1, sh); wb = clx_alignbit(w1, w2, sh); wc = clx_alignbit(w2, w3, sh); wd = clx_alignbit(w3, w4, sh);
+        }
+        uint32_t shsum = 0;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * b + ii;
+            // one Rice code (subframe.rs:337-341): z zeros, a one, k remainder bits = 32 - sh bits
+            const uint32_t z = (uint32_t)__clz((int)wa);
+            int32_t sh = (int32_t)(c1 - z);
+            const uint32_t u = (z << kk) | clx_bfe(wa, (uint32_t)sh, c.k);
+            uint32_t xr = (u >> 1) ^ (0u - (u & 1u));                      // rice_to_signed (subframe.rs:157-170)
+            if (MODE == 0) msh = sh < msh ? sh : msh;
+            else {
+                const int32_t shr = (int32_t)((uint32_t)sh & K.ricemask);   // (only a Rice code can be too long)
+                msh = shr < msh ? shr : msh;
+                if (MODE == 2) {                                            // verbatim rows ride along (subframe.rs:397-415)
+                    xr = K.verb ? (uint32_t)((int32_t)wa >> K.vsh) : xr;
+                    sh = K.verb ? (int32_t)K.vsh : sh;
+                }
+                xr = (xr & K.bitmask) | K.cor;
+            }
+            shsum += (uint32_t)sh;
+            wa = clx_alignbit(wa, wb, (uint32_t)sh); wb = clx_alignbit(wb, wc, (uint32_t)sh); wc = clx_alignbit(wc, wd, (uint32_t)sh); wd = clx_alignbit(wd, 0u, (uint32_t)sh);
+            // predictor on packed pairs, oldest first: only the last term depends on the sample before
+            int32_t acc = 0;
+#pragma unroll
+            for (int q = NP - 1; q >= 0; --q) acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
+            const int32_t s = (int32_t)(xr + (uint32_t)(acc >> shift));                             // + prediction (wrapping)
+            P[NH + i] = clx_perm((uint32_t)s, P[NH + i - 1], 0x05040302u);                          // (lo: the sample before, hi: this one)
+            hi = s > hi ? s : hi; lo = s < lo ? s : lo;
+            S16[i] = s;
+        }
+        CLX_OPAQUE(msh); CLX_OPAQUE(hi); CLX_OPAQUE(lo);         // (folded per four: no shift count of the block stays live for the vote)
+        c.p += MODE == 0 ? 128u - shsum : ((128u - shsum) & K.bitmask);
+    }
+    // stereo decorrelation and the stage: the wave-uniform choice of the form once per turn
+    cln_finish16(S16, F, tile, lane, sw);
+    // what was decoded is what the stream holds iff no code was longer than its window register, the last window lay inside the
+    // ring's filled part and nothing reached past the end of the frame; the predictor was exact iff the outputs (the next turn's
+    // history) stayed inside the range
+    const bool covered = (((pw - 1u) >> 5) + 5u <= g.fill && c.p <= limit) || (MODE != 0 && K.bitmask == 0u);
+    const bool ok = !live || (!bad && msh >= 0 && covered && hi < lim && lo >= -lim);
+    const bool all = __all(ok);
+    if (!all) { CLX_STAT(53, live && bad); CLX_STAT(54, live && msh < 0); CLX_STAT(55, live && !covered); CLX_STAT(56, live && !(hi < lim && lo >= -lim)); }
+    if (all && live) {
+        cur = c;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) H[j] = P[NH + 15 - j];
+    }
+    return all;
+}
+
+// Returns false when the wave gives the group up: the slow turn costs about five lean turns, so a wave that keeps needing it
+// (a lane whose signal stays outside the 16-bit range: loud side channels) is better off in clx_k_lanes, whose 24-bit tier takes
+// such lanes at full speed.  The group is then decoded again from its start by that kernel (rows are simply rewritten; nothing
+// has been reported for it yet).
+#ifndef CLN_SLOW_BUDGET
+#define CLN_SLOW_BUDGET 6u
+#endif
+template <int NP>
+__device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, uint32_t (&H)[2 * NP],
+                                         const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2,
+                                         uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, int lane) {
+
+    int4* const tile = stage - 4 * lane;                 // the wave's 64 x 4 staging slots seen as one tile
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+    bool slow = true;                                    // H holds i32 samples (the prologue leaves them so)
+    bool ring_ok = false;
+    uint32_t nslow = 0;
+    for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
+        const bool live = n != 0u && !r.err;
+        if (slow) {
+            // back to the lean turns as soon as every live lane's history fits the packed form
+            bool in = true;
+#pragma unroll
+            for (int j = 0; j < 2 * NP; ++j) in = in && (int32_t)H[j] < lim && (int32_t)H[j] >= -lim;
+            if (__all(in || !live || order == 0u)) {
+#pragma unroll
+                for (int j = 0; j < 2 * NP - 1; ++j) H[j] = clx_perm(H[j], H[j + 1], 0x05040100u);      // (lo: s[-2-j], hi: s[-1-j])
+                slow = false;
+            }
+        }
+        if (!slow) {
+            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
+            else cln_pump(buf, g, row, cur.p);
+            bool done;
+            if (mode == 0 || NP == 2) done = cln_lean_turn<NP, 0>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);     // (NP == 2 is only run with mode 0)
+            else if (mode == 1)       done = cln_lean_turn<NP, 1>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            else                      done = cln_lean_turn<NP, 2>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            if (done) {
+                cln_store_tile(tile, M, t0, lane);
+                CLX_STAT(50, 1);
+                continue;
+            }
+            // the turn goes the slow way from where it started: unpack the history (sign-extended halves)
+            uint32_t U[2 * NP];
+#pragma unroll
+            for (int j = 0; j < 2 * NP - 1; ++j) U[j] = (uint32_t)((int32_t)H[j] >> 16);
+            U[2 * NP - 1] = (uint32_t)(int32_t)(int16_t)(H[2 * NP - 2] & 0xffffu);
+#pragma unroll
+            for (int j = 0; j < 2 * NP; ++j) H[j] = U[j];
+            slow = true;
+        }
+        CLX_STAT(51, 1);
+        if (++nslow > CLN_SLOW_BUDGET && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // (wave-uniform; not when the end is near anyway)
+        // ---- slow turn: sixteen samples one by one, generic reader, i64 predictor (taps beyond the order are zero)
+        int32_t* const ys = reinterpret_cast<int32_t*>(stage);
+#pragma unroll 1
+        for (uint32_t ii = 0; ii < 16u; ++ii) {
+            int32_t x = 0;
+            if (live) x = cln_careful_code(r, cur, per, rice2, K);
+            int64_t acc = 0;
+#pragma unroll
+            for (int j = 2 * NP - 1; j >= 0; --j) acc += (int64_t)cln_coef<NP>(C, j) * (int64_t)(int32_t)H[j];
+            const int32_t s = (int32_t)((uint32_t)x + (uint32_t)(int32_t)(acc >> shift));
+#pragma unroll
+            for (int j = 2 * NP - 1; j > 0; --j) H[j] = H[j - 1];
+            H[0] = (uint32_t)s;
+            const int32_t v = clx_lfinish(s, F);
+            ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
+        }
+        cln_store_tile(tile, M, t0, lane);
+        ring_ok = false;                                  // the position moved without the ring
+    }
+    return true;
+}
+
+// LPC / fixed parameters of a lane after the prologue, in the lean kernel's form
+template <int NP>
+__device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LRing& g, uint32_t* row, int4* stage, uint32_t n, uint32_t i0, uint32_t nmax,
+                                        const LKind& K, int mode, const Finish& F, const LMover& M, int lane) {
+    uint32_t C[NP], H[2 * NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) C[q] = ((uint32_t)S.c[2 * q] << 16) | ((uint32_t)S.c[2 * q + 1] & 0xffffu);
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) H[j] = (uint32_t)S.hist[j];
+    LCur cur = { S.r.pos, S.k, S.pcnt, S.next_cnt, S.parts_left };
+    if (n == 0u) cur.p = 32u;            // a lane that decodes nothing rides along from a harmless position (never committed)
+    // range in which the packed evaluation is exact: 16-bit factors, and no partial sum of the taps wraps 32 bits
+    // (S.lim = min(2^23, (2^31 - 1) / sum|c|), clx_ltransition); a subframe without taps has nothing to keep in range
+    const int32_t lim = S.order == 0u ? 0x7fffffff : S.lim < 32768 ? S.lim : 32768;
+    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, mode, F, M, lane);
+    S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
+    return done;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_lean(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
+                const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
+                uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
+                uint32_t* __restrict__ taken, uint32_t gen) {
+    __shared__ LeanLds L;
+    const int lane = (int)threadIdx.x;
+    const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+    uint32_t f = 0xffffffffu;
+    if (slot < n_slots) f = slot_frame[slot];
+    clx_dev_frame fr;
+    fr.byte_off = 0; fr.out_off = 0; fr.limit_bits = 0; fr.first_slot = 0; fr.header_bytes = 0; fr.block_size = 0;
+    fr.n_channels = 0; fr.channel_assignment = 0; fr.bps = 1; fr.flags = 0;
+    if (f != 0xffffffffu) fr = frames[f];
+    const uint32_t ch = (f != 0xffffffffu) ? slot - fr.first_slot : 0u;
+    const uint32_t bs = fr.block_size;
+
+    LaneReader r;
+    r.arena = arena;
+    r.origin = (uint32_t)(fr.byte_off & ~15ull);
+    const uint32_t o = 8u * (uint32_t)(fr.byte_off & 15ull);
+    r.limit = o + fr.limit_bits;
+    r.pos = o + 8u * (uint32_t)fr.header_bytes;
+    r.err = 0u;
+    bool active = (f != 0xffffffffu);
+    if (active && ch != 0u) {
+        const uint32_t sp = sf_start[slot];
+        if (sp == 0xffffffffu) active = false;             // an earlier channel failed (the scan reported it): decodes nothing
+        else r.pos = sp;
+    }
+    // ---- does this wave qualify?  Every live lane: <= 16-bit audio, a FIXED / LPC subframe of at most 12 taps whose header
+    //      parses, the wave's common block size (a multiple of 16, beyond the prologue), a 16-byte aligned row.
+    int32_t* const rowp = out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
+    bool good = !active;
+    SfHead h = { 1u, 0u, 0u, 1u };
+    uint32_t bs0 = 0;
+    {
+        const unsigned long long am = __ballot(active);
+        if (am == 0ull) return;                            // nothing to decode here
+        bs0 = (uint32_t)__shfl((int)bs, (int)__ffsll((long long)am) - 1, 64);
+    }
+    if (active) {
+        good = fr.bps <= 16u && bs == bs0 && (bs & 15u) == 0u && bs >= 32u && (((uintptr_t)rowp) & 15u) == 0u && r.pos <= r.limit &&
+               (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
+        if (good) {
+            h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
+            // (constant and verbatim subframes have order 0; wasted bits are clx_k_lanes' business, except a constant's: they fold into it)
+            good = !r.err && h.order <= 12u && (h.wasted == 0u || h.kind == 0u);
+        }
+    }
+    if (!__all(good)) return;                              // clx_k_lanes / clx_k_lanes_hi decode this group
+    if (lane == 0) taken[blockIdx.x] = gen;
+
+    const uint32_t decor = active ? fr.channel_assignment : 0u;
+    const uint32_t pbs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(active ? bs : 0u), 0xB1, 0xF, 0xF, false);
+    const uint32_t pd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)decor, 0xB1, 0xF, 0xF, false);
+    const bool pair_ok = active && decor != CLX_CH_INDEPENDENT && pbs == bs && pd == decor;
+    uint32_t omax = active ? h.order : 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { const uint32_t b = __shfl_xor(omax, s, 64); omax = b > omax ? b : omax; }
+    const uint32_t nmax = bs0;
+    const uint32_t n = active ? bs : 0u;
+
+    // ---- the rows this lane moves (four lanes per row, 16 rows per store), dump slots for rows that do not exist
+    LMover M;
+    {
+        const uint32_t pc = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u);
+        int32_t* const dump = dump_all + (size_t)slot * 16u;
+        M.adv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int src = k * 16 + (lane >> 2);
+            const uint64_t ro = __shfl((unsigned long long)(rowp - out), src, 64);
+            const bool real = __shfl((int)(active ? 1 : 0), src, 64) != 0;
+            M.rq[k] = real ? out + ro + 4u * pc : dump + 4 * k;
+            M.adv |= real ? (1u << k) : 0u;
+        }
+        M.all_real = __all(M.adv == 15u);
+    }
+    const Finish F = clx_lfinish_setup(n, 0u, decor, pair_ok, lane);
+
+    // ---- careful prologue (as clx_lanes_body's): warm-up samples, the transition, the first residuals -- one sample per turn of
+    //      a rolled loop, i64 predictor; leaves every lane on a multiple of 16 samples, past its transition
+    LaneState<12> S;
+    S.r = r;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { S.c[j] = 0; S.hist[j] = 0; }
+    S.phase = 3u; S.cval = 0; S.trans_at = 0xffffffffu; S.transitioned = false;
+    S.order = 0; S.shift = 0; S.lim = 0x7fffffff;
+    S.k = 0; S.k1 = 1; S.pcnt = 0; S.next_cnt = 0; S.per = 0; S.parts_left = 0; S.rice2 = 0;
+    if (n) {                                               // (bs >= 32 > order: "order larger than block size" cannot happen here)
+        if (h.kind == 0u) {                                // decode_constant (subframe.rs:382-394) + its wasted-bits shift (216-225)
+            S.cval = (int32_t)((uint32_t)clx_lread_signed(S.r, h.sf_bps) << h.wasted); S.phase = 2u;
+        }
+        else if (h.kind == 1u) S.phase = 0u;                                               // decode_verbatim (397-415)
+        else { S.phase = 0u; S.trans_at = h.order; }
+    }
+    const uint32_t i0 = (omax + 4u + 15u) & ~15u;           // 16 or 32 (<= bs)
+    int32_t* const ys = reinterpret_cast<int32_t*>(L.stage[lane]);
+    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+#pragma unroll 1
+    for (uint32_t i = 0; i < i0; ++i) {
+        const int32_t x = clx_lcareful_raw<12>(S, h, bs, i, n);
+        const int32_t pred = clx_lpredict<12, true>(S.c, S.hist, S.shift);
+        const uint32_t use = (S.order != 0u && i >= S.order && i >= S.trans_at) ? 0xffffffffu : 0u;
+        const int32_t s = (int32_t)((uint32_t)x + ((uint32_t)pred & use));
+#pragma unroll
+        for (int j = 11; j > 0; --j) S.hist[j] = S.hist[j - 1];
+        S.hist[0] = s;
+        ys[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
+        if ((i & 15u) == 15u) cln_store_tile(L.stage[0], M, i & ~15u, lane);
+    }
+    // ---- steady state
+    const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
+    LRing g;
+    g.origin = r.origin; g.fill = 0; g.fs = 0; g.np = 0; g.pa = make_uint4(0u, 0u, 0u, 0u); g.pb = g.pa;
+    if (i0 < nmax) {
+        // what every lane does from here on (the prologue is over: predicted subframes have switched to residuals)
+        LKind K;
+        K.rice = S.phase == 1u; K.verb = S.phase == 0u;
+        K.bitmask = S.phase == 2u ? 0u : 0xffffffffu;
+        K.ricemask = K.rice ? 0xffffffffu : 0u;
+        K.cor = S.phase == 2u ? (uint32_t)S.cval : 0u;
+        K.vsh = (32u - h.sf_bps) & 31u;
+        const bool lv = n != 0u && !S.r.err;
+        const int mode = __any(lv && K.verb) ? 2 : __any(lv && !K.rice) ? 1 : 0;          // wave-uniform
+        bool done;
+        if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, L.ring[lane], L.stage[lane], n, i0, nmax, K, mode, F, M, lane);
+        else if (omax <= 8u)         done = cln_run<4>(buf, S, g, L.ring[lane], L.stage[lane], n, i0, nmax, K, mode, F, M, lane);
+        else                         done = cln_run<6>(buf, S, g, L.ring[lane], L.stage[lane], n, i0, nmax, K, mode, F, M, lane);
+        if (!done) {                                       // given up: clx_k_lanes decodes the group
+            if (lane == 0) taken[blockIdx.x] = 0u;
+            CLX_STAT(57, 1);
+            return;
+        }
+    }
+    // ---- trailing parameters of empty partitions are part of the stream (they move the next subframe / the CRC)
+    if (n != 0u && !S.r.err && S.transitioned) {
+        while (!S.r.err && S.parts_left != 0u) { (void)clx_lread_rice_param(S.r, S.rice2); S.parts_left -= 1u; }
+    }
+    if (active) {
+        if (S.r.err) clx_report_error(errkey, f, ch, S.r.err);
+        else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(S.r.pos - o);
+    }
+}

@@ -89,6 +89,58 @@ __device__ __forceinline__ int32_t clx_ms_pair(int32_t y, uint32_t sgn, uint32_t
                  : "=&v"(out), "=&v"(t), "=&v"(x), "=&v"(mid) : "v"(y), "v"(sgn), "v"(nsg), "v"(one));
     return out;
 }
+// v_dot2_i32_i16 (v_dot2c_i32_i16): a.lo16 * b.lo16 + a.hi16 * b.hi16 + acc, signed 16-bit factors, 32-bit wrapping sum.  A
+// builtin, not asm: the compiler then knows the instruction (wait states behind its result, scheduling around it).
+typedef short clx_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t clx_sdot2(uint32_t a, uint32_t b, int32_t acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(clx_short2, a), __builtin_bit_cast(clx_short2, b), acc, false);
+}
+// Raw buffer over the arena: 32-bit byte offsets per lane against one wave-uniform descriptor, and loads that reach past the
+// end of the allocation return zeros instead of faulting (what a lane with a damaged frame descriptor may ask for).
+typedef uint32_t clx_u32x4 __attribute__((ext_vector_type(4)));
+struct clx_buf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ clx_buf clx_make_buf(const void* base, uint32_t bytes) {
+    clx_buf b; b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); return b;
+}
+__device__ __forceinline__ uint4 clx_buf_load16(const clx_buf& b, uint32_t byte_off) {
+    const clx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)byte_off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// Four samples at once: one statement, so the two wait states in front of the first DPP read are paid once per four.
+__device__ __forceinline__ void clx_ms_pair4(const int32_t (&y)[4], int32_t (&out)[4], uint32_t sgn, uint32_t nsg, uint32_t one) {
+    uint32_t t, x, mid;
+    asm volatile("s_nop 1\n\t"
+                 "v_and_b32_dpp %4, %7, %13 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %5, %7, %11 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %6, %7 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_lshl_or_b32 %6, %6, 1, %4\n\t"
+                 "v_add3_u32 %0, %6, %5, %12\n\t"
+                 "v_ashrrev_i32 %0, 1, %0\n\t"
+                 "v_and_b32_dpp %4, %8, %13 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %5, %8, %11 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %6, %8 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_lshl_or_b32 %6, %6, 1, %4\n\t"
+                 "v_add3_u32 %1, %6, %5, %12\n\t"
+                 "v_ashrrev_i32 %1, 1, %1\n\t"
+                 "v_and_b32_dpp %4, %9, %13 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %5, %9, %11 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %6, %9 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_lshl_or_b32 %6, %6, 1, %4\n\t"
+                 "v_add3_u32 %2, %6, %5, %12\n\t"
+                 "v_ashrrev_i32 %2, 1, %2\n\t"
+                 "v_and_b32_dpp %4, %10, %13 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %5, %10, %11 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %6, %10 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_lshl_or_b32 %6, %6, 1, %4\n\t"
+                 "v_add3_u32 %3, %6, %5, %12\n\t"
+                 "v_ashrrev_i32 %3, 1, %3"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t), "=&v"(x), "=&v"(mid)
+                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(sgn), "v"(nsg), "v"(one));
+}
+// Wave vote on a bool without the detour through an int (s_and with exec + a scalar branch, no vector instruction).
+__device__ __forceinline__ bool clx_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// The value of x as something the optimiser cannot see through (no instruction): keeps an expression in the shape written.
+#define CLX_OPAQUE(x) asm volatile("" : "+v"(x))
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at lds_base + 16*lane (no VGPR
 // round trip, asynchronous, counted by vmcnt).  Inline asm on purpose: hipcc drains vmcnt(0) before the next LDS read
 // when it can see the DMA, which would serialise a prefetch ring; with asm the waits are placed by hand

@@ -196,7 +196,11 @@ enum {
     /* Build of the wave path's predictor kernel (default: by batch size): the multi-wave latency build
      * (clx_k_predict) or the one-wave throughput build (clx_k_predict_1w / _1w_hi). */
     CLX_K2_LATENCY      = 1u << 8,
-    CLX_K2_THROUGHPUT   = 1u << 9
+    CLX_K2_THROUGHPUT   = 1u << 9,
+    /* The fused lane build runs clx_k_lean first (the 16-bit tier: waves of <= 16-bit FIXED / LPC subframes of at most 12 taps in
+     * aligned rows) and the general kernels on the groups it leaves.  This flag leaves clx_k_lean out: every group goes through
+     * the general kernels (test and comparison target). */
+    CLX_LANES_GENERAL   = 1u << 10
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32

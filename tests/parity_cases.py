@@ -222,6 +222,121 @@ def resync_workload():
     return synth.concat("resync", ws)
 
 
+def lean_workload(scale=1):
+    """What the lean fused lane kernel (clx_k_lean: the 16-bit tier, clx_lean.hip) takes -- waves of 64 subframes of <= 16-bit audio in
+    rows of one block size that is a multiple of 16 -- arranged so that every one of its tiers and exits is used: lean turns with 4 /
+    8 / 12 taps, partition starts at every multiple of four codes, Rice2 parameters, constants and verbatim subframes riding along,
+    every channel assignment; and the ways out of a lean turn: history outside the 16-bit range (loud side channels), codes longer
+    than 32 bits (spikes under a small parameter), partitions that are not a multiple of four codes long, streams that outrun the
+    ring (16 bits per code), subframes that end right after the prologue.  Families are 64 subframes each, so every family is one
+    wave; `scale` repeats the lot with other seeds (GPU runs)."""
+    rng = np.random.default_rng(31337)
+    S = synth
+    ws = []
+
+    def family(bs, n_frames, channels, make):
+        pcm = np.empty((n_frames, channels, bs), dtype=np.int32)
+        fps = []
+        for i in range(n_frames):
+            chans, fp = make(i)
+            for c in range(channels):
+                pcm[i, c] = chans[c]
+            fps.append(fp)
+        ws.append(S.encode_frames("lean", pcm, channels, bs, 16, fps))
+
+    def music(i, bs, loud=1.0):
+        L, R, g = S.pcm_music_like(int(rng.integers(0, 1 << 20)) + i, bs)
+        return (np.clip(L * loud, -32768, 32767).astype(np.int32), np.clip(R * loud, -32768, 32767).astype(np.int32)), g
+
+    for rep in range(scale):
+        # (a) the plain cases: orders <= 4 / <= 8 / <= 12 (one instantiation of the turn each), every channel assignment
+        for omax, bs in ((4, 1024), (8, 1024), (12, 1024), (12, 4096)):
+            def mk(i, omax=omax, bs=bs):
+                (L, R), g = music(i, bs)
+                fp = S.FrameParams(i % 4, 0, i)
+                for c in range(2):
+                    if g.uniform() < 0.75:
+                        fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, omax + 1)), int(g.integers(5, 16)), int(g.integers(0, 9 if bs >= 4096 else 7)),
+                                        force_rice2=int(g.uniform() < 0.15))
+                    else:
+                        fp.sf[c] = S.sf(S.SF_FIXED, int(g.integers(0, min(omax, 4) + 1)), 0, int(g.integers(0, 7)))
+                return (L, R), fp
+            family(bs, 32, 2, mk)
+        # (b) constants and verbatim subframes among them (independent coding only: the generator codes what it is given)
+        def mk_b(i):
+            (L, R), g = music(i, 512)
+            fp = S.FrameParams(0, 0, i)
+            kinds = [S.SF_LPC, S.SF_LPC]
+            if i % 5 == 1:
+                kinds[i % 2] = S.SF_CONSTANT
+            elif i % 5 == 3:
+                kinds[(i // 5) % 2] = S.SF_VERBATIM
+            ch = [L, R]
+            for c in range(2):
+                if kinds[c] == S.SF_CONSTANT:
+                    ch[c] = np.full(512, int(g.integers(-9, 10)) * (4 if i % 3 == 0 else 1), dtype=np.int32)     # (some with wasted bits)
+                    fp.sf[c] = S.sf(S.SF_CONSTANT, 0, 0, 0)
+                elif kinds[c] == S.SF_VERBATIM:
+                    ch[c] = g.integers(-32768, 32768, 512).astype(np.int32)
+                    fp.sf[c] = S.sf(S.SF_VERBATIM, 0, 0, 0)
+                else:
+                    fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 13)), 12, int(g.integers(0, 6)))
+            return ch, fp
+        family(512, 32, 2, mk_b)
+        # (c) partitions of 18 and 9 codes (144 >> 3, >> 4): edges inside a four -- the slow turn's, then the give-up
+        def mk_c(i):
+            (L, R), g = music(i, 144)
+            fp = S.FrameParams(3 if i % 2 else 1, 0, i)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC, 8, 12, (3, 4, 2, 1)[i % 4])
+            return (L, R), fp
+        family(144, 32, 2, mk_c)
+        # (d) loud and out of phase: the side channel leaves the 16-bit range -- for four turns in every frame of the first family
+        #     (the wave goes through slow turns and returns to lean ones), for good in frames of the second (it gives the group up)
+        for burst in (True, False):
+            def mk_d(i, burst=burst):
+                bs = 2048
+                t = np.arange(bs)
+                env = np.where((t >= 610) & (t < 660), 30000.0, 400.0) if (burst or i % 3) else np.full(bs, 30000.0)
+                a = env * np.sin(2 * np.pi * (180 + 7 * i) * t / 44100.0)
+                L = np.clip(np.rint(a + rng.normal(0, 5, bs)), -32768, 32767).astype(np.int32)
+                R = np.clip(np.rint(-a + rng.normal(0, 5, bs)), -32768, 32767).astype(np.int32)
+                fp = S.FrameParams((3, 1, 2)[i % 3], 0, i)
+                for c in range(2):
+                    fp.sf[c] = S.sf(S.SF_LPC, 8, 14, 4)
+                return (L, R), fp
+            family(2048, 32, 2, mk_d)
+        # (e) spikes under a small Rice parameter: codes far longer than 32 bits (mono: 64 frames are one wave)
+        def mk_e(i):
+            bs = 1024
+            x = rng.integers(-6, 7, bs).astype(np.int32)
+            if i % 4 != 3:
+                x[rng.integers(40, bs, size=1 + i % 3)] = rng.integers(3000, 30000) * (1 if i % 2 else -1)
+            fp = S.FrameParams(0, 0, i)
+            fp.sf[0] = S.sf(S.SF_FIXED, 0, 0, 0, rice_param=2)
+            return (x,), fp
+        family(1024, 64, 1, mk_e)
+        # (f) full-scale noise, 15-16 bits per code: the ring cannot keep up for long
+        def mk_f(i):
+            bs = 1024
+            fp = S.FrameParams(0, 0, i)
+            ch = [rng.integers(-32768, 32768, bs).astype(np.int32), rng.integers(-3000, 3000, bs).astype(np.int32)]
+            fp.sf[0] = S.sf(S.SF_FIXED, 0, 0, 2, rice_param=14)
+            fp.sf[1] = S.sf(S.SF_LPC, 4, 10, 2)
+            return ch, fp
+        family(1024, 32, 2, mk_f)
+        # (g) blocks that end with (or right after) the prologue
+        for bs in (32, 48):
+            def mk_g(i, bs=bs):
+                (L, R), g = music(i, bs)
+                fp = S.FrameParams(i % 4, 0, i)
+                for c in range(2):
+                    fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 13)), 10, int(g.integers(0, 2)))
+                return (L, R), fp
+            family(bs, 32, 2, mk_g)
+    return synth.concat("lean tiers", ws)
+
+
 def check_regressions(oracle, backend):
     """Frames that once decoded differently from the oracle on some kernel selection (found by tools/stress_gpu.py)."""
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "*.npy")))

@@ -16,10 +16,12 @@ def ctx():
 
 
 @pytest.fixture(scope="module", params=[cx.PATH_WAVES | cx.K2_LATENCY, cx.PATH_WAVES | cx.K2_THROUGHPUT, cx.PATH_LANES | cx.LANES_SPLIT,
-                                        cx.PATH_LANES | cx.LANES_FUSED], ids=["waves", "waves-1w", "lanes", "lanes-fused"])
+                                        cx.PATH_LANES | cx.LANES_FUSED, cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL],
+                ids=["waves", "waves-1w", "lanes", "lanes-fused", "lanes-general"])
 def gpu(ctx, request):
     """Both kernel paths, every build of each: wave-per-frame (clx_kernels.hip) with the multi-wave and the one-wave
-    predictor kernels, lane-per-subframe (clx_lanes.hip) with the split and the fused decode kernels."""
+    predictor kernels, lane-per-subframe (clx_lanes.hip) with the split and the fused decode kernels -- the fused build with the
+    lean 16-bit tier (clx_k_lean, clx_lean.hip) in front of the general kernels, and with the general kernels alone."""
     return GpuBackend(ctx, request.param)
 
 
@@ -29,6 +31,11 @@ def gpu(ctx, request):
 ], ids=["config2", "config3", "config4", "config5", "small_mixed"])
 def test_gpu_workloads(oracle, gpu, make):
     pc.check_workload(oracle, gpu, make())
+
+
+def test_gpu_lean_tiers(oracle, gpu):
+    """every tier and exit of clx_k_lean (see parity_cases.lean_workload); the other selections decode the same frames"""
+    pc.check_workload(oracle, gpu, pc.lean_workload(scale=2))
 
 
 def test_gpu_edges(oracle, gpu):

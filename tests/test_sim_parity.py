@@ -13,9 +13,11 @@ from parity_util import SimBackend
 import claxon_amd as cx
 
 
-@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED], ids=["waves", "lanes", "lanes-fused"])
+@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED,
+                                        cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL], ids=["waves", "lanes", "lanes-fused", "lanes-general"])
 def sim(request):
-    """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip)."""
+    """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip: split build, fused build with
+    the lean 16-bit tier clx_k_lean in front, fused build with the general kernels alone)."""
     import simlib
     simlib.build()
     return SimBackend(request.param)
@@ -127,3 +129,58 @@ def test_sim_range_hops_take_both_predictors(oracle):
     pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=False)
     lean, wide = stats[16] + stats[32], stats[36]
     assert lean > 1000 and wide > 1000, (lean, wide)
+
+
+def test_sim_lean_tiers(oracle):
+    """clx_k_lean (the 16-bit tier of the fused lane build): bit-exact on a workload built to use every tier and every way out
+    of a lean turn -- and it really does (tier counters compiled into the simulator build only)."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    w = pc.lean_workload()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for i in range(64):
+        stats[i] = 0
+    pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
+    lean, slow, taken = stats[50] // 64, stats[51] // 64, stats[52]
+    why = {"partition edge inside a four / escape": stats[53], "code longer than 32 bits": stats[54], "ring ran dry / end of frame": stats[55],
+           "history outside the 16-bit range": stats[56]}
+    assert lean > 300 and slow > 20 and taken >= 8, (lean, slow, taken)
+    assert all(v > 0 for v in why.values()), why
+    assert stats[57] // 64 >= 2          # groups given up to the general kernels (and still bit-exact: they decoded them)
+
+
+def test_sim_lean_takes_the_bench_shapes(oracle):
+    """configs 2 / 3 (the bench workload's shape) and the mixed shapes of config 5 go through clx_k_lean, all turns lean."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for make, groups in ((lambda: synth.config3(32), 1), (lambda: synth.config2(64), 1)):
+        for i in range(64):
+            stats[i] = 0
+        pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), make(), verify_crc=False)
+        assert stats[52] == groups and stats[51] == 0 and stats[50] // 64 == 255 * groups, (stats[50], stats[51], stats[52])
+
+
+def test_sim_lean_truncations_and_flips(oracle):
+    """EOF and garbage parity inside frames the lean kernel takes (4096-sample 16-bit stereo): every cut / flip must give the
+    reference's status, message, end bit and samples."""
+    import simlib
+    simlib.build()
+    sim = SimBackend(cx.PATH_LANES | cx.LANES_FUSED)
+    w = synth.config5_unique(6, bs=256)
+    rng = np.random.default_rng(5)
+    seen = set()
+    for i in range(w.n):
+        fr = w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])].copy()
+        for c in sorted(set(rng.integers(8, len(fr), 10).tolist() + [len(fr) - 2, len(fr) - 1, len(fr)])):
+            seen.add(pc.assert_same_as_oracle(oracle, sim, fr[:c].copy(), True, "frame %d cut %d" % (i, c)))
+        _, _, h = cx.parse_frame_header(fr)
+        for trial in range(10):
+            g = fr.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(h.header_bytes * 8, len(g) * 8))
+                g[pos >> 3] ^= (0x80 >> (pos & 7))
+            seen.add(pc.assert_same_as_oracle(oracle, sim, g, False, "frame %d flip %d" % (i, trial)))
+    assert len(seen) >= 3, seen

@@ -34,6 +34,21 @@ static inline int32_t clx_ms_pair_(int line, int32_t y, uint32_t sgn, uint32_t n
     return (int32_t)(m + (side ^ sgn) + nsg) >> 1;
 }
 #define clx_ms_pair(y, sgn, nsg, one) clx_ms_pair_(__LINE__, (y), (sgn), (nsg), (one))
+static inline int32_t clx_sdot2(uint32_t a, uint32_t b, int32_t acc) {
+    const int32_t lo = (int32_t)(int16_t)(a & 0xffffu) * (int32_t)(int16_t)(b & 0xffffu);
+    const int32_t hi = (int32_t)(int16_t)(a >> 16) * (int32_t)(int16_t)(b >> 16);
+    return (int32_t)((uint32_t)lo + (uint32_t)hi + (uint32_t)acc);
+}
+struct clx_buf { const uint8_t* base; uint32_t bytes; };
+static inline clx_buf clx_make_buf(const void* base, uint32_t bytes) { clx_buf b; b.base = (const uint8_t*)base; b.bytes = bytes; return b; }
+static inline uint4 clx_buf_load16(const clx_buf& b, uint32_t byte_off) {     // dwords past the end of the buffer read as zero
+    uint32_t w[4] = { 0u, 0u, 0u, 0u };
+    for (int i = 0; i < 4; ++i) if ((uint64_t)byte_off + 4u * (uint32_t)i + 4u <= (uint64_t)b.bytes) memcpy(&w[i], b.base + byte_off + 4u * (uint32_t)i, 4);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+#define clx_ms_pair4(y, out, sgn, nsg, one) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_pair_(__LINE__, (y)[q_], (sgn), (nsg), (one)); } while (0)
+#define clx_any(p) (wavesim::any_(__LINE__, (p) ? 1 : 0) != 0)
+#define CLX_OPAQUE(x) ((void)(x))
 // LDS-DMA in the simulator: synchronous copy; the "LDS address" is simply the host pointer of the shared object.
 static inline uintptr_t clx_lds_addr(const void* p) { return (uintptr_t)p; }
 static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {

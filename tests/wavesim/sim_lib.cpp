@@ -5,6 +5,7 @@ extern "C" { uint64_t sim_stats[64]; }
 #define CLX_STAT(i, n) (sim_stats[i] += (uint64_t)(n))
 #include "clx_kernels.hip"
 #include "clx_lanes.hip"
+#include "clx_lean.hip"
 #include "clx_plan.h"
 
 extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
@@ -27,10 +28,19 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         // CLX_LANES_FUSED: the fused kernel; otherwise the two-wave one
         if (flags & CLX_LANES_FUSED) {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
+            // the lean kernel first (it marks the groups it decodes with this run's generation number), unless the caller
+            // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
+            std::vector<uint32_t> taken((n_slots + 63) / 64 + 1, 0u);
+            const uint32_t gen = 7u;
+            const bool lean = !(flags & CLX_LANES_GENERAL);
+            if (lean)
+                SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
+                           errkey.data(), endbits.data(), dump.data(), taken.data(), gen);
+            for (uint32_t t : taken) sim_stats[52] += t == gen;
             SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
-                       errkey.data(), endbits.data(), dump.data());
+                       errkey.data(), endbits.data(), dump.data(), lean ? taken.data() : nullptr, gen);
             SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
-                       errkey.data(), endbits.data(), dump.data());
+                       errkey.data(), endbits.data(), dump.data(), lean ? taken.data() : nullptr, gen);
         } else {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
