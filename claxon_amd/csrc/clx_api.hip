@@ -226,6 +226,14 @@ struct clx_stream_slot {
     size_t lo = 0, hi = 0;                                      // frames of the chunk whose results are pending (hi > lo)
 };
 
+#ifndef CLX_SUBMIT_MERGE
+#define CLX_SUBMIT_MERGE 6             // runs per merged launch of the fused lane kernels (<= CLX_MAX_MERGE)
+#endif
+#ifndef CLX_SUBMIT_STREAMS
+#define CLX_SUBMIT_STREAMS 2           // internal streams the merged launches rotate over (MERGE * STREAMS <= CLX_SUBMIT_DEPTH)
+#endif
+static_assert(CLX_SUBMIT_MERGE <= CLX_MAX_MERGE && CLX_SUBMIT_STREAMS * CLX_SUBMIT_MERGE <= CLX_SUBMIT_DEPTH && CLX_SUBMIT_STREAMS <= 6, "merge width");
+
 struct clx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -291,6 +299,23 @@ struct clx_batch {
         const int32_t* out = nullptr;            // where the pending submission writes
     } flight[kDepth];
     hipStream_t side_stream = nullptr;                 // CRC and left-over predictor kernels of the submissions in flight (launch_waves)
+    // Lane path, fused build: consecutive submissions are MERGED into one launch (grid.y = the runs; kernels take a clx_runs table).
+    // The machine runs only a handful of kernels from different queues side by side however many queues there are (measured:
+    // about six), and one run of these kernels is a serial chain per subframe on a fraction of the machine -- so filling it takes one
+    // grid that holds many runs, not many streams.  Submissions wait in `pend` until kMerge of them are there (or somebody asks for
+    // results / flushes); merged launches alternate between two internal streams, so that the scan stage of one overlaps the
+    // decode stage of the other.  Flights are only the runs' scratch buffers here.
+    enum { kMerge = CLX_SUBMIT_MERGE, kStreams = CLX_SUBMIT_STREAMS, kMaxStreams = 6 };
+    int merge = kMerge, n_streams = kStreams;          // (CLX_TUNE_MERGE / CLX_TUNE_STREAMS in the environment override them: tuning only)
+    struct Pending { const uint8_t* arena; size_t arena_len; int32_t* out; int flight; };
+    std::vector<Pending> pend;
+    hipStream_t pend_stream = nullptr;                 // the caller's stream the pending submissions came in on
+    hipStream_t mstream[kMaxStreams] = {};
+    hipEvent_t m_in[kMaxStreams] = {}, m_done[kMaxStreams] = {};
+    bool m_recorded[kMaxStreams] = {}, m_unwaited[kMaxStreams] = {};   // m_done[k] was recorded | nobody has been made to wait for it yet
+    std::vector<const int32_t*> m_outs[kMaxStreams];   // outputs the latest launch on each stream writes
+    int flight_launch_stream[CLX_SUBMIT_DEPTH] = {};   // stream of the merged launch that used a flight's scratch last, -1 none
+    uint64_t n_merged = 0;
     uint64_t n_submitted = 0;
     int last_slot = -1;              // flight of the most recent pipelined submission (-1: the last run was a plain clx_batch_run)
 };
@@ -357,6 +382,11 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_taken) (void)hipFree(b->d_taken);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
+    for (int k = 0; k < clx_batch::kMaxStreams; ++k) {
+        if (b->mstream[k]) { (void)hipStreamSynchronize(b->mstream[k]); (void)hipStreamDestroy(b->mstream[k]); }
+        if (b->m_in[k]) (void)hipEventDestroy(b->m_in[k]);
+        if (b->m_done[k]) (void)hipEventDestroy(b->m_done[k]);
+    }
     for (int i = 0; i < clx_batch::kDepth; ++i) {
         clx_batch::Flight& F = b->flight[i];
         if (F.stream) { (void)hipStreamSynchronize(F.stream); (void)hipStreamDestroy(F.stream); }
@@ -440,6 +470,8 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
             !grow(ctx, &b->d_endbits, &b->cap[8], nf * sizeof(uint64_t), "hipMalloc endbits") ||
             !grow(ctx, &b->d_taken, &b->cap[9], ((ns + 63) / 64) * sizeof(uint32_t), "hipMalloc taken") ||
             !hip_ok(ctx, hipMemset(b->d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "memset taken") ||
+            !hip_ok(ctx, hipMemset(b->d_sf_start, 0xff, ns * sizeof(uint32_t)), "memset sf_start") ||
+            !hip_ok(ctx, hipMemset(b->d_errkey, 0xff, nf * sizeof(uint32_t)), "memset errkey") ||
             !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
             !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) return CLX_API_ERROR;
     }
@@ -453,11 +485,15 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
         if (i != 0 && F.d_endbits) (void)hipFree(F.d_endbits);
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
         F.d_taken = nullptr; F.gen = 0;
+        if (i == 0) F.d_results = nullptr;
         F.d_sfd = nullptr; F.d_results = nullptr; F.d_sf_start = nullptr; F.d_errkey = nullptr; F.d_endbits = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.out = nullptr;   // (side_recorded stays: the event is still there)
     }
     b->last_slot = -1;
     b->planned_arena_len = (size_t)-1;
     b->ev_valid = false;
+    b->pend.clear();
+    for (int k = 0; k < clx_batch::kMaxStreams; ++k) { b->m_unwaited[k] = false; b->m_outs[k].clear(); }
+    for (int& f : b->flight_launch_stream) f = -1;
     return CLX_OK;
 }
 }  // namespace
@@ -471,6 +507,13 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     clx_batch* b = new (std::nothrow) clx_batch();
     if (!b) return CLX_API_ERROR;
     b->ctx = ctx; b->device = ctx->device;
+    {   // tuning knobs (measurement only; the defaults are compiled in): runs per merged launch, internal streams
+        const char* em = std::getenv("CLX_TUNE_MERGE"); const char* es = std::getenv("CLX_TUNE_STREAMS");
+        const int m = em ? std::atoi(em) : 0, st = es ? std::atoi(es) : 0;
+        if (m >= 1 && m <= CLX_MAX_MERGE) b->merge = m;
+        if (st >= 1 && st <= clx_batch::kMaxStreams) b->n_streams = st;
+        if (b->merge * b->n_streams > clx_batch::kDepthLanes) b->n_streams = std::max(1, clx_batch::kDepthLanes / b->merge);
+    }
     if (batch_plan(b, frames, n, out_sample_offsets, flags) != CLX_OK) { clx_batch_destroy(b); return CLX_API_ERROR; }
     *out = b;
     return CLX_OK;
@@ -522,51 +565,57 @@ int use_lanes(clx_batch* b, size_t arena_len) {
     }
     return 1;
 }
-// The lane kernels of one run: scan (where the later channels of multi-channel frames start), the decode (one or two waves per 64
-// subframes), the per-frame results, the CRC.  `sf_start`, `errkey`, `endbits`: the run's scratch (a set per flight in flight).
+// The lane kernels of `n_runs` runs of the batch in one launch each (grid.y = the run): scan (where the later channels of
+// multi-channel frames start), the decode (the lean 16-bit tier, then the general kernels on the groups it left -- or the two-wave
+// build), the per-frame results, the CRC.  The runs' scratch (sf_start, errkey) is expected cleared to 0xff: the host does that when
+// it allocates it, clx_k_finalize leaves it so behind every run.
 template <typename Mark>
-bool launch_lanes(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, uint32_t* sf_start, uint32_t* errkey, uint64_t* endbits,
-                  clx_frame_result* d_results, bool split, hipStream_t stream, Mark&& mark, uint32_t* taken, uint32_t gen) {
-    clx_ctx* ctx = b->ctx;
-    if (!hip_ok(ctx, hipMemsetAsync(errkey, 0xff, b->n * sizeof(uint32_t), stream), "memset errkey") ||
-        !hip_ok(ctx, hipMemsetAsync(sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream), "memset sf_start")) return false;
+bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool split, hipStream_t stream, Mark&& mark) {
+    const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
     if (b->n_multi) {
         if (!mark("clx_k_scan")) return false;
-        hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi, sf_start, errkey);
+        hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64), n_runs), dim3(64), 0, stream, runs,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi);
     }
     if (!split) {
-        // the 16-bit tier first: it marks the groups it decodes with this run's generation number, the general kernels skip them
-        const bool lean = !(b->flags & CLX_LANES_GENERAL) && taken != nullptr;
-        if (lean) {
+        // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them
+        if (runs.r[0].taken != nullptr) {
             if (!mark("clx_k_lean")) return false;
-            hipLaunchKernelGGL(clx_k_lean, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                               (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump, taken, gen);
+            hipLaunchKernelGGL(clx_k_lean, dim3(groups, n_runs), dim3(64), 0, stream, runs,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
         }
         if (!mark("clx_k_lanes")) return false;             // (+ clx_k_lanes_hi, its order > 12 twin)
-        hipLaunchKernelGGL(clx_k_lanes, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump, (const uint32_t*)(lean ? taken : nullptr), gen);
-        hipLaunchKernelGGL(clx_k_lanes_hi, dim3((unsigned)((b->n_slots + 63) / 64)), dim3(64), 0, stream, d_arena, alloc_len,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump, (const uint32_t*)(lean ? taken : nullptr), gen);
+        hipLaunchKernelGGL(clx_k_lanes, dim3(groups, n_runs), dim3(64), 0, stream, runs,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
+        hipLaunchKernelGGL(clx_k_lanes_hi, dim3(groups, n_runs), dim3(64), 0, stream, runs,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
     }
     else {
+        if (n_runs != 1) return false;
+        const clx_run& R = runs.r[0];
         if (!mark("clx_k_lanes2")) return false;
-        hipLaunchKernelGGL(clx_k_lanes2, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, d_arena, alloc_len,
+        hipLaunchKernelGGL(clx_k_lanes2, dim3((unsigned)((b->n_slots + 127) / 128)), dim3(256), 0, stream, R.arena, R.alloc_len,
                            (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots,
-                           (const uint32_t*)sf_start, d_out, errkey, endbits, b->d_dump);
+                           (const uint32_t*)R.sf_start, R.out, R.errkey, R.end_bits, b->d_dump);
     }
     if (!mark("clx_k_finalize")) return false;
-    hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream,
-                       (const clx_dev_frame*)b->d_frames, (const uint32_t*)errkey, (const uint64_t*)endbits, (uint32_t)b->n, d_results);
+    hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256), n_runs), dim3(256), 0, stream, runs,
+                       (const clx_dev_frame*)b->d_frames, (uint32_t)b->n);
     if (b->flags & CLX_VERIFY_CRC16) {
         if (!mark("clx_k_crc16")) return false;
-        hipLaunchKernelGGL(clx_k_crc16, dim3(crc_grid(b->n)), dim3(256), 0, stream, d_arena,
-                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_results);
+        hipLaunchKernelGGL(clx_k_crc16_runs, dim3(crc_grid(b->n), n_runs), dim3(256), 0, stream, runs,
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n);
     }
     return true;
+}
+// the run that decodes (arena, arena_len) into `out` with a flight's scratch
+clx_run make_run(const clx_batch* b, const clx_batch::Flight& F, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, bool lean) {
+    clx_run R;
+    R.arena = d_arena; R.alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;      // claxon_hip.h: the allocation covers this
+    R.out = d_out; R.sf_start = F.d_sf_start; R.errkey = F.d_errkey; R.end_bits = F.d_endbits;
+    R.taken = (lean && !(b->flags & CLX_LANES_GENERAL)) ? F.d_taken : nullptr;
+    R.results = F.d_results; R.gen = F.gen; R.pad = 0;
+    return R;
 }
 void launch_stage1_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
                          hipStream_t stream) {
@@ -632,8 +681,57 @@ bool launch_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int3
     if (side != nullptr && hipEventRecord(ev_side, side) != hipSuccess) return false;
     return true;
 }
-// make `stream` wait for every pipelined submission that nobody has waited for yet
+// Launch the pending submissions of the fused lane path as ONE grid (grid.y = the runs) on one of the two internal streams.
+int launch_pending(clx_batch* b) {
+    clx_ctx* ctx = b->ctx;
+    if (b->pend.empty()) return CLX_OK;
+    const int k = (int)(b->n_merged % (uint64_t)b->n_streams);
+    if (!b->mstream[k]) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&b->mstream[k], hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&b->m_in[k], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&b->m_done[k], hipEventDisableTiming));
+    }
+    hipStream_t ms = b->mstream[k];
+    // behind everything queued so far on the stream the submissions came in on (their inputs)
+    HIP_TRY(ctx, hipEventRecord(b->m_in[k], b->pend_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ms, b->m_in[k], 0));
+    // (this stream's previous launch is ahead of this one in the stream) the latest launch on ANOTHER stream must be waited for when
+    // it writes an output buffer this launch writes, or used a scratch set this launch uses (only after partial launches: flights
+    // are handed out in rotation, `merge` at a time, and merge * n_streams of them make a full round)
+    for (int j = 0; j < b->n_streams; ++j) {
+        if (j == k || !b->m_recorded[j]) continue;
+        bool other = false;
+        for (const auto& P : b->pend) {
+            if (b->flight_launch_stream[P.flight] == j) other = true;
+            for (const int32_t* o : b->m_outs[j]) if (o == P.out) other = true;
+        }
+        if (other) HIP_TRY(ctx, hipStreamWaitEvent(ms, b->m_done[j], 0));
+    }
+    clx_runs runs;
+    std::memset(&runs, 0, sizeof runs);
+    b->m_outs[k].clear();
+    unsigned n_runs = 0;
+    for (const auto& P : b->pend) {
+        clx_batch::Flight& F = b->flight[P.flight];
+        if (++F.gen == 0u) { HIP_TRY(ctx, hipMemsetAsync(F.d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), ms)); F.gen = 1u; }
+        runs.r[n_runs++] = make_run(b, F, P.arena, P.arena_len, P.out, true);
+        b->m_outs[k].push_back(P.out);
+        b->flight_launch_stream[P.flight] = k;
+    }
+    const auto no_mark = [](const char*) { return true; };
+    if (!launch_lanes(b, runs, n_runs, false, ms, no_mark)) return CLX_API_ERROR;
+    HIP_TRY(ctx, hipEventRecord(b->m_done[k], ms));
+    b->m_recorded[k] = true; b->m_unwaited[k] = true;
+    b->pend.clear();
+    ++b->n_merged;
+    HIP_TRY(ctx, hipGetLastError());
+    return CLX_OK;
+}
+// make `stream` wait for every pipelined submission that nobody has waited for yet (what is pending is launched first)
 int wait_flights(clx_batch* b, hipStream_t stream) {
+    if (launch_pending(b) != CLX_OK) return CLX_API_ERROR;
+    for (int k = 0; k < clx_batch::kMaxStreams; ++k)
+        if (b->m_unwaited[k]) { HIP_TRY(b->ctx, hipStreamWaitEvent(stream, b->m_done[k], 0)); b->m_unwaited[k] = false; }
     for (auto& F : b->flight)
         if (F.pending) {
             HIP_TRY(b->ctx, hipStreamWaitEvent(stream, F.ev_done, 0));
@@ -671,8 +769,12 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         // single-wave (throughput) build beyond (1.28 against 1.34 ms at 48k subframes); CLX_LANES_FUSED / CLX_LANES_SPLIT force one
         const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false : b->choice.lanes_split;
         clx_batch::Flight& F0 = b->flight[0];
+        F0.d_results = b->d_results; F0.d_sf_start = b->d_sf_start; F0.d_errkey = b->d_errkey; F0.d_endbits = b->d_endbits; F0.d_taken = b->d_taken;
         if (++F0.gen == 0u) { HIP_TRY(ctx, hipMemsetAsync(b->d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), stream)); F0.gen = 1u; }
-        if (!launch_lanes(b, d_arena, alloc_len, d_out, b->d_sf_start, b->d_errkey, b->d_endbits, b->d_results, split, stream, mark, b->d_taken, F0.gen)) return CLX_API_ERROR;
+        clx_runs runs;
+        std::memset(&runs, 0, sizeof runs);
+        runs.r[0] = make_run(b, F0, d_arena, arena_len, d_out, !split);
+        if (!launch_lanes(b, runs, 1u, split, stream, mark)) return CLX_API_ERROR;
     } else {
         // (K1 writes every slot of every frame on every run; the slots that only pad a stereo pair to an even index are cleared once)
         clx_batch::Flight& F0 = b->flight[0];
@@ -733,6 +835,44 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
     const int slot = (int)(b->n_submitted % (uint64_t)depth);
     clx_batch::Flight& F = b->flight[slot];
+    const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
+    if (!F.d_results) {
+        if (slot == 0) F.d_results = b->d_results;
+        else HIP_TRY(ctx, hipMalloc((void**)&F.d_results, nf * sizeof(clx_frame_result)));
+    }
+    if (want_lanes) {
+        // ---- fused lane kernels: the submission joins the pending ones; kMerge of them go out as one launch (launch_pending)
+        if (!F.d_sf_start) {
+            if (slot == 0) { F.d_sf_start = b->d_sf_start; F.d_errkey = b->d_errkey; F.d_endbits = b->d_endbits; F.d_taken = b->d_taken; }
+            else {
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_sf_start, ns * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_errkey, nf * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_endbits, nf * sizeof(uint64_t)));
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_taken, ((ns + 63) / 64) * sizeof(uint32_t)));
+                // (scratch starts cleared; clx_k_finalize leaves it cleared behind every run)
+                HIP_TRY(ctx, hipMemset(F.d_sf_start, 0xff, ns * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMemset(F.d_errkey, 0xff, nf * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMemset(F.d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)));
+            }
+        }
+        // what cannot share a launch with the pending submissions goes after them: another caller stream (the launch waits for
+        // ONE stream's inputs), an output buffer one of them writes, a plan that has to be uploaded again (the arena's length)
+        bool apart = !b->pend.empty() && b->pend_stream != stream;
+        for (const auto& P : b->pend) if (P.out == d_out) apart = true;
+        if (b->planned_arena_len != arena_len && b->planned_arena_len != (size_t)-1) {
+            if (wait_flights(b, stream) != CLX_OK) return CLX_API_ERROR;       // (the submissions in flight read the plan)
+        } else if (apart && launch_pending(b) != CLX_OK) return CLX_API_ERROR;
+        if (upload_plan(b, arena_len, stream) != CLX_OK) return CLX_API_ERROR;
+        b->pend.push_back(clx_batch::Pending{ d_arena, arena_len, d_out, slot });
+        b->pend_stream = stream;
+        b->last_slot = slot;
+        b->last_stream = stream;
+        ++b->n_submitted;
+        b->ev_valid = false;
+        if ((int)b->pend.size() >= b->merge && launch_pending(b) != CLX_OK) return CLX_API_ERROR;
+        return CLX_OK;
+    }
+    // ---- wave kernels: a whole run on the flight's own stream
     if (!F.stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&F.stream, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_in, hipEventDisableTiming));
@@ -740,33 +880,10 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_rice, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&F.ev_side, hipEventDisableTiming));
     }
-    const size_t ns = b->n_slots ? (size_t)b->n_slots : 1, nf = b->n ? b->n : 1;
-    if (!F.d_results) {
-        if (slot == 0) F.d_results = b->d_results;
-        else HIP_TRY(ctx, hipMalloc((void**)&F.d_results, nf * sizeof(clx_frame_result)));
-    }
-    if (want_lanes) {
-        if (!F.d_sf_start) {
-            if (slot == 0) { F.d_sf_start = b->d_sf_start; F.d_errkey = b->d_errkey; F.d_endbits = b->d_endbits; }
-            else {
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_sf_start, ns * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_errkey, nf * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_endbits, nf * sizeof(uint64_t)));
-            }
-        }
-        if (!F.d_taken) {
-            if (slot == 0) F.d_taken = b->d_taken;
-            else {
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_taken, ((ns + 63) / 64) * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMemset(F.d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)));
-            }
-        }
-    } else {
-        if (!b->side_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
-        if (!F.d_sfd) {
-            if (slot == 0) F.d_sfd = b->d_sfd;
-            else { HIP_TRY(ctx, hipMalloc((void**)&F.d_sfd, ns * sizeof(clx_sf_desc))); F.sfd_stale = true; }
-        }
+    if (!b->side_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+    if (!F.d_sfd) {
+        if (slot == 0) F.d_sfd = b->d_sfd;
+        else { HIP_TRY(ctx, hipMalloc((void**)&F.d_sfd, ns * sizeof(clx_sf_desc))); F.sfd_stale = true; }
     }
     // a plan that has to be uploaded again (the arena's length changed) is read by the submissions in flight
     if (b->planned_arena_len != arena_len && b->planned_arena_len != (size_t)-1 && wait_flights(b, stream) != CLX_OK) return CLX_API_ERROR;
@@ -784,15 +901,9 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     // (this flight's previous side-stream kernels used the descriptors and results that are about to be overwritten)
     if (F.side_recorded) HIP_TRY(ctx, hipStreamWaitEvent(F.stream, F.ev_side, 0));
     const auto no_mark = [](const char*) { return true; };
-    if (want_lanes) {
-        if (++F.gen == 0u) { HIP_TRY(ctx, hipMemsetAsync(F.d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t), F.stream)); F.gen = 1u; }
-        if (!launch_lanes(b, d_arena, alloc_len, d_out, F.d_sf_start, F.d_errkey, F.d_endbits, F.d_results, false, F.stream, no_mark, F.d_taken, F.gen)) return CLX_API_ERROR;
-        F.side_pending = false;
-    } else {
-        if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, ns * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
-        if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, no_mark, true, b->side_stream, F.ev_rice, F.ev_side)) return CLX_API_ERROR;
-        F.side_pending = true; F.side_recorded = true;
-    }
+    if (F.sfd_stale) { HIP_TRY(ctx, hipMemsetAsync(F.d_sfd, 0, ns * sizeof(clx_sf_desc), F.stream)); F.sfd_stale = false; }
+    if (!launch_waves(b, d_arena, alloc_len, d_out, F.d_sfd, F.d_results, F.stream, no_mark, true, b->side_stream, F.ev_rice, F.ev_side)) return CLX_API_ERROR;
+    F.side_pending = true; F.side_recorded = true;
     HIP_TRY(ctx, hipEventRecord(F.ev_done, F.stream));
     F.pending = true;
     F.out = d_out;

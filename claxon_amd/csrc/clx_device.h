@@ -44,7 +44,25 @@ struct clx_sf_desc {
     int16_t  coef[32];       // coef[j] multiplies s[i-1-j] (first coded coefficient <-> newest sample)
 };
 
+// Lane path: one launch may decode several RUNS of the same planned batch -- the same frame descriptors against different arenas
+// and output buffers (consecutive submissions merged into one grid: blockIdx.y picks the run).  What differs between the runs:
+#define CLX_MAX_MERGE 12
+struct clx_run {
+    const uint8_t* arena;    // the run's compressed frames
+    uint64_t alloc_len;      // bytes readable from `arena` (the padded allocation)
+    int32_t* out;            // the run's planar output
+    uint32_t* sf_start;      // scratch: start bit of every later subframe (clx_k_scan -> decode kernels)
+    uint32_t* errkey;        // scratch: first-error key per frame
+    uint64_t* end_bits;      // scratch: end bit per frame
+    uint32_t* taken;         // per group of 64 slots: == gen when clx_k_lean decoded the group in this run
+    clx_frame_result* results;
+    uint32_t gen;
+    uint32_t pad;
+};
+struct clx_runs { clx_run r[CLX_MAX_MERGE]; };       // passed to the kernels by value
+
 #ifdef __cplusplus
+static_assert(sizeof(clx_run) == 72, "clx_run layout");
 static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
 static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
 // K1 writes the 16 bytes in front of `coef` as one store: {out_base | n, lim_log2, flags | order, shift, wasted, decor}

@@ -1411,9 +1411,8 @@ __constant__ K3Rom clx_k3_rom = clx_make_k3_rom();
 // are taken in rounds of 1 KiB that END at the frame's end -- lane L the 16 bytes [1024 r + 16 L, +16) of the round -- so the
 // first round starts in front of the frame: those bytes count as zeros, which a CRC with initial value 0 does not see
 // (crc.rs:109-112).  Every position then has a multiplier that does not depend on the frame's length.
-extern "C" __global__ __launch_bounds__(256)
-void clx_k_crc16(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
-                 clx_frame_result* __restrict__ results) {
+__device__ __forceinline__ void clx_crc16_frames(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
+                                                 clx_frame_result* __restrict__ results) {
     __shared__ K3Rom T;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&clx_k3_rom);
@@ -1473,6 +1472,17 @@ void clx_k_crc16(const uint8_t* __restrict__ arena, const clx_dev_frame* __restr
             if (contrib != presumed) { results[f].status = CLX_FORMAT_ERROR; results[f].msg = CLX_MSG_FRAME_CRC_MISMATCH; }
         }
     }
+}
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_crc16(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
+                 clx_frame_result* __restrict__ results) {
+    clx_crc16_frames(arena, frames, n_frames, results);
+}
+// the same for the runs of a merged lane-path launch (blockIdx.y picks the run)
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_crc16_runs(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_frames) {
+    const clx_run& R = runs.r[blockIdx.y];
+    clx_crc16_frames(R.arena, frames, n_frames, R.results);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -274,11 +274,14 @@ __device__ __forceinline__ void clx_win_skip(Win& w, uint32_t nb) {
 // P: locate subframes 1..C-1 of every multi-channel frame
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_scan(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
-                const clx_dev_frame* __restrict__ frames,
-                const uint32_t* __restrict__ multi, uint32_t n_multi,
-                uint32_t* __restrict__ sf_start, uint32_t* __restrict__ errkey) {
+void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames,
+                const uint32_t* __restrict__ multi, uint32_t n_multi) {
     __shared__ LanesLds L;
+    const clx_run& R = runs.r[blockIdx.y];
+    const uint8_t* const arena = R.arena;
+    const uint64_t arena_alloc_len = R.alloc_len;
+    uint32_t* const sf_start = R.sf_start;
+    uint32_t* const errkey = R.errkey;
     CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
     uint32_t* const row = L.ring[lane];
@@ -1027,14 +1030,17 @@ __device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* r
 // cost every wave its occupancy: 256 VGPRs = one wave per SIMD).  Both are launched over all slots; a wave leaves at once
 // when its subframes belong to the other kernel.
 template <bool HI>
-__device__ __forceinline__ void clx_lanes_fused(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
-                 const clx_dev_frame* __restrict__ frames,
-                 const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
-                 const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
-                 const uint32_t* __restrict__ taken, uint32_t gen) {
+__device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_dev_frame* __restrict__ frames,
+                 const uint32_t* __restrict__ slot_frame, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     __shared__ LanesLds L;
-    if (taken != nullptr && taken[blockIdx.x] == gen) return;        // clx_k_lean (clx_lean.hip) decoded this group in this run
+    const clx_run& R = runs.r[blockIdx.y];
+    if (R.taken != nullptr && R.taken[blockIdx.x] == R.gen) return;  // clx_k_lean (clx_lean.hip) decoded this group in this run
+    const uint8_t* const arena = R.arena;
+    const uint64_t arena_alloc_len = R.alloc_len;
+    const uint32_t* const sf_start = R.sf_start;
+    int32_t* const out = R.out;
+    uint32_t* const errkey = R.errkey;
+    uint64_t* const end_bits = R.end_bits;
     CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
@@ -1101,18 +1107,14 @@ __device__ __forceinline__ void clx_lanes_fused(const uint8_t* __restrict__ aren
     CLX_TL_END(3, blockIdx.x);
 }
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_lanes(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
-                 const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                 uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
-                 const uint32_t* __restrict__ taken, uint32_t gen) {
-    clx_lanes_fused<false>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all, taken, gen);
+void clx_k_lanes(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+                 int32_t* __restrict__ dump_all) {
+    clx_lanes_fused<false>(runs, frames, slot_frame, n_slots, dump_all);
 }
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_lanes_hi(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
-                    const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                    uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
-                    const uint32_t* __restrict__ taken, uint32_t gen) {
-    clx_lanes_fused<true>(arena, arena_alloc_len, frames, slot_frame, n_slots, sf_start, out, errkey, end_bits, dump_all, taken, gen);
+void clx_k_lanes_hi(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+                    int32_t* __restrict__ dump_all) {
+    clx_lanes_fused<true>(runs, frames, slot_frame, n_slots, dump_all);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1462,19 +1464,24 @@ void clx_k_lanes2(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 // F: error keys -> clx_frame_result
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(256)
-void clx_k_finalize(const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ errkey, const uint64_t* __restrict__ end_bits,
-                    uint32_t n_frames, clx_frame_result* __restrict__ results) {
+void clx_k_finalize(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_frames) {
+    const clx_run& R = runs.r[blockIdx.y];
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
     if (f >= n_frames) return;
-    const uint32_t key = errkey[f];
+    const uint32_t key = R.errkey[f];
+    const clx_dev_frame fr = frames[f];
     clx_frame_result r;
     if (key == 0xffffffffu) {
-        r.status = CLX_OK; r.msg = CLX_MSG_NONE; r.end_bit = end_bits[f];
+        r.status = CLX_OK; r.msg = CLX_MSG_NONE; r.end_bit = R.end_bits[f];
         // the footer is read whether or not it is compared (frame.rs:754; under cfg(fuzzing) only the comparison goes away)
-        if (!(frames[f].flags & 1u) && ((r.end_bit + 7ull) & ~7ull) + 16ull > (uint64_t)frames[f].limit_bits) {
+        if (!(fr.flags & 1u) && ((r.end_bit + 7ull) & ~7ull) + 16ull > (uint64_t)fr.limit_bits) {
             r.status = CLX_IO_ERROR; r.msg = CLX_MSG_UNEXPECTED_EOF;
         }
     }
     else { r.status = (int32_t)((key >> 16) & 0xffu); r.msg = key & 0xffffu; r.end_bit = 0; }
-    results[f] = r;
+    R.results[f] = r;
+    // leave the run's scratch as the next run expects to find it (nothing else reads it after this kernel): no error yet, no later
+    // subframe located yet -- the host clears it once, when it is allocated
+    R.errkey[f] = 0xffffffffu;
+    for (uint32_t c = 1; c < fr.n_channels; ++c) R.sf_start[fr.first_slot + c] = 0xffffffffu;
 }

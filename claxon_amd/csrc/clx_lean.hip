@@ -26,10 +26,14 @@
 #endif
 #define CLN_ROW (CLN_RING + 4u)         // slots RING .. RING+3 mirror slots 0 .. 3: a window of five dwords never wraps
 
+// The ring is slot-major -- ring[slot][lane] -- so that a lane's dwords all sit in the lane's own LDS bank (bank = lane mod 32):
+// the lanes of a wave read at unrelated slots (their streams advance at their own pace), and in a lane-major layout those reads
+// collide three to four deep (measured: 56 % of the LDS's active cycles were bank conflicts).
 struct LeanLds {
-    uint32_t ring[64][CLN_ROW];
-    int4 stage[64][4];                  // the turn's 64 x 16 output samples (int4 [row][piece ^ swizzle], as in K2)
+    uint32_t ring[CLN_ROW][64];
+    int4 stage[64][4];                  // the turn's 64 x 16 output samples (int4 [row][piece ^ swizzle])
 };
+#define CLN_AT(col, slot) ((col)[(slot) * 64u])        // dword `slot` of the lane whose column `col` is
 
 // s in [0, 2 * RING) -> s mod RING
 __device__ __forceinline__ uint32_t cln_wrap(uint32_t s) {
@@ -45,9 +49,9 @@ struct LRing {
     uint4 pa, pb;
 };
 __device__ __forceinline__ void cln_put(uint32_t* row, uint32_t s, const uint4 v) {
-    const uint4 b = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
-    *reinterpret_cast<uint4*>(row + s) = b;
-    if (s == 0u) *reinterpret_cast<uint4*>(row + CLN_RING) = b;
+    const uint32_t b0 = __builtin_bswap32(v.x), b1 = __builtin_bswap32(v.y), b2 = __builtin_bswap32(v.z), b3 = __builtin_bswap32(v.w);
+    CLN_AT(row, s) = b0; CLN_AT(row, s + 1u) = b1; CLN_AT(row, s + 2u) = b2; CLN_AT(row, s + 3u) = b3;
+    if (s == 0u) { CLN_AT(row, CLN_RING) = b0; CLN_AT(row, CLN_RING + 1u) = b1; CLN_AT(row, CLN_RING + 2u) = b2; CLN_AT(row, CLN_RING + 3u) = b3; }
 }
 // synchronous fill from the granule that holds dword `d` (the start of the steady state, and after a slow turn)
 __device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t* row, uint32_t d) {
@@ -82,7 +86,7 @@ __device__ __forceinline__ uint32_t cln_slot(const LRing& g, uint32_t d) {
 // 32 bits at bit position p (p >= 1), left aligned, for the partition parameters
 __device__ __forceinline__ uint32_t cln_peek32(const uint32_t* row, const LRing& g, uint32_t p) {
     const uint32_t s = cln_slot(g, (p - 1u) >> 5);
-    return clx_alignbit(row[s], row[s + 1u], 0u - p);
+    return clx_alignbit(CLN_AT(row, s), CLN_AT(row, s + 1u), 0u - p);
 }
 
 // the part of the subframe's state the turns work on
@@ -141,14 +145,17 @@ struct LMover {
 __device__ __forceinline__ void cln_store_tile(const int4* tile, const LMover& M, uint32_t t0, int lane) {
     clx_wave_sync();
     const int4 w0 = tile[lane], w1 = tile[64 + lane], w2 = tile[128 + lane], w3 = tile[192 + lane];
-    if (M.all_real) {
-        *reinterpret_cast<int4*>(M.rq[0] + t0) = w0; *reinterpret_cast<int4*>(M.rq[1] + t0) = w1;
-        *reinterpret_cast<int4*>(M.rq[2] + t0) = w2; *reinterpret_cast<int4*>(M.rq[3] + t0) = w3;
-    } else {
-        *reinterpret_cast<int4*>(M.rq[0] + ((M.adv & 1u) ? t0 : 0u)) = w0; *reinterpret_cast<int4*>(M.rq[1] + ((M.adv & 2u) ? t0 : 0u)) = w1;
-        *reinterpret_cast<int4*>(M.rq[2] + ((M.adv & 4u) ? t0 : 0u)) = w2; *reinterpret_cast<int4*>(M.rq[3] + ((M.adv & 8u) ? t0 : 0u)) = w3;
-    }
+    if (M.all_real) clx_store4x16(M.rq[0] + t0, M.rq[1] + t0, M.rq[2] + t0, M.rq[3] + t0, w0, w1, w2, w3);
+    else clx_store4x16(M.rq[0] + ((M.adv & 1u) ? t0 : 0u), M.rq[1] + ((M.adv & 2u) ? t0 : 0u), M.rq[2] + ((M.adv & 4u) ? t0 : 0u),
+                       M.rq[3] + ((M.adv & 8u) ? t0 : 0u), w0, w1, w2, w3);
     clx_wave_sync();
+}
+// The stage holds one turn's tile; it leaves for HBM at the START of the next turn (and when the kernel ends), so that the stores
+// are a whole turn old when the next counted wait on the vector-memory counter comes (the ring's refill, landed a turn after it
+// was requested): nothing in the steady state waits for a store's round trip.
+struct LTile { bool pending; uint32_t t0; };
+__device__ __forceinline__ void cln_flush(LTile& T, const int4* tile, const LMover& M, int lane) {
+    if (T.pending) { cln_store_tile(tile, M, T.t0, lane); T.pending = false; }          // (wave-uniform)
 }
 
 // j-th coefficient (applies to s[i-1-j]) out of the packed form: C[q] = (c[2q] << 16) | (c[2q+1] & 0xffff)
@@ -231,7 +238,7 @@ __device__ __forceinline__ bool cln_lean_turn(const uint32_t* row, const LRing& 
         uint32_t wa, wb, wc, wd;
         {
             const uint32_t s = cln_slot(g, (c.p - 1u) >> 5);
-            const uint32_t w0 = row[s], w1 = row[s + 1u], w2 = row[s + 2u], w3 = row[s + 3u], w4 = row[s + 4u];
+            const uint32_t w0 = CLN_AT(row, s), w1 = CLN_AT(row, s + 1u), w2 = CLN_AT(row, s + 2u), w3 = CLN_AT(row, s + 3u), w4 = CLN_AT(row, s + 4u);
             const uint32_t sh = 0u - c.p;             // v_alignbit takes the low five bits: (32 - p % 32) % 32
             wa = clx_alignbit(w0, w1, sh); wb = clx_alignbit(w1, w2, sh); wc = clx_alignbit(w2, w3, sh); wd = clx_alignbit(w3, w4, sh);
         }
@@ -295,15 +302,16 @@ __device__ __forceinline__ bool cln_lean_turn(const uint32_t* row, const LRing& 
 template <int NP>
 __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, uint32_t (&H)[2 * NP],
                                          const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2,
-                                         uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, int lane) {
+                                         uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane) {
 
     int4* const tile = stage - 4 * lane;                 // the wave's 64 x 4 staging slots seen as one tile
-    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+    const uint32_t sw = ((uint32_t)lane >> 1) & 3u;      // (eight neighbouring lanes' 16-byte stage stores then cover all 32 banks)
     bool slow = true;                                    // H holds i32 samples (the prologue leaves them so)
     bool ring_ok = false;
     uint32_t nslow = 0;
     for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
         const bool live = n != 0u && !r.err;
+        cln_flush(T, tile, M, lane);                     // the turn before's tile
         if (slow) {
             // back to the lean turns as soon as every live lane's history fits the packed form
             bool in = true;
@@ -323,7 +331,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             else if (mode == 1)       done = cln_lean_turn<NP, 1>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
             else                      done = cln_lean_turn<NP, 2>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
             if (done) {
-                cln_store_tile(tile, M, t0, lane);
+                T.pending = true; T.t0 = t0;
                 CLX_STAT(50, 1);
                 continue;
             }
@@ -354,7 +362,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             const int32_t v = clx_lfinish(s, F);
             ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
         }
-        cln_store_tile(tile, M, t0, lane);
+        T.pending = true; T.t0 = t0;
         ring_ok = false;                                  // the position moved without the ring
     }
     return true;
@@ -363,7 +371,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
 // LPC / fixed parameters of a lane after the prologue, in the lean kernel's form
 template <int NP>
 __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LRing& g, uint32_t* row, int4* stage, uint32_t n, uint32_t i0, uint32_t nmax,
-                                        const LKind& K, int mode, const Finish& F, const LMover& M, int lane) {
+                                        const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane) {
     uint32_t C[NP], H[2 * NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) C[q] = ((uint32_t)S.c[2 * q] << 16) | ((uint32_t)S.c[2 * q + 1] & 0xffffu);
@@ -374,17 +382,24 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     // range in which the packed evaluation is exact: 16-bit factors, and no partial sum of the taps wraps 32 bits
     // (S.lim = min(2^23, (2^31 - 1) / sum|c|), clx_ltransition); a subframe without taps has nothing to keep in range
     const int32_t lim = S.order == 0u ? 0x7fffffff : S.lim < 32768 ? S.lim : 32768;
-    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, mode, F, M, lane);
+    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
 }
 
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_lean(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, const clx_dev_frame* __restrict__ frames,
-                const uint32_t* __restrict__ slot_frame, uint32_t n_slots, const uint32_t* __restrict__ sf_start, int32_t* __restrict__ out,
-                uint32_t* __restrict__ errkey, uint64_t* __restrict__ end_bits, int32_t* __restrict__ dump_all,
-                uint32_t* __restrict__ taken, uint32_t gen) {
+void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+                int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;
+    const clx_run& R = runs.r[blockIdx.y];
+    const uint8_t* const arena = R.arena;
+    const uint64_t arena_alloc_len = R.alloc_len;
+    const uint32_t* const sf_start = R.sf_start;
+    int32_t* const out = R.out;
+    uint32_t* const errkey = R.errkey;
+    uint64_t* const end_bits = R.end_bits;
+    uint32_t* const taken = R.taken;
+    const uint32_t gen = R.gen;
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
     uint32_t f = 0xffffffffu;
@@ -445,7 +460,7 @@ void clx_k_lean(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, con
     // ---- the rows this lane moves (four lanes per row, 16 rows per store), dump slots for rows that do not exist
     LMover M;
     {
-        const uint32_t pc = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u);
+        const uint32_t pc = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 3) & 3u);       // piece ^ swizzle of row (lane >> 2): ((row >> 1) & 3)
         int32_t* const dump = dump_all + (size_t)slot * 16u;
         M.adv = 0;
 #pragma unroll
@@ -477,8 +492,9 @@ void clx_k_lean(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, con
         else { S.phase = 0u; S.trans_at = h.order; }
     }
     const uint32_t i0 = (omax + 4u + 15u) & ~15u;           // 16 or 32 (<= bs)
+    LTile T = { false, 0u };
     int32_t* const ys = reinterpret_cast<int32_t*>(L.stage[lane]);
-    const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+    const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
 #pragma unroll 1
     for (uint32_t i = 0; i < i0; ++i) {
         const int32_t x = clx_lcareful_raw<12>(S, h, bs, i, n);
@@ -488,8 +504,9 @@ void clx_k_lean(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, con
 #pragma unroll
         for (int j = 11; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
+        if ((i & 15u) == 0u) cln_flush(T, L.stage[0], M, lane);
         ys[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
-        if ((i & 15u) == 15u) cln_store_tile(L.stage[0], M, i & ~15u, lane);
+        if ((i & 15u) == 15u) { T.pending = true; T.t0 = i & ~15u; }
     }
     // ---- steady state
     const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
@@ -506,15 +523,16 @@ void clx_k_lean(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len, con
         const bool lv = n != 0u && !S.r.err;
         const int mode = __any(lv && K.verb) ? 2 : __any(lv && !K.rice) ? 1 : 0;          // wave-uniform
         bool done;
-        if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, L.ring[lane], L.stage[lane], n, i0, nmax, K, mode, F, M, lane);
-        else if (omax <= 8u)         done = cln_run<4>(buf, S, g, L.ring[lane], L.stage[lane], n, i0, nmax, K, mode, F, M, lane);
-        else                         done = cln_run<6>(buf, S, g, L.ring[lane], L.stage[lane], n, i0, nmax, K, mode, F, M, lane);
+        if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
+        else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
+        else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
         if (!done) {                                       // given up: clx_k_lanes decodes the group
             if (lane == 0) taken[blockIdx.x] = 0u;
             CLX_STAT(57, 1);
             return;
         }
     }
+    cln_flush(T, L.stage[0], M, lane);                      // the last turn's tile
     // ---- trailing parameters of empty partitions are part of the stream (they move the next subframe / the CRC)
     if (n != 0u && !S.r.err && S.transitioned) {
         while (!S.r.err && S.parts_left != 0u) { (void)clx_lread_rice_param(S.r, S.rice2); S.parts_left -= 1u; }

@@ -141,6 +141,18 @@ __device__ __forceinline__ void clx_ms_pair4(const int32_t (&y)[4], int32_t (&ou
 __device__ __forceinline__ bool clx_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // The value of x as something the optimiser cannot see through (no instruction): keeps an expression in the shape written.
 #define CLX_OPAQUE(x) asm volatile("" : "+v"(x))
+// Four 16-byte stores as ONE asm statement.  hipcc makes the next write of a register that a store of its own has read wait for
+// that store's COMPLETION (s_waitcnt vmcnt(0): a round trip to the L2) -- the hardware only needs the two wait states behind the
+// last store of the statement (the data is read when the store issues).  An asm store is not in hipcc's vmcnt bookkeeping: its
+// counted waits for LOADS can then only be longer than needed, never shorter (loads return in order among themselves), so the
+// stores are placed where the next counted wait is a turn away (clx_lean.hip).
+typedef int clx_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void clx_store4x16(int32_t* p0, int32_t* p1, int32_t* p2, int32_t* p3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
+    const clx_i32x4 a = { w0.x, w0.y, w0.z, w0.w }, b = { w1.x, w1.y, w1.z, w1.w }, c = { w2.x, w2.y, w2.z, w2.w }, d = { w3.x, w3.y, w3.z, w3.w };
+    asm volatile("global_store_dwordx4 %0, %4, off\n\tglobal_store_dwordx4 %1, %5, off\n\tglobal_store_dwordx4 %2, %6, off\n\t"
+                 "global_store_dwordx4 %3, %7, off\n\ts_nop 1"
+                 :: "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
+}
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at lds_base + 16*lane (no VGPR
 // round trip, asynchronous, counted by vmcnt).  Inline asm on purpose: hipcc drains vmcnt(0) before the next LDS read
 // when it can see the DMA, which would serialise a prefetch ring; with asm the waits are placed by hand

@@ -49,6 +49,9 @@ static inline uint4 clx_buf_load16(const clx_buf& b, uint32_t byte_off) {     //
 #define clx_ms_pair4(y, out, sgn, nsg, one) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_pair_(__LINE__, (y)[q_], (sgn), (nsg), (one)); } while (0)
 #define clx_any(p) (wavesim::any_(__LINE__, (p) ? 1 : 0) != 0)
 #define CLX_OPAQUE(x) ((void)(x))
+static inline void clx_store4x16(int32_t* p0, int32_t* p1, int32_t* p2, int32_t* p3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
+    *reinterpret_cast<int4*>(p0) = w0; *reinterpret_cast<int4*>(p1) = w1; *reinterpret_cast<int4*>(p2) = w2; *reinterpret_cast<int4*>(p3) = w3;
+}
 // LDS-DMA in the simulator: synchronous copy; the "LDS address" is simply the host pointer of the shared object.
 static inline uintptr_t clx_lds_addr(const void* p) { return (uintptr_t)p; }
 static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {

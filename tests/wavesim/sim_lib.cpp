@@ -24,30 +24,33 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         std::vector<uint64_t> endbits(n ? n : 1, 0);
         const size_t n_multi = clx_plan_lanes(dev.data(), n, n_slots, slot_frame.data(), multi.data());
         if (n_slots_out) *n_slots_out = n_slots;
-        if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, arena, alloc_len + 16, dev.data(), multi.data(), (uint32_t)n_multi, sf_start.data(), errkey.data());
-        // CLX_LANES_FUSED: the fused kernel; otherwise the two-wave one
+        // one run (the library merges several submissions of a batch into one launch: blockIdx.y; here always run 0)
+        std::vector<uint32_t> taken((n_slots + 63) / 64 + 1, 0u);
+        const bool lean = (flags & CLX_LANES_FUSED) && !(flags & CLX_LANES_GENERAL);
+        clx_runs runs;
+        memset(&runs, 0, sizeof runs);
+        runs.r[0].arena = arena; runs.r[0].alloc_len = alloc_len + 16; runs.r[0].out = out; runs.r[0].sf_start = sf_start.data();
+        runs.r[0].errkey = errkey.data(); runs.r[0].end_bits = endbits.data(); runs.r[0].taken = lean ? taken.data() : nullptr;
+        runs.r[0].results = results; runs.r[0].gen = 7u;
+        if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
+        // CLX_LANES_FUSED: the fused kernels; otherwise the two-wave one
         if (flags & CLX_LANES_FUSED) {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             // the lean kernel first (it marks the groups it decodes with this run's generation number), unless the caller
             // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
-            std::vector<uint32_t> taken((n_slots + 63) / 64 + 1, 0u);
-            const uint32_t gen = 7u;
-            const bool lean = !(flags & CLX_LANES_GENERAL);
-            if (lean)
-                SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
-                           errkey.data(), endbits.data(), dump.data(), taken.data(), gen);
-            for (uint32_t t : taken) sim_stats[52] += t == gen;
-            SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
-                       errkey.data(), endbits.data(), dump.data(), lean ? taken.data() : nullptr, gen);
-            SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
-                       errkey.data(), endbits.data(), dump.data(), lean ? taken.data() : nullptr, gen);
+            if (lean) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
+            for (uint32_t t : taken) sim_stats[52] += t == runs.r[0].gen;
+            SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
+            SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
         } else {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
                        errkey.data(), endbits.data(), dump.data());
         }
-        SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, dev.data(), errkey.data(), endbits.data(), (uint32_t)n, results);
-        if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16, (n + 3) / 4, 256, arena, dev.data(), (uint32_t)n, results);
+        SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, runs, dev.data(), (uint32_t)n);
+        // (the scratch is left ready for a next run)
+        for (size_t i = 0; i < n; ++i) if (errkey[i] != 0xffffffffu) return CLX_API_ERROR;
+        if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16_runs, (n + 3) / 4, 256, runs, dev.data(), (uint32_t)n);
         return CLX_OK;
     }
     SIM_LAUNCH(clx_k_residual, n, 64, arena, alloc_len, dev.data(), (uint32_t)n, out, sfd.data(), results);
