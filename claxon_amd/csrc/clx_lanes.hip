@@ -216,13 +216,17 @@ __device__ __forceinline__ void clx_ring_reset(Ring& g, uint32_t* row, uint32_t 
     g.npend = 0;
     clx_ring_set_lim(g, limit);
 }
-// every 4th block: land the granules requested last time, request new ones while the ring has room
-__device__ __forceinline__ void clx_ring_pump(Ring& g, uint32_t* row, uint32_t pos, uint32_t limit) {
-    const uint32_t dw = pos >> 5;
+// every 4th block: land the granules requested last time, request new ones while the ring has room.  The two halves can be
+// called apart (clx_lanes_body: the landing -- the one place that waits on the vector-memory counter -- goes in front of the
+// turn's stores, a whole turn after the loads were requested, so that it never waits for a store's round trip).
+__device__ __forceinline__ void clx_ring_land(Ring& g, uint32_t* row) {
     if (g.npend >= 1u) { clx_ring_put(row, g.fill, g.pend0); g.fill += 4u; }
     if (g.npend >= 2u) { clx_ring_put(row, g.fill, g.pend1); g.fill += 4u; }
     if (g.npend >= 3u) { clx_ring_put(row, g.fill, g.pend2); g.fill += 4u; }
     g.npend = 0;
+}
+__device__ __forceinline__ void clx_ring_request(Ring& g, uint32_t* row, uint32_t pos, uint32_t limit) {
+    const uint32_t dw = pos >> 5;
     if (dw + 8u > g.fill || dw + CLX_RING < g.fill) clx_ring_reset(g, row, dw, limit);       // ran dry, or the position jumped
     else {
         const uint32_t room = CLX_RING - (g.fill - dw);                                     // dwords that may be overwritten
@@ -231,6 +235,10 @@ __device__ __forceinline__ void clx_ring_pump(Ring& g, uint32_t* row, uint32_t p
         if (room >= 12u) { g.pend2 = clx_ring_fetch(g, g.fill + 8u); g.npend = 3u; }        // 384 bits per 16 codes: 24 bits per code sustained
         clx_ring_set_lim(g, limit);
     }
+}
+__device__ __forceinline__ void clx_ring_pump(Ring& g, uint32_t* row, uint32_t pos, uint32_t limit) {
+    clx_ring_land(g, row);
+    clx_ring_request(g, row, pos, limit);
 }
 __device__ __forceinline__ uint32_t clx_ring_peek32(const uint32_t* row, uint32_t pos) {
     const uint32_t s = (pos >> 5) & (CLX_RING - 1u);
@@ -261,6 +269,17 @@ __device__ __forceinline__ Win clx_win_load64(const uint32_t* row, uint32_t pos)
     w.a = (uint32_t)(((((uint64_t)w0 << 32) | w1) << off) >> 32); w.b = (uint32_t)(((((uint64_t)w1 << 32) | w2) << off) >> 32);
     w.c = (uint32_t)(((((uint64_t)w2 << 32) | w3) << off) >> 32); w.d = (uint32_t)(((((uint64_t)w3 << 32) | w4) << off) >> 32);
     w.e = (uint32_t)(((((uint64_t)w4 << 32) | w5) << off) >> 32);
+    return w;
+}
+// the same from five dwords with funnel shifts only: the window starts in the dword that holds bit p - 1 (p >= 1: a frame header
+// precedes every subframe), so the shift count (32 - p % 32) % 32 never has to be 32 -- v_alignbit takes the low five bits of -p
+__device__ __forceinline__ Win clx_win_load5(const uint32_t* row, uint32_t pos) {
+    const uint32_t s = ((pos - 1u) >> 5) & (CLX_RING - 1u);
+    const uint32_t w0 = row[s], w1 = row[s + 1u], w2 = row[s + 2u], w3 = row[s + 3u], w4 = row[s + 4u];
+    const uint32_t sh = 0u - pos;
+    Win w;
+    w.a = clx_alignbit(w0, w1, sh); w.b = clx_alignbit(w1, w2, sh); w.c = clx_alignbit(w2, w3, sh); w.d = clx_alignbit(w3, w4, sh);
+    w.e = 0u;
     return w;
 }
 // drop nb (1..32) bits
@@ -403,7 +422,7 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames,
                     bad = bad || pc < 4u;                       // (a partition edge inside the four codes: the general block's)
                     pc -= 4u;
                     pw = p;
-                    Win w = clx_win_load64(row, p);
+                    Win w = clx_win_load5(row, p);
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         const uint32_t nb = (uint32_t)__clz((int)w.a) + k1q;   // 32 + k1 when the window is all zeros
@@ -754,7 +773,7 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
     const LeanKind K = clx_lean_kind<OMAX>(S, h);         // (the prologue is over: no lane changes its kind any more)
     const int lean_mode = clx_lean_mode(n != 0u && !r.err, K, S.phase);
     for (uint32_t t0 = i0; t0 < nmax; t0 += 4u) {
-        if ((t0 & 12u) == 0u && t0 != i0) clx_ring_pump(g, ringrow, r.pos, r.limit);
+        if ((t0 & 12u) == 0u && t0 != i0) { clx_ring_land(g, ringrow); clx_ring_request(g, ringrow, r.pos, r.limit); }   // (landed already after a lean turn)
         const bool live = (n != 0u) && !r.err && t0 < n;
         // ---- lean turn: sixteen samples at once when every live lane is in the middle of a Rice partition (or repeats a
         //      constant), nothing is near an edge and the 24-bit predictor holds: four register windows, ONE vote.
@@ -803,10 +822,13 @@ __device__ __forceinline__ void clx_lanes_body(LaneState<OMAX>& S, Ring& g, uint
                 clx_wave_sync();
                 const uint32_t t = t0 + 4u * M.pc;
                 const int4 w0 = tile[lane], w1 = tile[64 + lane], w2 = tile[128 + lane], w3 = tile[192 + lane];
-                *reinterpret_cast<int4*>(t < M.rn[0] ? const_cast<int32_t*>(M.rp[0]) + t : dump + 0) = w0;
-                *reinterpret_cast<int4*>(t < M.rn[1] ? const_cast<int32_t*>(M.rp[1]) + t : dump + 4) = w1;
-                *reinterpret_cast<int4*>(t < M.rn[2] ? const_cast<int32_t*>(M.rp[2]) + t : dump + 8) = w2;
-                *reinterpret_cast<int4*>(t < M.rn[3] ? const_cast<int32_t*>(M.rp[3]) + t : dump + 12) = w3;
+                // The granules requested when the turn began are landed HERE (the wait on the vector-memory counter that goes
+                // with it is a turn old), and the stores are an asm statement the compiler keeps no count of: otherwise the next
+                // write of any register the stores read would wait for their round trip (clx_store4x16, clx_intrin.h).
+                clx_ring_land(g, ringrow);
+                clx_store4x16(t < M.rn[0] ? const_cast<int32_t*>(M.rp[0]) + t : dump + 0, t < M.rn[1] ? const_cast<int32_t*>(M.rp[1]) + t : dump + 4,
+                              t < M.rn[2] ? const_cast<int32_t*>(M.rp[2]) + t : dump + 8, t < M.rn[3] ? const_cast<int32_t*>(M.rp[3]) + t : dump + 12,
+                              w0, w1, w2, w3);
                 clx_wave_sync();
                 t0 += 12u;                                   // the whole turn is done
                 CLX_STAT(16, 1);

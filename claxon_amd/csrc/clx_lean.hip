@@ -22,7 +22,8 @@
 //
 // Mirrors the reference read for read like clx_k_lanes: subframe.rs:29-91, 184-228, 236-380, 492-516, 651-721; frame.rs:319-389.
 #ifndef CLN_RING
-#define CLN_RING 24u                    // stream dwords per lane in the ring (a multiple of 4)
+#define CLN_RING 24u                    // stream dwords per lane in the ring (a multiple of 4).  32 would make the slot a bit field, but the
+                                        // 2 KiB more per wave cost more than the two instructions per window (0.208 against 0.202 ms per step)
 #endif
 #define CLN_ROW (CLN_RING + 4u)         // slots RING .. RING+3 mirror slots 0 .. 3: a window of five dwords never wraps
 
@@ -171,7 +172,7 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finis
         for (int b = 0; b < 4; ++b) {
             const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
             int32_t y[4];
-            clx_ms_pair4(m, y, F.sgn, F.sgn & 1u, 1u);
+            clx_ms_short4(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
             tile[(uint32_t)lane * 4u + ((uint32_t)b ^ sw)] = make_int4(y[0], y[1], y[2], y[3]);
         }
     } else if (F.any_decor) {
@@ -198,8 +199,10 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finis
 // ---- the lean turn -------------------------------------------------------------------------------------------------------
 // H on entry: packed pairs, H[j] = (lo: s[t0-2-j], hi: s[t0-1-j]) for j = 0 .. 2NP-2.  Returns the wave's vote; on success the
 // cursor and H are advanced by sixteen samples (live lanes) and the tile is in the stage.
-template <int NP, int MODE>
-__device__ __forceinline__ bool cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[2 * NP], const uint32_t (&C)[NP],
+// EDGE: some lane's partition ends inside this turn (a parameter may have to be read in front of a four).  Without it the turn is
+// ONE basic block: the compiler then overlaps the LDS round trip of a four's window with the predictor work of the four before.
+template <int NP, int MODE, bool EDGE>
+__device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[2 * NP], const uint32_t (&C)[NP],
                                               uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2, uint32_t limit, bool live, const LKind& K,
                                               const Finish& F, int4* tile, int lane, uint32_t sw) {
     constexpr int NH = 2 * NP - 1;                    // pairs carried from turn to turn
@@ -219,18 +222,20 @@ __device__ __forceinline__ bool cln_lean_turn(const uint32_t* row, const LRing& 
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         // a partition that starts exactly here: its parameter comes first (subframe.rs:314-319 / 362-367)
-        const bool at = c.pcnt == 0u;
-        if (clx_any(at)) {
-            const uint32_t pv = cln_peek32(row, g, c.p);
-            if (at) {
-                c.k = pv >> (32u - pb);
-                bad = bad || c.k == esc || c.parts == 0u || c.next == 0u;
-                c.p += pb; c.parts -= 1u; c.pcnt = c.next; c.next = per;
-                c1 = 31u - c.k;
+        if (EDGE) {
+            const bool at = c.pcnt == 0u;
+            if (clx_any(at)) {
+                const uint32_t pv = cln_peek32(row, g, c.p);
+                if (at) {
+                    c.k = pv >> (32u - pb);
+                    bad = bad || c.k == esc || c.parts == 0u || c.next == 0u;
+                    c.p += pb; c.parts -= 1u; c.pcnt = c.next; c.next = per;
+                    c1 = 31u - c.k;
+                }
+                CLX_OPAQUE(c1);
             }
-            CLX_OPAQUE(c1);
+            bad = bad || c.pcnt < 4u;                 // (a partition edge inside the four codes: the slow turn's)
         }
-        bad = bad || c.pcnt < 4u;                     // (a partition edge inside the four codes: the slow turn's)
         c.pcnt -= 4u;
         const uint32_t kk = c.k & 31u;
         // register window: 128 bits from bit c.p on
@@ -284,12 +289,17 @@ __device__ __forceinline__ bool cln_lean_turn(const uint32_t* row, const LRing& 
     const bool ok = !live || (!bad && msh >= 0 && covered && hi < lim && lo >= -lim);
     const bool all = __all(ok);
     if (!all) { CLX_STAT(53, live && bad); CLX_STAT(54, live && msh < 0); CLX_STAT(55, live && !covered); CLX_STAT(56, live && !(hi < lim && lo >= -lim)); }
-    if (all && live) {
+    if (all) {
+        // every lane takes the turn's end state -- no select per register: what a lane that decodes nothing computed is never
+        // looked at; only its position must stay where its ring is
+        const uint32_t p_in = cur.p;
         cur = c;
+        if (!live) cur.p = p_in;
 #pragma unroll
         for (int j = 0; j < NH; ++j) H[j] = P[NH + 15 - j];
     }
-    return all;
+    if (all) return 1;
+    return __any(live && !(hi < lim && lo >= -lim)) ? -1 : 0;      // (-1: some lane's signal left the range of the packed evaluation)
 }
 
 // Returns false when the wave gives the group up: the slow turn costs about five lean turns, so a wave that keeps needing it
@@ -322,19 +332,28 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
                 for (int j = 0; j < 2 * NP - 1; ++j) H[j] = clx_perm(H[j], H[j + 1], 0x05040100u);      // (lo: s[-2-j], hi: s[-1-j])
                 slow = false;
             }
+            else if (t0 == i0 && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // outside the range from the start
         }
         if (!slow) {
             if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
             else cln_pump(buf, g, row, cur.p);
-            bool done;
-            if (mode == 0 || NP == 2) done = cln_lean_turn<NP, 0>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);     // (NP == 2 is only run with mode 0)
-            else if (mode == 1)       done = cln_lean_turn<NP, 1>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
-            else                      done = cln_lean_turn<NP, 2>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
-            if (done) {
+            int done;
+            if (mode == 0 || NP == 2) {                // (NP == 2 is only run with mode 0)
+                // a partition edge inside the turn?  (lanes that decode nothing never say yes; cur.pcnt of the others is exact)
+                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                else                                 done = cln_lean_turn<NP, 0, false>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            }
+            else if (mode == 1)       done = cln_lean_turn<NP, 1, true>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            else                      done = cln_lean_turn<NP, 2, true>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            if (done > 0) {
                 T.pending = true; T.t0 = t0;
                 CLX_STAT(50, 1);
                 continue;
             }
+            // A signal outside the 16-bit range usually stays there for a while (a loud side channel): the general kernels' 24-bit
+            // tier takes such lanes at full speed, the slow turn below at a fifth of it -- give the group up at once, while little
+            // has been spent on it.  (Other failures are isolated events: a long code, a partition edge, the ring.)
+            if (done < 0 && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;
             // the turn goes the slow way from where it started: unpack the history (sign-extended halves)
             uint32_t U[2 * NP];
 #pragma unroll
@@ -381,7 +400,8 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     if (n == 0u) cur.p = 32u;            // a lane that decodes nothing rides along from a harmless position (never committed)
     // range in which the packed evaluation is exact: 16-bit factors, and no partial sum of the taps wraps 32 bits
     // (S.lim = min(2^23, (2^31 - 1) / sum|c|), clx_ltransition); a subframe without taps has nothing to keep in range
-    const int32_t lim = S.order == 0u ? 0x7fffffff : S.lim < 32768 ? S.lim : 32768;
+    // (a subframe without taps has no history to keep in range; 2^29 is what the short mid/side form needs)
+    const int32_t lim = S.order == 0u ? (1 << 29) : S.lim < 32768 ? S.lim : 32768;
     const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;

@@ -153,6 +153,33 @@ __device__ __forceinline__ void clx_store4x16(int32_t* p0, int32_t* p1, int32_t*
                  "global_store_dwordx4 %3, %7, off\n\ts_nop 1"
                  :: "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
+// Mid/side reconstruction of four samples for lane pairs (even lane = mid -> left, odd lane = side -> right), the short form:
+//   left = mid + ((side + 1) >> 1),   right = mid - (side >> 1) = mid + ((-side + 1) >> 1)
+// which equals frame.rs:382-384's ((2 mid | side & 1) +- side) / 2 while nothing wraps (|mid|, |side| < 2^29: the caller's range
+// check).  sgn = odd lane ? ~0 : 0, c = odd lane ? 2 : 1, so that both are  mid + (((side ^ sgn) + c) >> 1).  Four instructions
+// per sample; one statement per four samples (the two wait states in front of the first DPP read are paid once).
+__device__ __forceinline__ void clx_ms_short4(const int32_t (&y)[4], int32_t (&out)[4], uint32_t sgn, uint32_t c) {
+    uint32_t t;
+    asm volatile("s_nop 1\n\t"
+                 "v_xor_b32_dpp %4, %5, %9 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32 %4, %4, %10\n\t"
+                 "v_ashrrev_i32 %4, 1, %4\n\t"
+                 "v_add_u32_dpp %0, %5, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %4, %6, %9 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32 %4, %4, %10\n\t"
+                 "v_ashrrev_i32 %4, 1, %4\n\t"
+                 "v_add_u32_dpp %1, %6, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %4, %7, %9 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32 %4, %4, %10\n\t"
+                 "v_ashrrev_i32 %4, 1, %4\n\t"
+                 "v_add_u32_dpp %2, %7, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %4, %8, %9 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32 %4, %4, %10\n\t"
+                 "v_ashrrev_i32 %4, 1, %4\n\t"
+                 "v_add_u32_dpp %3, %8, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
+                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(sgn), "v"(c));
+}
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at lds_base + 16*lane (no VGPR
 // round trip, asynchronous, counted by vmcnt).  Inline asm on purpose: hipcc drains vmcnt(0) before the next LDS read
 // when it can see the DMA, which would serialise a prefetch ring; with asm the waits are placed by hand

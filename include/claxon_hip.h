@@ -261,27 +261,28 @@ int  clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size_t n,
                       const uint64_t* out_sample_offsets, uint32_t flags, clx_batch** out);
 int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                    int32_t* d_out, void* stream);
-/* Pipelined submission: the same work and the same results as clx_batch_run, with several submissions in flight -- each a
- * whole run on an internal stream of its own with its own scratch buffers and results (the reference has no counterpart: one
- * FrameReader decodes one frame at a time, frame.rs:667).  Which kernels a batch's submissions use is chosen for throughput
- * (clx_batch_submit_lanes): usually the lane kernels, fused build -- a run of those is one serial chain per subframe that
- * occupies a fraction of the machine's registers for 0.9-1.3 ms, and a dozen of them side by side fill it --; the wave kernels,
- * four in flight, for small batches of short codes.  The internal streams want a hardware queue each: set
- * GPU_MAX_HW_QUEUES=16 in the environment before the HIP runtime starts (its default of 4 makes them share queues:
- * 0.32 instead of 0.18 ms per 10 000 stereo frames; clx_create sets it when it is unset, which helps when clx_create is the
- * process's first HIP call).
- * A submission starts after everything queued on `stream` so far.  Give the submissions in flight different `d_out` buffers,
- * i.e. rotate over clx_batch_submit_depth(b) of them (re-using a buffer is legal: the submission then waits for the earlier
- * one that writes it).  Work enqueued on `stream` after clx_batch_flush sees every submission finished; clx_batch_results
- * flushes by itself and returns the LAST submission's results. */
+/* Pipelined submission: the same work and the same results as clx_batch_run, with several submissions in flight (the reference
+ * has no counterpart: one FrameReader decodes one frame at a time, frame.rs:667).  Which kernels a batch's submissions use is
+ * chosen for throughput (clx_batch_submit_lanes):
+ *   - usually the lane kernels, fused build.  One run of those is a serial chain per subframe on a fraction of the machine, and
+ *     the machine runs only a handful of kernels from different queues side by side -- so consecutive submissions are MERGED:
+ *     they wait until a few of them are there (or until somebody flushes / asks for results) and go out as ONE grid whose second
+ *     dimension is the submission, on two internal streams in turn (the scan stage of one launch overlaps the decode stage of
+ *     the other).  Every submission has its own scratch buffers and results.  No environment variable is involved: two internal
+ *     streams fit HIP's default number of hardware queues.
+ *   - the wave kernels, four in flight on internal streams of their own, for small batches of short codes.
+ * A submission starts no earlier than everything queued on `stream` when it (or a later one merged with it) was submitted.  Give
+ * the submissions in flight different `d_out` buffers, i.e. rotate over clx_batch_submit_depth(b) of them (re-using a buffer is
+ * legal: the submission then goes out after the earlier one that writes it).  Submissions may stay pending until
+ * clx_batch_flush: work enqueued on `stream` after it sees every submission finished; clx_batch_results and
+ * clx_batch_interleave flush by themselves; clx_batch_results returns the LAST submission's results. */
 #ifndef CLX_SUBMIT_DEPTH
 #define CLX_SUBMIT_DEPTH 12     /* the most submissions any batch keeps in flight */
 #endif
 int  clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                       int32_t* d_out, void* stream);
 /* How many submissions THIS batch keeps in flight, i.e. how many output buffers to rotate over: 4 for the wave kernels, 12 for
- * the lane kernels (a run of those is one serial chain per subframe on a fraction of the machine's registers: a dozen side by
- * side fill it), 1 where a submission is a plain run. */
+ * the lane kernels (two merged launches of six), 1 where a submission is a plain run. */
 int  clx_batch_submit_depth(const clx_batch* b);
 int  clx_batch_submit_lanes(const clx_batch* b);      /* 1: its pipelined submissions run the fused lane kernels */
 int  clx_batch_flush(clx_batch* b, void* stream);

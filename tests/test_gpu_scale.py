@@ -80,6 +80,47 @@ def test_auto_lane_path_fused(oracle, ctx, big3):
                     forbid=["clx_k_residual", "clx_k_lanes2"])
 
 
+def test_bench_configuration_against_the_oracle(oracle, ctx):
+    """Exactly what bench.py times (BASELINE configs[2]): 10 000 stereo 4096-sample 16-bit mid/side LPC-8 frames, the library's own
+    kernel choice, CRC-16 verified in the step, consecutive steps submitted with submit_depth output buffers in rotation (the fused
+    lane kernels, lean 16-bit tier, several submissions merged per launch) -- every buffer, every status, message and end bit
+    against the oracle, over more steps than buffers so that every scratch set and both internal streams are used twice."""
+    import torch
+    w = synth.config3(10000)
+    descs = pc.workload_descs(w)
+    d_arenas = [torch.from_numpy(w.arena).to("cuda:0") for _ in range(2)]
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True)
+    depth = batch.submit_depth
+    assert depth == cx.SUBMIT_DEPTH and batch.submit_lanes          # the pipelined choice for this workload: fused lane kernels
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(depth)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(2 * depth + 5):
+        batch.submit(d_arenas[i % 2].data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.array_equal(res["status"], r["statuses"]) and np.all(res["status"] == cx.OK)
+    assert np.array_equal(res["msg"], r["msgs"])
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    d_ref = torch.from_numpy(ref).to("cuda:0")
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o, d_ref)), "output buffer %d differs from the oracle" % k
+    assert np.array_equal(ref, w.pcm)
+    # one run at a time with the same kernels, profiled: the 16-bit tier decoded every group (the general kernels found nothing)
+    bl = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED)
+    bl.set_profiling(True)
+    outs[0].fill_(0x13131313)
+    bl.run(d_arenas[0].data_ptr(), w.arena_len, outs[0].data_ptr())
+    torch.cuda.synchronize()
+    kt = bl.kernel_times()
+    assert {"clx_k_scan", "clx_k_lean", "clx_k_lanes", "clx_k_finalize", "clx_k_crc16"} <= set(kt), sorted(kt)
+    assert kt["clx_k_lanes"] < 0.05 * kt["clx_k_lean"], kt           # (ms: clx_k_lanes + _hi only looked at the taken flags)
+    assert bool(torch.equal(outs[0], d_ref))
+    bl.close(); batch.close()
+
+
 def test_forced_builds_at_scale(oracle, ctx, big3):
     """The builds the thresholds would not pick at this size, forced by flag on the same 12 288 frames."""
     w = pc.head(big3, 12288)

@@ -52,6 +52,12 @@ static inline uint4 clx_buf_load16(const clx_buf& b, uint32_t byte_off) {     //
 static inline void clx_store4x16(int32_t* p0, int32_t* p1, int32_t* p2, int32_t* p3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
     *reinterpret_cast<int4*>(p0) = w0; *reinterpret_cast<int4*>(p1) = w1; *reinterpret_cast<int4*>(p2) = w2; *reinterpret_cast<int4*>(p3) = w3;
 }
+static inline int32_t clx_ms_short_(int line, int32_t y, uint32_t sgn, uint32_t c) {
+    const uint32_t side = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xF5, 0xF, 0xF, false);
+    const uint32_t mid = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xA0, 0xF, 0xF, false);
+    return (int32_t)(mid + (uint32_t)((int32_t)((side ^ sgn) + c) >> 1));
+}
+#define clx_ms_short4(y, out, sgn, c) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_short_(__LINE__, (y)[q_], (sgn), (c)); } while (0)
 // LDS-DMA in the simulator: synchronous copy; the "LDS address" is simply the host pointer of the shared object.
 static inline uintptr_t clx_lds_addr(const void* p) { return (uintptr_t)p; }
 static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {
