@@ -227,10 +227,11 @@ struct clx_stream_slot {
 };
 
 #ifndef CLX_SUBMIT_MERGE
-#define CLX_SUBMIT_MERGE 6             // runs per merged launch of the fused lane kernels (<= CLX_MAX_MERGE)
+#define CLX_SUBMIT_MERGE 4             // runs per merged launch of the fused lane kernels (<= CLX_MAX_MERGE); 4 x 3, 6 x 2, 3 x 4 and 2 x 6 are
+                                       // within a few percent of each other (profiles/r03_merge_sweep.txt)
 #endif
 #ifndef CLX_SUBMIT_STREAMS
-#define CLX_SUBMIT_STREAMS 2           // internal streams the merged launches rotate over (MERGE * STREAMS <= CLX_SUBMIT_DEPTH)
+#define CLX_SUBMIT_STREAMS 3           // internal streams the merged launches rotate over (MERGE * STREAMS <= CLX_SUBMIT_DEPTH)
 #endif
 static_assert(CLX_SUBMIT_MERGE <= CLX_MAX_MERGE && CLX_SUBMIT_STREAMS * CLX_SUBMIT_MERGE <= CLX_SUBMIT_DEPTH && CLX_SUBMIT_STREAMS <= 6, "merge width");
 
@@ -303,7 +304,7 @@ struct clx_batch {
     // The machine runs only a handful of kernels from different queues side by side however many queues there are (measured:
     // about six), and one run of these kernels is a serial chain per subframe on a fraction of the machine -- so filling it takes one
     // grid that holds many runs, not many streams.  Submissions wait in `pend` until kMerge of them are there (or somebody asks for
-    // results / flushes); merged launches alternate between two internal streams, so that the scan stage of one overlaps the
+    // results / flushes); merged launches rotate over three internal streams, so that the scan stage of one overlaps the
     // decode stage of the other.  Flights are only the runs' scratch buffers here.
     enum { kMerge = CLX_SUBMIT_MERGE, kStreams = CLX_SUBMIT_STREAMS, kMaxStreams = 6 };
     int merge = kMerge, n_streams = kStreams;          // (CLX_TUNE_MERGE / CLX_TUNE_STREAMS in the environment override them: tuning only)

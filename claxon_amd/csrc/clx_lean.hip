@@ -46,8 +46,8 @@ __device__ __forceinline__ uint32_t cln_wrap(uint32_t s) {
 struct LRing {
     uint32_t origin;        // byte offset of the lane's 16-byte aligned stream origin in the arena
     uint32_t fill, fs;      // stream dwords [fill - RING, fill) are in the ring; fs = fill mod RING (the slot `fill` goes to)
-    uint32_t np;            // granules requested at the last pump (0..2), in pa / pb
-    uint4 pa, pb;
+    uint32_t np;            // granules requested at the last pump (0..3), in pa / pb / pc
+    uint4 pa, pb, pc;
 };
 __device__ __forceinline__ void cln_put(uint32_t* row, uint32_t s, const uint4 v) {
     const uint32_t b0 = __builtin_bswap32(v.x), b1 = __builtin_bswap32(v.y), b2 = __builtin_bswap32(v.z), b3 = __builtin_bswap32(v.w);
@@ -68,15 +68,18 @@ __device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t
     }
     g.fill = f0 + CLN_RING; g.fs = s0; g.np = 0;
 }
-// once per turn: land what was requested a turn ago, request what fits now (two granules: 16 bits per code sustained)
+// once per turn: land what was requested a turn ago, request what fits now (three granules: 24 bits per code sustained -- a
+// verbatim subframe of 17-bit samples takes 272 bits per turn)
 __device__ __forceinline__ void cln_pump(const clx_buf& buf, LRing& g, uint32_t* row, uint32_t p) {
     if (g.np >= 1u) { cln_put(row, g.fs, g.pa); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
     if (g.np >= 2u) { cln_put(row, g.fs, g.pb); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    if (g.np >= 3u) { cln_put(row, g.fs, g.pc); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
     const uint32_t d = (p - 1u) >> 5;                                   // the oldest dword a window may still read
     const int32_t room = (int32_t)(CLN_RING + d - g.fill);                // slots that hold dwords before d
     g.np = 0;
     if (room >= 4) { g.pa = clx_buf_load16(buf, g.origin + 4u * g.fill); g.np = 1u; }
     if (room >= 8) { g.pb = clx_buf_load16(buf, g.origin + 4u * g.fill + 16u); g.np = 2u; }
+    if (room >= 12) { g.pc = clx_buf_load16(buf, g.origin + 4u * g.fill + 32u); g.np = 3u; }
 }
 // slot of stream dword d, for d in [fill - RING, fill)
 __device__ __forceinline__ uint32_t cln_slot(const LRing& g, uint32_t d) {
@@ -96,13 +99,15 @@ struct LCur { uint32_t p, k, pcnt, next, parts; };
 
 // What a lane does in the steady state (fixed once the prologue is over): Rice codes, verbatim fields (subframe.rs:397-415) or a
 // constant (382-394).  The three kinds share one instruction stream; the masks that make them do so are compiled in only for
-// waves that hold a lane of the rarer kinds (MODE 1: constants, MODE 2: verbatim fields).
+// waves that hold a lane of the rarer kinds (MODE 1).
 struct LKind {
     bool rice, verb;
     uint32_t bitmask;        // all ones where the lane consumes bits (Rice, verbatim), 0 for a constant
     uint32_t ricemask;       // all ones for Rice lanes: only their codes can outgrow the window register
+    uint32_t verbmask;       // all ones for verbatim lanes
     uint32_t cor;            // the constant, OR-ed in for constant lanes
     uint32_t vsh;            // 32 - (width of a verbatim field)
+    uint32_t vshm;           // vsh for verbatim lanes, 0 for the others: what is left of the window register behind a field
 };
 
 // One sample's raw value the careful way (generic reader over global memory; every rare case in line): partition parameters
@@ -201,14 +206,24 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finis
 // cursor and H are advanced by sixteen samples (live lanes) and the tile is in the stage.
 // EDGE: some lane's partition ends inside this turn (a parameter may have to be read in front of a four).  Without it the turn is
 // ONE basic block: the compiler then overlaps the LDS round trip of a four's window with the predictor work of the four before.
-template <int NP, int MODE, bool EDGE>
+// WIDE: the same turn for waves in which a lane's signal is outside the 16-bit range (a loud side channel): H holds i32 samples
+// (H[j] = s[t0-1-j]) and the predictor is a chain of v_mad_i32_i24 on the unpacked coefficients CW -- exact while every history
+// sample lies in [-lim, lim) with lim <= 2^23 and sum|c| * lim < 2^31 (clx_ltransition's S.lim; checked on the data like the packed
+// form's).  Twice the predictor instructions of the packed form, everything else the same.
+template <int NP, int MODE, bool EDGE, bool WIDE>
 __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[2 * NP], const uint32_t (&C)[NP],
-                                              uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2, uint32_t limit, bool live, const LKind& K,
-                                              const Finish& F, int4* tile, int lane, uint32_t sw) {
+                                              const int32_t (&CW)[2 * NP], uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2, uint32_t limit,
+                                              bool live, const LKind& K, const Finish& F, int4* tile, int lane, uint32_t sw) {
     constexpr int NH = 2 * NP - 1;                    // pairs carried from turn to turn
     uint32_t P[NH + 16];                              // P[NH + m] = pair that ends at sample m of the turn (m = -NH .. 15)
+    int32_t hw[2 * NP + 16];                          // WIDE: hw[2NP - 1 - j + i] = s[i - 1 - j]: the samples in time order, the turn's own appended
+    if (!WIDE) {
 #pragma unroll
-    for (int j = 0; j < NH; ++j) P[NH - 1 - j] = H[j];
+        for (int j = 0; j < NH; ++j) P[NH - 1 - j] = H[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) hw[2 * NP - 1 - j] = (int32_t)H[j];
+    }
     LCur c = cur;
     if (MODE == 0 ? !live : !(live && K.rice)) c.pcnt = 0x7fffff00u;      // (lanes without Rice codes never meet a partition edge)
     uint32_t c1 = 31u - c.k;
@@ -258,22 +273,27 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             uint32_t xr = (u >> 1) ^ (0u - (u & 1u));                      // rice_to_signed (subframe.rs:157-170)
             if (MODE == 0) msh = sh < msh ? sh : msh;
             else {
+                // constants and verbatim fields (subframe.rs:382-415) ride along under masks -- no branch, no select on a condition
                 const int32_t shr = (int32_t)((uint32_t)sh & K.ricemask);   // (only a Rice code can be too long)
                 msh = shr < msh ? shr : msh;
-                if (MODE == 2) {                                            // verbatim rows ride along (subframe.rs:397-415)
-                    xr = K.verb ? (uint32_t)((int32_t)wa >> K.vsh) : xr;
-                    sh = K.verb ? (int32_t)K.vsh : sh;
-                }
-                xr = (xr & K.bitmask) | K.cor;
+                const uint32_t xv = (uint32_t)((int32_t)wa >> K.vsh);
+                xr = ((xr & K.ricemask) | (xv & K.verbmask)) | K.cor;
+                sh = (int32_t)((uint32_t)shr | K.vshm);
             }
             shsum += (uint32_t)sh;
             wa = clx_alignbit(wa, wb, (uint32_t)sh); wb = clx_alignbit(wb, wc, (uint32_t)sh); wc = clx_alignbit(wc, wd, (uint32_t)sh); wd = clx_alignbit(wd, 0u, (uint32_t)sh);
-            // predictor on packed pairs, oldest first: only the last term depends on the sample before
+            // predictor, oldest tap first: only the last term depends on the sample before
             int32_t acc = 0;
+            if (!WIDE) {
 #pragma unroll
-            for (int q = NP - 1; q >= 0; --q) acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
+                for (int q = NP - 1; q >= 0; --q) acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
+            } else {
+#pragma unroll
+                for (int j = 2 * NP - 1; j >= 0; --j) acc = __mul24(CW[j], hw[2 * NP - 1 - j + i]) + acc;      // c[j] * s[i-1-j]: v_mad_i32_i24
+            }
             const int32_t s = (int32_t)(xr + (uint32_t)(acc >> shift));                             // + prediction (wrapping)
-            P[NH + i] = clx_perm((uint32_t)s, P[NH + i - 1], 0x05040302u);                          // (lo: the sample before, hi: this one)
+            if (!WIDE) P[NH + i] = clx_perm((uint32_t)s, P[NH + i - 1], 0x05040302u);               // (lo: the sample before, hi: this one)
+            else hw[2 * NP + i] = s;
             hi = s > hi ? s : hi; lo = s < lo ? s : lo;
             S16[i] = s;
         }
@@ -295,11 +315,20 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
         const uint32_t p_in = cur.p;
         cur = c;
         if (!live) cur.p = p_in;
+        if (!WIDE) {
 #pragma unroll
-        for (int j = 0; j < NH; ++j) H[j] = P[NH + 15 - j];
+            for (int j = 0; j < NH; ++j) H[j] = P[NH + 15 - j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * NP; ++j) H[j] = (uint32_t)hw[2 * NP + 15 - j];
+        }
     }
     if (all) return 1;
-    return __any(live && !(hi < lim && lo >= -lim)) ? -1 : 0;      // (-1: some lane's signal left the range of the packed evaluation)
+    // why not: 0 a rare case the slow turn handles (a partition edge inside a four, an escape code, a code longer than 32 bits, the
+    // end of the frame), -1 some lane's signal left the range of this evaluation, -2 nothing but the ring having run dry
+    if (__any(live && (bad || msh < 0 || c.p > limit))) return 0;
+    if (__any(live && !(hi < lim && lo >= -lim))) return -1;
+    return -2;
 }
 
 // Returns false when the wave gives the group up: the slow turn costs about five lean turns, so a wave that keeps needing it
@@ -311,7 +340,8 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
 #endif
 template <int NP>
 __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, uint32_t (&H)[2 * NP],
-                                         const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2,
+                                         const uint32_t (&C)[NP], const int32_t (&CW)[2 * NP], uint32_t order, uint32_t shift, int32_t lim, int32_t lim24,
+                                         uint32_t per, uint32_t rice2,
                                          uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane) {
 
     int4* const tile = stage - 4 * lane;                 // the wave's 64 x 4 staging slots seen as one tile
@@ -332,29 +362,27 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
                 for (int j = 0; j < 2 * NP - 1; ++j) H[j] = clx_perm(H[j], H[j + 1], 0x05040100u);      // (lo: s[-2-j], hi: s[-1-j])
                 slow = false;
             }
-            else if (t0 == i0 && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // outside the range from the start
         }
+        if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
+        else cln_pump(buf, g, row, cur.p);
+        const bool was_slow = slow;                      // (no lean turn is tried: the history does not fit the packed form)
+        int done = 0;
+        bool refilled = false;                           // the ring was refilled on the spot once in this turn (a lane outran it)
         if (!slow) {
-            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
-            else cln_pump(buf, g, row, cur.p);
-            int done;
+          again_lean:
             if (mode == 0 || NP == 2) {                // (NP == 2 is only run with mode 0)
                 // a partition edge inside the turn?  (lanes that decode nothing never say yes; cur.pcnt of the others is exact)
-                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
-                else                                 done = cln_lean_turn<NP, 0, false>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true, false>(row, g, cur, H, C, CW, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                else                                 done = cln_lean_turn<NP, 0, false, false>(row, g, cur, H, C, CW, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
             }
-            else if (mode == 1)       done = cln_lean_turn<NP, 1, true>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
-            else                      done = cln_lean_turn<NP, 2, true>(row, g, cur, H, C, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            else                      done = cln_lean_turn<NP, 1, true, false>(row, g, cur, H, C, CW, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
             if (done > 0) {
                 T.pending = true; T.t0 = t0;
                 CLX_STAT(50, 1);
                 continue;
             }
-            // A signal outside the 16-bit range usually stays there for a while (a loud side channel): the general kernels' 24-bit
-            // tier takes such lanes at full speed, the slow turn below at a fifth of it -- give the group up at once, while little
-            // has been spent on it.  (Other failures are isolated events: a long code, a partition edge, the ring.)
-            if (done < 0 && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;
-            // the turn goes the slow way from where it started: unpack the history (sign-extended halves)
+            if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; CLX_STAT(59, 1); goto again_lean; }
+            // not this way: the turn is taken again from where it started, on the unpacked history (sign-extended halves)
             uint32_t U[2 * NP];
 #pragma unroll
             for (int j = 0; j < 2 * NP - 1; ++j) U[j] = (uint32_t)((int32_t)H[j] >> 16);
@@ -362,6 +390,24 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
 #pragma unroll
             for (int j = 0; j < 2 * NP; ++j) H[j] = U[j];
             slow = true;
+        }
+        // ---- wide turn: a lane's signal is outside the 16-bit range (a loud side channel usually stays there for a while) but
+        //      inside the 24-bit one: the same turn with v_mad_i32_i24 on the i32 history.  (After a lean turn that failed for
+        //      another reason -- a long code, a partition edge, the ring -- it would fail the same way: the slow turn's.)
+        if (was_slow || done < 0) {
+            bool in24 = true;
+#pragma unroll
+            for (int j = 0; j < 2 * NP; ++j) in24 = in24 && (int32_t)H[j] < lim24 && (int32_t)H[j] >= -lim24;
+            if (__all(in24 || !live || order == 0u)) {
+              again_wide:
+                const int dw = cln_lean_turn<NP, 1, true, true>(row, g, cur, H, C, CW, shift, lim24, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                if (dw > 0) {
+                    T.pending = true; T.t0 = t0;
+                    CLX_STAT(58, 1);
+                    continue;
+                }
+                if (dw == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; CLX_STAT(59, 1); goto again_wide; }
+            }
         }
         CLX_STAT(51, 1);
         if (++nslow > CLN_SLOW_BUDGET && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // (wave-uniform; not when the end is near anyway)
@@ -402,7 +448,12 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     // (S.lim = min(2^23, (2^31 - 1) / sum|c|), clx_ltransition); a subframe without taps has nothing to keep in range
     // (a subframe without taps has no history to keep in range; 2^29 is what the short mid/side form needs)
     const int32_t lim = S.order == 0u ? (1 << 29) : S.lim < 32768 ? S.lim : 32768;
-    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane);
+    int32_t CW[2 * NP];
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) CW[j] = S.c[j];
+    // the 24-bit evaluation's range (clx_ltransition), under the same cap for subframes without taps
+    const int32_t lim24 = S.order == 0u ? (1 << 29) : S.lim;
+    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, CW, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
 }
@@ -531,17 +582,19 @@ void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
     // ---- steady state
     const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
     LRing g;
-    g.origin = r.origin; g.fill = 0; g.fs = 0; g.np = 0; g.pa = make_uint4(0u, 0u, 0u, 0u); g.pb = g.pa;
+    g.origin = r.origin; g.fill = 0; g.fs = 0; g.np = 0; g.pa = make_uint4(0u, 0u, 0u, 0u); g.pb = g.pa; g.pc = g.pa;
     if (i0 < nmax) {
         // what every lane does from here on (the prologue is over: predicted subframes have switched to residuals)
         LKind K;
         K.rice = S.phase == 1u; K.verb = S.phase == 0u;
         K.bitmask = S.phase == 2u ? 0u : 0xffffffffu;
         K.ricemask = K.rice ? 0xffffffffu : 0u;
+        K.verbmask = K.verb ? 0xffffffffu : 0u;
         K.cor = S.phase == 2u ? (uint32_t)S.cval : 0u;
         K.vsh = (32u - h.sf_bps) & 31u;
+        K.vshm = K.verb ? K.vsh : 0u;
         const bool lv = n != 0u && !S.r.err;
-        const int mode = __any(lv && K.verb) ? 2 : __any(lv && !K.rice) ? 1 : 0;          // wave-uniform
+        const int mode = __any(lv && !K.rice) ? 1 : 0;                                    // wave-uniform: the mixed form or the plain one
         bool done;
         if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
         else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);

@@ -292,7 +292,7 @@ def lean_workload(scale=1):
             return (L, R), fp
         family(144, 32, 2, mk_c)
         # (d) loud and out of phase: the side channel leaves the 16-bit range -- for four turns in every frame of the first family
-        #     (the wave goes through slow turns and returns to lean ones), for good in frames of the second (it gives the group up)
+        #     (the wave goes through wide turns -- the 24-bit form -- and returns to lean ones), for good in frames of the second
         for burst in (True, False):
             def mk_d(i, burst=burst):
                 bs = 2048

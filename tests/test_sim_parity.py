@@ -142,12 +142,12 @@ def test_sim_lean_tiers(oracle):
     for i in range(64):
         stats[i] = 0
     pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
-    lean, slow, taken = stats[50] // 64, stats[51] // 64, stats[52]
+    lean, slow, wide, taken = stats[50] // 64, stats[51] // 64, stats[58] // 64, stats[52]
     why = {"partition edge inside a four / escape": stats[53], "code longer than 32 bits": stats[54], "ring ran dry / end of frame": stats[55],
            "history outside the 16-bit range": stats[56]}
-    assert lean > 300 and slow > 20 and taken >= 8, (lean, slow, taken)
+    assert lean > 300 and slow > 10 and wide > 50 and taken >= 8, (lean, slow, wide, taken)      # wide: the 24-bit form of the turn (loud side channels)
     assert all(v > 0 for v in why.values()), why
-    assert stats[57] // 64 >= 2          # groups given up to the general kernels (and still bit-exact: they decoded them)
+    assert stats[57] // 64 >= 1          # groups given up to the general kernels (and still bit-exact: they decoded them)
 
 
 def test_sim_lean_takes_the_bench_shapes(oracle):
