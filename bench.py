@@ -25,10 +25,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The library keeps several submissions in flight on internal streams (clx_batch_submit); a hardware queue per stream lets their
-# kernels overlap as intended.  HIP's default is 4 queues for the whole process, which the internal streams then share in pairs
-# (0.33 instead of 0.30 ms per step).  Has to be in the environment before the HIP runtime starts; carried in the JSON line.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (No HIP environment variable is set here: the timed steps go out as merged launches on three internal streams of the library,
+# which HIP's default number of hardware queues covers.  GPU_MAX_HW_QUEUES, if the caller sets it, is carried in the line.)
 
 import numpy as np  # noqa: E402
 
@@ -193,7 +191,10 @@ def main():
     # never less than max(kernel), never more than their sum when steps do not overlap
     t_path_ms = ms_per_step if pipelined else path_ms
     achieved = alg_bytes / (t_path_ms * 1e-3) / 1e9
-    traffic, traffic_src = _pmc_traffic(args.workload + path_tag, w.n)
+    # (which committed profile the counters come from: the fused lane kernels when the timed steps ran them -- pipelined
+    #  submissions of these workloads do --, else the kernels clx_batch_run selected)
+    timed_lanes = "clx_k_lean" in kernel_ms or "clx_k_lanes" in kernel_ms
+    traffic, traffic_src, prof = _pmc_traffic(args.workload + ("_lanes" if timed_lanes else ""), w.n)
     roofline = {"bound": "hbm", "kernel": "+".join(kernel_ms.keys()), "achieved": round(achieved, 1), "peak": PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "path_ms": round(t_path_ms, 4), "path_ms_basis": ("ms_per_step of the pipelined steps (kernels of consecutive steps overlap)" if pipelined
@@ -205,6 +206,21 @@ def main():
                                     "note": "one of the path's kernels; the path's bytes over its time alone would overstate it"},
                 "step_achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_GBS, 4)}
+    if prof and prof.get("insts"):
+        # What actually bounds these kernels: the SIMDs' instruction issue.  A SIMD of gfx950 takes one vector
+        # instruction per ~4.2 cycles whatever it is (2.3 for the simplest: mov / add / logic / shift), a scalar one between vector
+        # ones ~2.2, an LDS one ~8 (profiles/r03_ubench_valu_cost.txt, r02_ubench_valu_peak.txt); the counts are wave-instructions
+        # per launch from the same committed --pmc profile as `traffic`.
+        ins = prof["insts"].values()
+        valu, salu, lds = (sum(k[c] for k in ins) for c in ("valu", "salu", "lds"))
+        smp = float(prof.get("samples_per_launch") or w.total_samples)
+        cyc = (4.2 * valu + 2.2 * salu + 8.0 * lds) / 1024.0                 # per SIMD (256 CUs x 4)
+        bound_ms = cyc / 2.2e6                                               # at the ~2.2 GHz the kernels run at (GRBM_GUI_ACTIVE)
+        scale = w.total_samples / smp
+        roofline["issue"] = {"bound": "valu issue", "valu_per_sample": round(64.0 * valu / smp, 1), "salu_per_sample": round(64.0 * salu / smp, 1),
+                             "lds_per_sample": round(64.0 * lds / smp, 2), "simd_cycles_per_launch": int(cyc * scale),
+                             "bound_ms": round(bound_ms * scale, 4), "frac": round(bound_ms * scale / t_path_ms, 4),
+                             "note": "instruction counts: committed rocprofv3 --pmc profile (traffic_source); frac = issue-bound time / time of the step"}
 
     extras = rank == 0 and not args.no_extras
     if extras:
@@ -230,6 +246,8 @@ def main():
            "bit_exact": True, "bit_exact_checked": "every output buffer vs the source PCM before the timed steps, and again -- on buffers cleared in between -- after them",
            "crc16_in_step": bool(with_crc), "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
            "steps_in_flight": depth if pipelined else 1, "distinct_input_copies_in_flight": len(arenas),
+           "value_basis": ("throughput of consecutive steps (one 10 000-frame batch each), up to %d in flight on the library's internal streams; "
+                           "config.one_step_at_a_time is a single batch's latency" % depth) if pipelined else "one step at a time",
            "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
     out = {
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
@@ -661,10 +679,10 @@ def _pmc_traffic(workload, frames):
         with open(p) as f:
             e = json.load(f).get("%s_frames_%d" % (workload, frames))
         if e:
-            return e.get("path_bytes"), e.get("source")
+            return e.get("path_bytes"), e.get("source"), e
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 if __name__ == "__main__":

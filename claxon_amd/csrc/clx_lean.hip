@@ -171,7 +171,14 @@ __device__ __forceinline__ int32_t cln_coef(const uint32_t (&C)[NP], int j) {
 }
 
 // stereo decorrelation of the turn's sixteen samples (clx_lfinish, clx_lanes.hip) into the stage
-__device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finish& F, int4* tile, int lane, uint32_t sw) {
+__device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Finish& F, int4* tile, int lane, uint32_t sw) {
+    int32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = s0[i];
+    if (F.any_wasted) {                                  // wasted-bits shift (subframe.rs:216-225): a wave with such a lane only
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = (int32_t)((uint32_t)s[i] << F.wasted);
+    }
     if (F.all_ms) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -447,12 +454,15 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     // range in which the packed evaluation is exact: 16-bit factors, and no partial sum of the taps wraps 32 bits
     // (S.lim = min(2^23, (2^31 - 1) / sum|c|), clx_ltransition); a subframe without taps has nothing to keep in range
     // (a subframe without taps has no history to keep in range; 2^29 is what the short mid/side form needs)
-    const int32_t lim = S.order == 0u ? (1 << 29) : S.lim < 32768 ? S.lim : 32768;
+    const int32_t cap = (1 << 29) >> (int)F.wasted;       // (what is shifted left by the wasted bits must still fit)
+    const int32_t lim0 = S.order == 0u ? (1 << 29) : S.lim < 32768 ? S.lim : 32768;
+    const int32_t lim = lim0 < cap ? lim0 : cap;
     int32_t CW[2 * NP];
 #pragma unroll
     for (int j = 0; j < 2 * NP; ++j) CW[j] = S.c[j];
     // the 24-bit evaluation's range (clx_ltransition), under the same cap for subframes without taps
-    const int32_t lim24 = S.order == 0u ? (1 << 29) : S.lim;
+    const int32_t lim24a = S.order == 0u ? (1 << 29) : S.lim;
+    const int32_t lim24 = lim24a < cap ? lim24a : cap;
     const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, CW, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
@@ -511,11 +521,14 @@ void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
                (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
         if (good) {
             h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
-            // (constant and verbatim subframes have order 0; wasted bits are clx_k_lanes' business, except a constant's: they fold into it)
-            good = !r.err && h.order <= 12u && (h.wasted == 0u || h.kind == 0u);
+            good = !r.err && h.order <= 12u;               // (constant and verbatim subframes have order 0)
         }
     }
-    if (!__all(good)) return;                              // clx_k_lanes / clx_k_lanes_hi decode this group
+    if (!__all(good)) {                                    // clx_k_lanes / clx_k_lanes_hi decode this group
+        CLX_STAT(60, 1); CLX_STAT(61, active && (fr.bps > 16u || bs != bs0 || (bs & 15u) != 0u || bs < 32u)); CLX_STAT(62, active && r.err != 0u);
+        CLX_STAT(63, active && !r.err && h.order > 12u);
+        return;
+    }
     if (lane == 0) taken[blockIdx.x] = gen;
 
     const uint32_t decor = active ? fr.channel_assignment : 0u;
@@ -544,7 +557,7 @@ void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
         }
         M.all_real = __all(M.adv == 15u);
     }
-    const Finish F = clx_lfinish_setup(n, 0u, decor, pair_ok, lane);
+    const Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
 
     // ---- careful prologue (as clx_lanes_body's): warm-up samples, the transition, the first residuals -- one sample per turn of
     //      a rolled loop, i64 predictor; leaves every lane on a multiple of 16 samples, past its transition

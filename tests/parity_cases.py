@@ -325,6 +325,16 @@ def lean_workload(scale=1):
             fp.sf[1] = S.sf(S.SF_LPC, 4, 10, 2)
             return ch, fp
         family(1024, 32, 2, mk_f)
+        # (h) wasted bits (subframe.rs:216-225): samples that are multiples of 4 / 8 in one channel or both, every channel assignment
+        def mk_h(i):
+            (L, R), g = music(i, 512, loud=0.2)
+            wl, wr = (2, 0, 3, 1)[i % 4], (0, 2, 3, 0)[i % 4]
+            L = (L >> wl) << wl; R = (R >> wr) << wr
+            fp = S.FrameParams(i % 4 if (wl == wr) else 0, 0, i)       # (side / mid of unequal shifts would not be multiples any more)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC if i % 3 else S.SF_FIXED, int(g.integers(1, 5)) if i % 3 == 0 else int(g.integers(1, 13)), 12, int(g.integers(0, 5)))
+            return (L, R), fp
+        family(512, 32, 2, mk_h)
         # (g) blocks that end with (or right after) the prologue
         for bs in (32, 48):
             def mk_g(i, bs=bs):
