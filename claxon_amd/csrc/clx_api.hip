@@ -227,11 +227,12 @@ struct clx_stream_slot {
 };
 
 #ifndef CLX_SUBMIT_MERGE
-#define CLX_SUBMIT_MERGE 4             // runs per merged launch of the fused lane kernels (<= CLX_MAX_MERGE); 4 x 3, 6 x 2, 3 x 4 and 2 x 6 are
-                                       // within a few percent of each other (profiles/r03_merge_sweep.txt)
+#define CLX_SUBMIT_MERGE 6             // runs per merged launch of the fused lane kernels (<= CLX_MAX_MERGE).  6 x 2 is the best shape with the
+                                       // runtime's default of 4 hardware queues; 4 x 3 and 2 x 6 need GPU_MAX_HW_QUEUES=16 to match it, and the
+                                       // library sets no environment (profiles/r03_merge_sweep.txt)
 #endif
 #ifndef CLX_SUBMIT_STREAMS
-#define CLX_SUBMIT_STREAMS 3           // internal streams the merged launches rotate over (MERGE * STREAMS <= CLX_SUBMIT_DEPTH)
+#define CLX_SUBMIT_STREAMS 2           // internal streams the merged launches rotate over (MERGE * STREAMS <= CLX_SUBMIT_DEPTH)
 #endif
 static_assert(CLX_SUBMIT_MERGE <= CLX_MAX_MERGE && CLX_SUBMIT_STREAMS * CLX_SUBMIT_MERGE <= CLX_SUBMIT_DEPTH && CLX_SUBMIT_STREAMS <= 6, "merge width");
 
