@@ -271,6 +271,7 @@ struct clx_batch {
     uint32_t* d_slot_frame = nullptr;
     uint32_t* d_multi = nullptr;
     size_t n_multi = 0;
+    bool any_bps_le16 = false, any_bps_gt16 = false;     // which of clx_k_lean / clx_k_lean24 can find work at all
     uint32_t* d_sf_start = nullptr;
     uint32_t* d_errkey = nullptr;
     uint64_t* d_endbits = nullptr;
@@ -465,6 +466,8 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
     if (b->lanes_planned) {
         std::vector<uint32_t> slot_frame(ns), multi(nf);
         b->n_multi = clx_plan_lanes(b->h_frames.data(), n, slot, slot_frame.data(), multi.data());
+        b->any_bps_le16 = b->any_bps_gt16 = false;
+        for (size_t i = 0; i < n; ++i) { if (b->h_frames[i].bps <= 16u) b->any_bps_le16 = true; else b->any_bps_gt16 = true; }
         if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
             !grow(ctx, &b->d_multi, &b->cap[5], nf * sizeof(uint32_t), "hipMalloc multi") ||
             !grow(ctx, &b->d_sf_start, &b->cap[6], ns * sizeof(uint32_t), "hipMalloc sf_start") ||
@@ -581,9 +584,16 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
     }
     if (!split) {
         // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them
-        if (runs.r[0].taken != nullptr) {
+        if (runs.r[0].taken != nullptr && b->any_bps_le16) {
             if (!mark("clx_k_lean")) return false;
             hipLaunchKernelGGL(clx_k_lean, dim3(groups, n_runs), dim3(64), 0, stream, runs,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
+        }
+        // the split tier for audio of more than 16 bits (launched when the batch holds such frames: it also takes <= 16-bit groups of
+        // more than 12 taps that share the batch, which otherwise stay with clx_k_lanes_hi)
+        if (runs.r[0].taken != nullptr && b->any_bps_gt16) {
+            if (!mark("clx_k_lean24")) return false;
+            hipLaunchKernelGGL(clx_k_lean24, dim3(groups, n_runs), dim3(64), 0, stream, runs,
                                (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
         }
         if (!mark("clx_k_lanes")) return false;             // (+ clx_k_lanes_hi, its order > 12 twin)

@@ -217,16 +217,30 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Fini
 // (H[j] = s[t0-1-j]) and the predictor is a chain of v_mad_i32_i24 on the unpacked coefficients CW -- exact while every history
 // sample lies in [-lim, lim) with lim <= 2^23 and sum|c| * lim < 2^31 (clx_ltransition's S.lim; checked on the data like the packed
 // form's).  Twice the predictor instructions of the packed form, everything else the same.
-template <int NP, int MODE, bool EDGE, bool WIDE>
-__device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[2 * NP], const uint32_t (&C)[NP],
-                                              const int32_t (&CW)[2 * NP], uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2, uint32_t limit,
-                                              bool live, const LKind& K, const Finish& F, int4* tile, int lane, uint32_t sw) {
+// FORM 2 (SPLIT, clx_k_lean24): the same turn for audio of more than 16 bits and / or more than 12 taps.  Every sample is kept as
+// two 16-bit pieces, s = hi * 4096 + lo with lo = s & 0xfff and hi = s >> 12, each in its own packed history (H = NH pairs of lo
+// pieces, then NH pairs of hi pieces); the predictor is two v_dot2_i32_i16 chains and
+//     (sum c*s) >> shift  =  ((A_hi << e1) + (A_lo >> e2)) >> e3        e1 = max(12 - shift, 0), e2 = min(shift, 12), e3 = max(shift - 12, 0)
+// -- the reference's i64 evaluation (subframe.rs:586-614) exactly, while sum|c| < 2^19 (any 15-bit coefficients of <= 32 taps) and
+// every history sample lies in [-lim, lim) with lim <= (floor((2^31 - 1) / sum|c|) - 1) * 4096: then neither chain wraps, A_hi * 4096
+// is a multiple of 2^e2, and A_hi + (A_lo >> 12) stays inside 32 bits.  No 64-bit instruction per sample.
+template <int NP, int MODE, bool EDGE, int FORM, int HN>
+__device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[HN], const uint32_t (&C)[NP],
+                                              const int32_t (&CW)[2 * NP], uint32_t shift, uint32_t e1, uint32_t e3, int32_t lim, uint32_t per, uint32_t rice2,
+                                              uint32_t limit, bool live, const LKind& K, const Finish& F, int4* tile, int lane, uint32_t sw) {
+    constexpr bool WIDE = FORM == 1, SPLIT = FORM == 2;
     constexpr int NH = 2 * NP - 1;                    // pairs carried from turn to turn
-    uint32_t P[NH + 16];                              // P[NH + m] = pair that ends at sample m of the turn (m = -NH .. 15)
+    static_assert(HN == (SPLIT ? 2 * NH : 2 * NP), "history registers");
+    uint32_t P[NH + 16];                              // P[NH + m] = pair that ends at sample m of the turn (m = -NH .. 15); SPLIT: of lo pieces
+    uint32_t PH[SPLIT ? NH + 16 : 1];                 // SPLIT: the same of hi pieces
     int32_t hw[2 * NP + 16];                          // WIDE: hw[2NP - 1 - j + i] = s[i - 1 - j]: the samples in time order, the turn's own appended
     if (!WIDE) {
 #pragma unroll
         for (int j = 0; j < NH; ++j) P[NH - 1 - j] = H[j];
+        if (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < NH; ++j) PH[NH - 1 - j] = H[(SPLIT ? NH : 0) + j];
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 2 * NP; ++j) hw[2 * NP - 1 - j] = (int32_t)H[j];
@@ -291,15 +305,30 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             wa = clx_alignbit(wa, wb, (uint32_t)sh); wb = clx_alignbit(wb, wc, (uint32_t)sh); wc = clx_alignbit(wc, wd, (uint32_t)sh); wd = clx_alignbit(wd, 0u, (uint32_t)sh);
             // predictor, oldest tap first: only the last term depends on the sample before
             int32_t acc = 0;
-            if (!WIDE) {
+            int32_t pred;
+            if (SPLIT) {
+                int32_t ah = 0;
+#pragma unroll
+                for (int q = NP - 1; q >= 0; --q) {
+                    acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
+                    ah = clx_sdot2(C[q], PH[(SPLIT ? NH + i - 1 - 2 * q : 0)], ah);
+                }
+                pred = (int32_t)(((uint32_t)ah << e1) + (uint32_t)(acc >> shift)) >> e3;
+            } else if (!WIDE) {
 #pragma unroll
                 for (int q = NP - 1; q >= 0; --q) acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
+                pred = acc >> shift;
             } else {
 #pragma unroll
                 for (int j = 2 * NP - 1; j >= 0; --j) acc = __mul24(CW[j], hw[2 * NP - 1 - j + i]) + acc;      // c[j] * s[i-1-j]: v_mad_i32_i24
+                pred = acc >> shift;
             }
-            const int32_t s = (int32_t)(xr + (uint32_t)(acc >> shift));                             // + prediction (wrapping)
-            if (!WIDE) P[NH + i] = clx_perm((uint32_t)s, P[NH + i - 1], 0x05040302u);               // (lo: the sample before, hi: this one)
+            const int32_t s = (int32_t)(xr + (uint32_t)pred);                                       // + prediction (wrapping)
+            if (SPLIT) {
+                P[NH + i] = clx_perm((uint32_t)s & 0xfffu, P[NH + i - 1], 0x05040302u);             // (lo: the sample before's piece, hi: this one's)
+                PH[(SPLIT ? NH + i : 0)] = clx_perm((uint32_t)(s >> 12), PH[(SPLIT ? NH + i - 1 : 0)], 0x05040302u);
+            }
+            else if (!WIDE) P[NH + i] = clx_perm((uint32_t)s, P[NH + i - 1], 0x05040302u);          // (lo: the sample before, hi: this one)
             else hw[2 * NP + i] = s;
             hi = s > hi ? s : hi; lo = s < lo ? s : lo;
             S16[i] = s;
@@ -325,6 +354,10 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
         if (!WIDE) {
 #pragma unroll
             for (int j = 0; j < NH; ++j) H[j] = P[NH + 15 - j];
+            if (SPLIT) {
+#pragma unroll
+                for (int j = 0; j < NH; ++j) H[(SPLIT ? NH : 0) + j] = PH[(SPLIT ? NH + 15 - j : 0)];
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * NP; ++j) H[j] = (uint32_t)hw[2 * NP + 15 - j];
@@ -379,10 +412,10 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
           again_lean:
             if (mode == 0 || NP == 2) {                // (NP == 2 is only run with mode 0)
                 // a partition edge inside the turn?  (lanes that decode nothing never say yes; cur.pcnt of the others is exact)
-                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true, false>(row, g, cur, H, C, CW, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
-                else                                 done = cln_lean_turn<NP, 0, false, false>(row, g, cur, H, C, CW, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                else                                 done = cln_lean_turn<NP, 0, false, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
             }
-            else                      done = cln_lean_turn<NP, 1, true, false>(row, g, cur, H, C, CW, shift, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            else                      done = cln_lean_turn<NP, 1, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
             if (done > 0) {
                 T.pending = true; T.t0 = t0;
                 CLX_STAT(50, 1);
@@ -407,7 +440,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             for (int j = 0; j < 2 * NP; ++j) in24 = in24 && (int32_t)H[j] < lim24 && (int32_t)H[j] >= -lim24;
             if (__all(in24 || !live || order == 0u)) {
               again_wide:
-                const int dw = cln_lean_turn<NP, 1, true, true>(row, g, cur, H, C, CW, shift, lim24, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                const int dw = cln_lean_turn<NP, 1, true, 1>(row, g, cur, H, C, CW, shift, 0u, 0u, lim24, per, rice2, r.limit, live, K, F, tile, lane, sw);
                 if (dw > 0) {
                     T.pending = true; T.t0 = t0;
                     CLX_STAT(58, 1);
@@ -468,11 +501,126 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     return done;
 }
 
-extern "C" __global__ __launch_bounds__(64)
-void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
-                int32_t* __restrict__ dump_all) {
-    __shared__ LeanLds L;
+// ---- clx_k_lean24: the split form --------------------------------------------------------------------------------------------
+// history as 12-bit lo / 16-bit hi pieces in packed pairs (cln_lean_turn, FORM 2): H[j] = pieces of (lo half: s[-2-j], hi half:
+// s[-1-j]) for the lo pieces, H[NH + j] the same for the hi pieces; U[j] = s[-1-j]
+template <int NP>
+__device__ __forceinline__ void cln_pack12(const int32_t (&U)[2 * NP], uint32_t (&H)[2 * (2 * NP - 1)]) {
+    constexpr int NH = 2 * NP - 1;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        H[j] = (((uint32_t)U[j] & 0xfffu) << 16) | ((uint32_t)U[j + 1] & 0xfffu);
+        H[NH + j] = ((uint32_t)(U[j] >> 12) << 16) | ((uint32_t)(U[j + 1] >> 12) & 0xffffu);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void cln_unpack12(const uint32_t (&H)[2 * (2 * NP - 1)], int32_t (&U)[2 * NP]) {
+    constexpr int NH = 2 * NP - 1;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) U[j] = (int32_t)((uint32_t)((int32_t)H[NH + j] >> 16) << 12) + (int32_t)(H[j] >> 16);
+    U[2 * NP - 1] = (int32_t)((uint32_t)(int32_t)(int16_t)(H[2 * NH - 1] & 0xffffu) << 12) + (int32_t)(H[NH - 1] & 0xffffu);
+}
+
+// The steady state of clx_k_lean24: split turns; the slow turn (as cln_body's) for what they leave -- and for as long as a lane's
+// history is outside the range in which the split evaluation is exact.  Returns false when the wave gives the group up.
+template <int NP, int OMAX>
+__device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, const int32_t (&hist0)[OMAX],
+                                           const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2,
+                                           uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane) {
+    constexpr int NH = 2 * NP - 1;
+    int4* const tile = stage - 4 * lane;
+    const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
+    const uint32_t e1 = shift <= 12u ? 12u - shift : 0u, e2 = shift <= 12u ? shift : 12u, e3 = shift <= 12u ? 0u : shift - 12u;
+    uint32_t H[2 * NH];
+    int32_t CW[2 * NP];                                  // (the split form does not look at the unpacked coefficients)
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) CW[j] = 0;
+    {   // (a history outside the range cannot even be kept in the pieces: such a wave -- garbage, or audio beyond 24 bits -- gives
+        //  the group up at once, here and behind a slow turn)
+        int32_t U[2 * NP];
+        bool in = true;
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) { U[j] = hist0[j]; in = in && U[j] < lim && U[j] >= -lim; }
+        if (!__all(in || n == 0u || r.err != 0u || order == 0u)) return false;
+        cln_pack12<NP>(U, H);
+    }
+    bool ring_ok = false;
+    uint32_t nslow = 0;
+    for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
+        const bool live = n != 0u && !r.err;
+        cln_flush(T, tile, M, lane);                     // the turn before's tile
+        if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
+        else cln_pump(buf, g, row, cur.p);
+        {
+            bool refilled = false;
+          again:
+            const int done = cln_lean_turn<NP, 1, true, 2>(row, g, cur, H, C, CW, e2, e1, e3, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            if (done > 0) {
+                T.pending = true; T.t0 = t0;
+                CLX_STAT(9, 1);
+                continue;
+            }
+            if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; CLX_STAT(12, 1); goto again; }
+        }
+        CLX_STAT(10, 1);
+        if (++nslow > CLN_SLOW_BUDGET && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // (wave-uniform; not when the end is near anyway)
+        // ---- slow turn: sixteen samples one by one, generic reader, i64 predictor (taps beyond the order are zero)
+        int32_t U[2 * NP];
+        cln_unpack12<NP>(H, U);
+        int32_t* const ys = reinterpret_cast<int32_t*>(stage);
+#pragma unroll 1
+        for (uint32_t ii = 0; ii < 16u; ++ii) {
+            int32_t x = 0;
+            if (live) x = cln_careful_code(r, cur, per, rice2, K);
+            int64_t acc = 0;
+#pragma unroll
+            for (int j = 2 * NP - 1; j >= 0; --j) acc += (int64_t)cln_coef<NP>(C, j) * (int64_t)U[j];
+            const int32_t s = (int32_t)((uint32_t)x + (uint32_t)(int32_t)(acc >> shift));
+#pragma unroll
+            for (int j = 2 * NP - 1; j > 0; --j) U[j] = U[j - 1];
+            U[0] = s;
+            const int32_t v = clx_lfinish(s, F);
+            ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
+        }
+        bool in = true;
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) in = in && U[j] < lim && U[j] >= -lim;
+        if (!__all(in || !live || order == 0u)) return false;
+        cln_pack12<NP>(U, H);
+        T.pending = true; T.t0 = t0;
+        ring_ok = false;                                  // the position moved without the ring
+    }
+    return true;
+}
+
+template <int NP, int OMAX>
+__device__ __forceinline__ bool cln_run24(const clx_buf& buf, LaneState<OMAX>& S, LRing& g, uint32_t* row, int4* stage, uint32_t n, uint32_t i0, uint32_t nmax,
+                                          const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane) {
+    static_assert(2 * NP <= OMAX, "taps");
+    uint32_t C[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) C[q] = ((uint32_t)S.c[2 * q] << 16) | ((uint32_t)S.c[2 * q + 1] & 0xffffu);
+    LCur cur = { S.r.pos, S.k, S.pcnt, S.next_cnt, S.parts_left };
+    if (n == 0u) cur.p = 32u;            // a lane that decodes nothing rides along from a harmless position (never committed)
+    // the range in which the split evaluation is exact (cln_lean_turn): (floor((2^31 - 1) / sum|c|) - 1) * 4096, at most 2^27 (the
+    // hi piece is a 16-bit factor); a subframe without taps has no history to keep in range: 2^29 there and as the cap (what the
+    // short mid/side form and the wasted-bits shift still hold)
+    const int32_t cap = (1 << 29) >> (int)F.wasted;
+    const int32_t lim0 = S.order == 0u ? (1 << 29) : S.lim > (1 << 15) ? (1 << 27) : (int32_t)((uint32_t)(S.lim - 1) << 12);
+    const int32_t lim = lim0 < cap ? lim0 : cap;
+    const bool done = cln_body24<NP, OMAX>(buf, S.r, g, row, stage, cur, S.hist, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, F, M, T, lane);
+    S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
+    return done;
+}
+
+// The kernels' common body.  SPLIT = false: clx_k_lean (<= 16-bit audio, <= 12 taps); true: clx_k_lean24 (<= 24-bit audio -- a side
+// channel has 25 --, <= 32 taps, the groups clx_k_lean left).
+template <bool SPLIT>
+__device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame,
+                                           uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    constexpr int OMAX = SPLIT ? 32 : 12;
     const clx_run& R = runs.r[blockIdx.y];
+    if (SPLIT && R.taken[blockIdx.x] == R.gen) return;       // clx_k_lean has decoded this group
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
     const uint32_t* const sf_start = R.sf_start;
@@ -517,16 +665,18 @@ void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
         bs0 = (uint32_t)__shfl((int)bs, (int)__ffsll((long long)am) - 1, 64);
     }
     if (active) {
-        good = fr.bps <= 16u && bs == bs0 && (bs & 15u) == 0u && bs >= 32u && (((uintptr_t)rowp) & 15u) == 0u && r.pos <= r.limit &&
-               (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
+        good = fr.bps <= (SPLIT ? 24u : 16u) && bs == bs0 && (bs & 15u) == 0u && bs >= (SPLIT ? 64u : 32u) && (((uintptr_t)rowp) & 15u) == 0u &&
+               r.pos <= r.limit && (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
         if (good) {
             h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
-            good = !r.err && h.order <= 12u;               // (constant and verbatim subframes have order 0)
+            good = !r.err && h.order <= (uint32_t)OMAX;    // (constant and verbatim subframes have order 0)
         }
     }
     if (!__all(good)) {                                    // clx_k_lanes / clx_k_lanes_hi decode this group
-        CLX_STAT(60, 1); CLX_STAT(61, active && (fr.bps > 16u || bs != bs0 || (bs & 15u) != 0u || bs < 32u)); CLX_STAT(62, active && r.err != 0u);
-        CLX_STAT(63, active && !r.err && h.order > 12u);
+        if (!SPLIT) {
+            CLX_STAT(60, 1); CLX_STAT(61, active && (fr.bps > 16u || bs != bs0 || (bs & 15u) != 0u || bs < 32u)); CLX_STAT(62, active && r.err != 0u);
+            CLX_STAT(63, active && !r.err && h.order > 12u);
+        }
         return;
     }
     if (lane == 0) taken[blockIdx.x] = gen;
@@ -561,32 +711,32 @@ void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
 
     // ---- careful prologue (as clx_lanes_body's): warm-up samples, the transition, the first residuals -- one sample per turn of
     //      a rolled loop, i64 predictor; leaves every lane on a multiple of 16 samples, past its transition
-    LaneState<12> S;
+    LaneState<OMAX> S;
     S.r = r;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) { S.c[j] = 0; S.hist[j] = 0; }
+    for (int j = 0; j < OMAX; ++j) { S.c[j] = 0; S.hist[j] = 0; }
     S.phase = 3u; S.cval = 0; S.trans_at = 0xffffffffu; S.transitioned = false;
     S.order = 0; S.shift = 0; S.lim = 0x7fffffff;
     S.k = 0; S.k1 = 1; S.pcnt = 0; S.next_cnt = 0; S.per = 0; S.parts_left = 0; S.rice2 = 0;
-    if (n) {                                               // (bs >= 32 > order: "order larger than block size" cannot happen here)
+    if (n) {                                               // (bs > order: "order larger than block size" cannot happen here)
         if (h.kind == 0u) {                                // decode_constant (subframe.rs:382-394) + its wasted-bits shift (216-225)
             S.cval = (int32_t)((uint32_t)clx_lread_signed(S.r, h.sf_bps) << h.wasted); S.phase = 2u;
         }
         else if (h.kind == 1u) S.phase = 0u;                                               // decode_verbatim (397-415)
         else { S.phase = 0u; S.trans_at = h.order; }
     }
-    const uint32_t i0 = (omax + 4u + 15u) & ~15u;           // 16 or 32 (<= bs)
+    const uint32_t i0 = (omax + 4u + 15u) & ~15u;           // 16 or 32 (SPLIT: up to 48) (<= bs)
     LTile T = { false, 0u };
     int32_t* const ys = reinterpret_cast<int32_t*>(L.stage[lane]);
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
 #pragma unroll 1
     for (uint32_t i = 0; i < i0; ++i) {
-        const int32_t x = clx_lcareful_raw<12>(S, h, bs, i, n);
-        const int32_t pred = clx_lpredict<12, true>(S.c, S.hist, S.shift);
+        const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
+        const int32_t pred = clx_lpredict<OMAX, true>(S.c, S.hist, S.shift);
         const uint32_t use = (S.order != 0u && i >= S.order && i >= S.trans_at) ? 0xffffffffu : 0u;
         const int32_t s = (int32_t)((uint32_t)x + ((uint32_t)pred & use));
 #pragma unroll
-        for (int j = 11; j > 0; --j) S.hist[j] = S.hist[j - 1];
+        for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
         if ((i & 15u) == 0u) cln_flush(T, L.stage[0], M, lane);
         ys[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
@@ -609,12 +759,19 @@ void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
         const bool lv = n != 0u && !S.r.err;
         const int mode = __any(lv && !K.rice) ? 1 : 0;                                    // wave-uniform: the mixed form or the plain one
         bool done;
-        if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
-        else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
-        else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
+        if constexpr (SPLIT) {
+            // the split evaluation needs sum|c| < 2^19 (S.lim >= 4096) -- any <= 32 coefficients of <= 15 bits but the all -2^14 row
+            if (__any(lv && S.order != 0u && S.lim < 4096)) done = false;
+            else if (omax <= 12u) done = cln_run24<6, OMAX>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, F, M, T, lane);
+            else                  done = cln_run24<16, OMAX>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, F, M, T, lane);
+        } else {
+            if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
+            else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
+            else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
+        }
         if (!done) {                                       // given up: clx_k_lanes decodes the group
             if (lane == 0) taken[blockIdx.x] = 0u;
-            CLX_STAT(57, 1);
+            CLX_STAT(SPLIT ? 11 : 57, 1);
             return;
         }
     }
@@ -627,4 +784,18 @@ void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
         if (S.r.err) clx_report_error(errkey, f, ch, S.r.err);
         else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(S.r.pos - o);
     }
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+                int32_t* __restrict__ dump_all) {
+    __shared__ LeanLds L;
+    cln_kernel<false>(L, runs, frames, slot_frame, n_slots, dump_all);
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_lean24(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+                  int32_t* __restrict__ dump_all) {
+    __shared__ LeanLds L;
+    cln_kernel<true>(L, runs, frames, slot_frame, n_slots, dump_all);
 }

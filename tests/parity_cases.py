@@ -347,6 +347,138 @@ def lean_workload(scale=1):
     return synth.concat("lean tiers", ws)
 
 
+def lean24_workload(scale=1):
+    """What clx_k_lean24 takes (the split tier of the fused lane build, clx_lean.hip): waves of 64 subframes of <= 24-bit audio (or
+    of <= 16-bit audio with more than 12 taps) in rows of one block size that is a multiple of 16, >= 64.  Families of 64 subframes
+    (one wave each): 24- and 20-bit music with <= 12 and <= 32 taps in every channel assignment, constants and verbatim subframes
+    riding along, partitions that end inside a four, 16-bit audio with 13-32 taps, long codes, streams that outrun the ring, wasted
+    bits, blocks that end with the prologue, and signals / coefficient rows that leave the range of the split evaluation (the wave
+    gives the group up to the general kernels)."""
+    rng = np.random.default_rng(424242)
+    S = synth
+    ws = []
+
+    def family(bs, n_frames, channels, bps, make):
+        pcm = np.empty((n_frames, channels, bs), dtype=np.int32)
+        fps = []
+        for i in range(n_frames):
+            chans, fp = make(i)
+            for c in range(channels):
+                pcm[i, c] = chans[c]
+            fps.append(fp)
+        ws.append(S.encode_frames("lean24", pcm, channels, bs, bps, fps))
+
+    def music(i, bs, bits, loud=1.0):
+        L, R, g = S.pcm_music_like(int(rng.integers(0, 1 << 20)) + i, bs)
+        k = loud * (1 << (bits - 16))
+        lim = 1 << (bits - 1)
+        return (np.clip(L * k, -lim, lim - 1).astype(np.int32), np.clip(R * k, -lim, lim - 1).astype(np.int32)), g
+
+    for rep in range(scale):
+        # (a) the plain cases: <= 12 taps and <= 32 taps (one instantiation of the turn each), 24 and 20 bits, every channel assignment
+        for omax, bs, bits in ((12, 1024, 24), (32, 1024, 24), (32, 4096, 24), (32, 512, 20)):
+            def mk(i, omax=omax, bs=bs, bits=bits):
+                (L, R), g = music(i, bs, bits)
+                fp = S.FrameParams(i % 4, 0, i)
+                for c in range(2):
+                    if g.uniform() < 0.8:
+                        fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1 if omax <= 12 else 9, omax + 1)), int(g.integers(6, 16)), int(g.integers(0, 8 if bs >= 4096 else 5)),
+                                        force_rice2=int(g.uniform() < 0.3))
+                    else:
+                        fp.sf[c] = S.sf(S.SF_FIXED, int(g.integers(0, 5)), 0, int(g.integers(0, 5)))
+                return (L, R), fp
+            family(bs, 32, 2, bits, mk)
+        # (b) constants and verbatim subframes among them
+        def mk_b(i):
+            (L, R), g = music(i, 512, 24)
+            fp = S.FrameParams(0, 0, i)
+            kinds = [S.SF_LPC, S.SF_LPC]
+            if i % 5 == 1:
+                kinds[i % 2] = S.SF_CONSTANT
+            elif i % 5 == 3:
+                kinds[(i // 5) % 2] = S.SF_VERBATIM
+            ch = [L, R]
+            for c in range(2):
+                if kinds[c] == S.SF_CONSTANT:
+                    ch[c] = np.full(512, int(g.integers(-500000, 500000)) * (16 if i % 3 == 0 else 1), dtype=np.int32)
+                    fp.sf[c] = S.sf(S.SF_CONSTANT, 0, 0, 0)
+                elif kinds[c] == S.SF_VERBATIM:
+                    ch[c] = g.integers(-(1 << 23), 1 << 23, 512).astype(np.int32)
+                    fp.sf[c] = S.sf(S.SF_VERBATIM, 0, 0, 0)
+                else:
+                    fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 33)), 13, int(g.integers(0, 4)))
+            return ch, fp
+        family(512, 32, 2, 24, mk_b)
+        # (c) partitions of 18 and 9 codes (144 >> 3, >> 4): edges inside a four -- the slow turn's, then the give-up
+        def mk_c(i):
+            (L, R), g = music(i, 144, 24)
+            fp = S.FrameParams(3 if i % 2 else 1, 0, i)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC, 8, 12, (3, 4, 2, 1)[i % 4])
+            return (L, R), fp
+        family(144, 32, 2, 24, mk_c)
+        # (d) 16-bit audio with 13-32 taps: clx_k_lean leaves it (more than 12 taps), the split tier takes it
+        def mk_d(i):
+            (L, R), g = music(i, 1024, 16)
+            fp = S.FrameParams(i % 4, 0, i)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(13, 33)), int(g.integers(8, 16)), int(g.integers(0, 5)))
+            return (L, R), fp
+        family(1024, 32, 2, 16, mk_d)
+        # (e) spikes under a small Rice parameter: codes far longer than 32 bits (mono: 64 frames are one wave)
+        def mk_e(i):
+            bs = 1024
+            x = rng.integers(-600, 700, bs).astype(np.int32)
+            if i % 4 != 3:
+                x[rng.integers(40, bs, size=1 + i % 3)] = rng.integers(30000, 300000) * (1 if i % 2 else -1)
+            fp = S.FrameParams(0, 0, i)
+            fp.sf[0] = S.sf(S.SF_FIXED, 0, 0, 0, rice_param=8)
+            return (x,), fp
+        family(1024, 64, 1, 24, mk_e)
+        # (f) full-scale noise, 23-24 bits per code: the ring cannot keep up for long
+        def mk_f(i):
+            bs = 1024
+            fp = S.FrameParams(0, 0, i)
+            ch = [rng.integers(-(1 << 23), 1 << 23, bs).astype(np.int32), rng.integers(-300000, 300000, bs).astype(np.int32)]
+            fp.sf[0] = S.sf(S.SF_FIXED, 0, 0, 2, rice_param=22)
+            fp.sf[1] = S.sf(S.SF_LPC, 4, 10, 2)
+            return ch, fp
+        family(1024, 32, 2, 24, mk_f)
+        # (h) wasted bits, every channel assignment
+        def mk_h(i):
+            (L, R), g = music(i, 512, 24, loud=0.2)
+            wl, wr = (4, 0, 8, 1)[i % 4], (0, 4, 8, 0)[i % 4]
+            L = (L >> wl) << wl; R = (R >> wr) << wr
+            fp = S.FrameParams(i % 4 if (wl == wr) else 0, 0, i)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC if i % 3 else S.SF_FIXED, int(g.integers(1, 5)) if i % 3 == 0 else int(g.integers(1, 33)), 14, int(g.integers(0, 4)))
+            return (L, R), fp
+        family(512, 32, 2, 24, mk_h)
+        # (g) blocks that end with (or right after) the prologue (48 samples for more than 28 taps)
+        for bs in (64, 80):
+            def mk_g(i, bs=bs):
+                (L, R), g = music(i, bs, 24)
+                fp = S.FrameParams(i % 4, 0, i)
+                for c in range(2):
+                    fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 33)), 10, int(g.integers(0, 2)))
+                return (L, R), fp
+            family(bs, 32, 2, 24, mk_g)
+        # (i) full scale and out of phase under 32 taps of 15 bits: a 25-bit side channel and large coefficient sums -- where the
+        #     split evaluation's range ends, the wave hands the group to the general kernels
+        def mk_i(i):
+            bs = 1024
+            t = np.arange(bs)
+            a = 8.3e6 * np.sin(2 * np.pi * (90 + 11 * i) * t / 44100.0) * (1.0 if i % 2 else np.minimum(1.0, t / 600.0))
+            L = np.clip(np.rint(a + rng.normal(0, 50, bs)), -(1 << 23), (1 << 23) - 1).astype(np.int32)
+            R = np.clip(np.rint(-a + rng.normal(0, 50, bs)), -(1 << 23), (1 << 23) - 1).astype(np.int32)
+            fp = S.FrameParams((3, 1, 2, 0)[i % 4], 0, i)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC, 32, 15, 3)
+            return (L, R), fp
+        family(1024, 32, 2, 24, mk_i)
+    return synth.concat("lean24 tiers", ws)
+
+
 def check_regressions(oracle, backend):
     """Frames that once decoded differently from the oracle on some kernel selection (found by tools/stress_gpu.py)."""
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "*.npy")))

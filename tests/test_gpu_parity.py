@@ -38,6 +38,12 @@ def test_gpu_lean_tiers(oracle, gpu):
     pc.check_workload(oracle, gpu, pc.lean_workload(scale=2))
 
 
+@pytest.mark.gpu
+def test_gpu_lean24_tiers(oracle, gpu):
+    """every tier and exit of clx_k_lean24, the split tier for > 16-bit audio and > 12 taps (see parity_cases.lean24_workload)"""
+    pc.check_workload(oracle, gpu, pc.lean24_workload(scale=2))
+
+
 def test_gpu_edges(oracle, gpu):
     pc.check_workload(oracle, gpu, pc.edge_workload())
 

@@ -150,6 +150,65 @@ def test_sim_lean_tiers(oracle):
     assert stats[57] // 64 >= 1          # groups given up to the general kernels (and still bit-exact: they decoded them)
 
 
+def test_sim_lean24_tiers(oracle):
+    """clx_k_lean24 (the split tier: > 16-bit audio, > 12 taps): bit-exact on a workload built to use both instantiations of its turn
+    and every way out of one -- and it really takes those groups (tier counters compiled into the simulator build only)."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    w = pc.lean24_workload()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for i in range(64):
+        stats[i] = 0
+    pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
+    split, slow, bailed, refilled, taken = stats[9] // 64, stats[10] // 64, stats[11] // 64, stats[12] // 64, stats[13]
+    why = {"partition edge inside a four / escape": stats[53], "code longer than 32 bits": stats[54], "ring ran dry / end of frame": stats[55]}
+    assert stats[52] == 0                      # nothing here is clx_k_lean's (more than 16 bits, or more than 12 taps)
+    assert split > 500 and slow > 10 and refilled > 20 and taken >= 10 and bailed >= 1, (split, slow, bailed, refilled, taken)
+    assert all(v > 0 for v in why.values()), why
+
+
+def test_sim_lean24_takes_config4(oracle):
+    """config 4 (24-bit, 32 taps, wasted bits, every channel assignment) goes through clx_k_lean24, all turns split ones."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for i in range(64):
+        stats[i] = 0
+    pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), synth.config4(32), verify_crc=True)
+    assert stats[13] == 1 and stats[10] == 0 and stats[9] // 64 == 253, (stats[9], stats[10], stats[13])
+
+
+def test_sim_lean24_truncations_and_flips(oracle):
+    """EOF and garbage inside frames the split tier takes (24-bit stereo, up to 32 taps): every cut / flip must give the reference's
+    status, message, end bit and samples -- garbage drives the history out of the split evaluation's range (the wave gives the group
+    up) often enough."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for i in range(64):
+        stats[i] = 0
+    sim = SimBackend(cx.PATH_LANES | cx.LANES_FUSED)
+    w = synth.config4(6, bs=256)
+    rng = np.random.default_rng(7)
+    seen = set()
+    for i in range(w.n):
+        fr = w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])].copy()
+        for c in sorted(set(rng.integers(8, len(fr), 10).tolist() + [len(fr) - 2, len(fr) - 1, len(fr)])):
+            seen.add(pc.assert_same_as_oracle(oracle, sim, fr[:c].copy(), True, "frame %d cut %d" % (i, c)))
+        _, _, h = cx.parse_frame_header(fr)
+        for trial in range(12):
+            g = fr.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(h.header_bytes * 8, len(g) * 8))
+                g[pos >> 3] ^= (0x80 >> (pos & 7))
+            seen.add(pc.assert_same_as_oracle(oracle, sim, g, False, "frame %d flip %d" % (i, trial)))
+    assert len(seen) >= 3, seen
+    assert stats[13] > 50 and stats[11] // 64 >= 1, (stats[13], stats[11])
+
+
 def test_sim_lean_takes_the_bench_shapes(oracle):
     """configs 2 / 3 (the bench workload's shape) and the mixed shapes of config 5 go through clx_k_lean, all turns lean."""
     import ctypes as C

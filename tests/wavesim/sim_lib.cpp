@@ -40,6 +40,13 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
             // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
             if (lean) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
             for (uint32_t t : taken) sim_stats[52] += t == runs.r[0].gen;
+            if (lean) {     // the split tier on what is left (the library launches it when the batch holds frames of more than 16 bits)
+                uint64_t before = 0, after = 0;
+                for (uint32_t t : taken) before += t == runs.r[0].gen;
+                SIM_LAUNCH(clx_k_lean24, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
+                for (uint32_t t : taken) after += t == runs.r[0].gen;
+                sim_stats[13] += after - before;
+            }
             SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
             SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
         } else {
