@@ -227,9 +227,8 @@ struct clx_stream_slot {
 };
 
 #ifndef CLX_SUBMIT_MERGE
-#define CLX_SUBMIT_MERGE 6             // runs per merged launch of the fused lane kernels (<= CLX_MAX_MERGE).  6 x 2 is the best shape with the
-                                       // runtime's default of 4 hardware queues; 4 x 3 and 2 x 6 need GPU_MAX_HW_QUEUES=16 to match it, and the
-                                       // library sets no environment (profiles/r03_merge_sweep.txt)
+#define CLX_SUBMIT_MERGE 12            // runs per merged launch of the fused lane kernels (<= CLX_MAX_MERGE).  12 x 2 is the best shape with the
+                                       // runtime's default of 4 hardware queues (profiles/r03_merge_sweep.txt); the library sets no environment
 #endif
 #ifndef CLX_SUBMIT_STREAMS
 #define CLX_SUBMIT_STREAMS 2           // internal streams the merged launches rotate over (MERGE * STREAMS <= CLX_SUBMIT_DEPTH)
@@ -264,7 +263,7 @@ struct clx_batch {
     clx_dev_frame* d_frames = nullptr;
     clx_sf_desc* d_sfd = nullptr;
     clx_frame_result* d_results = nullptr;
-    int32_t* d_dump = nullptr;       // wave path: 64 bytes per predictor lane for out-of-row stores
+    int32_t* d_dump = nullptr;       // 128 bytes per lane for out-of-row stores (the wave kernels and clx_k_lanes use 64 of them)
     // lane path
     bool lanes = false;              // clx_batch_run uses the lane kernels
     bool lanes_planned = false;      // their plan data (d_slot_frame, d_multi, scratch) exists: run or submit may use them
@@ -459,7 +458,7 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
     b->lanes = (flags & CLX_PATH_LANES) ? true : (flags & CLX_PATH_WAVES) ? false : b->choice.lanes;
     {   // where stores that fall outside a row go (K2 and D2 keep their store instructions unconditional)
         const size_t lanes64 = ((ns + 127) / 128) * 128;
-        if (!grow(ctx, &b->d_dump, &b->cap[3], lanes64 * 16 * sizeof(int32_t), "hipMalloc dump")) return CLX_API_ERROR;
+        if (!grow(ctx, &b->d_dump, &b->cap[3], lanes64 * 32 * sizeof(int32_t), "hipMalloc dump")) return CLX_API_ERROR;      // (128 bytes per lane: clx_k_lean's)
     }
     // (the lane kernels' plan data: when either a run or a pipelined submission may use them)
     b->lanes_planned = b->lanes || ((flags & CLX_PATH_WAVES) == 0 && b->choice_submit.lanes);
@@ -822,7 +821,7 @@ extern "C" int clx_batch_submit_lanes(const clx_batch* b) { return b && !b->prof
 extern "C" int clx_batch_submit_depth(const clx_batch* b) {
     if (!b) return 1;
     if (b->profiling) return 1;
-    if (submit_wants_lanes(b)) return (b->flags & CLX_LANES_SPLIT) ? 1 : clx_batch::kDepthLanes;
+    if (submit_wants_lanes(b)) return (b->flags & CLX_LANES_SPLIT) ? 1 : b->merge * b->n_streams;      // (<= kDepthLanes)
     return (b->flags & CLX_K2_THROUGHPUT) ? 1 : clx_batch::kDepthWaves;
 }
 
@@ -833,7 +832,7 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     if (!d_arena || !d_out) { ctx->last_error = "null device pointer"; return CLX_API_ERROR; }
     if (((uintptr_t)d_arena & 15u) != 0) { ctx->last_error = "device arena must be 16-byte aligned"; return CLX_API_ERROR; }
     // Which kernels (clx_select_path, `pipelined`): the wave kernels with the multi-wave predictor build, four submissions in
-    // flight; or the lane kernels, fused build, twelve in flight -- a run of those is one serial chain per subframe on a fraction of
+    // flight; or the lane kernels, fused build, twenty-four in flight (two merged launches of twelve) -- a run of those is one serial chain per subframe on a fraction of
     // the machine's registers, and a dozen of them side by side fill it.  The two-wave lane build and the one-wave predictor build
     // gain nothing from company (measured, tools/bench_configs.py): forced by flag they are plain runs.
     bool want_lanes = submit_wants_lanes(b);

@@ -601,6 +601,8 @@ struct Finish {
     uint32_t rmask, s1, bit, sg;
     bool p_other, r_other;
     bool any_decor, all_ms, any_wasted;
+    // per-lane constants of clx_decor4's form  (even & pmask) + ((((odd ^ dsg) & drm) + dc) >> s1)
+    uint32_t dsg, drm, dc, pmask;
 };
 __device__ __forceinline__ Finish clx_lfinish_setup(uint32_t n, uint32_t wasted, uint32_t decor, bool pair_ok, int lane) {
     Finish F;
@@ -614,6 +616,10 @@ __device__ __forceinline__ Finish clx_lfinish_setup(uint32_t n, uint32_t wasted,
     F.rmask = (d_ms || d_ls || d_rs) ? 0xffffffffu : 0u;
     F.s1 = d_ms ? 1u : 0u; F.bit = F.s1;
     F.sg = ((d_ms && odd) || d_ls) ? 0xffffffffu : 0u;
+    F.drm = odd ? 0xffffffffu : (d_ms || d_rs) ? 0xffffffffu : 0u;            // (an odd lane's own value is "the odd one")
+    F.dsg = (odd && (d_ms || d_ls)) ? 0xffffffffu : 0u;
+    F.dc = d_ms ? (odd ? 2u : 1u) : d_ls ? 1u : 0u;
+    F.pmask = (!odd || d_ms || d_ls) ? 0xffffffffu : 0u;
     F.any_decor = __any(pair_ok);
     F.all_ms = __all(n == 0u || d_ms);        // idle lanes (the tail of the last wave) do not spoil the short sequence
     F.any_wasted = __any(n != 0u && wasted != 0u);

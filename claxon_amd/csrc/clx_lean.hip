@@ -25,14 +25,16 @@
 #define CLN_RING 24u                    // stream dwords per lane in the ring (a multiple of 4).  32 would make the slot a bit field, but the
                                         // 2 KiB more per wave cost more than the two instructions per window (0.208 against 0.202 ms per step)
 #endif
-#define CLN_ROW (CLN_RING + 4u)         // slots RING .. RING+3 mirror slots 0 .. 3: a window of five dwords never wraps
+#define CLN_ROW (CLN_RING + 4u)
+#define CLN_SCHED_FENCE() CLX_SCHED_BARRIER()         // slots RING .. RING+3 mirror slots 0 .. 3: a window of five dwords never wraps
 
 // The ring is slot-major -- ring[slot][lane] -- so that a lane's dwords all sit in the lane's own LDS bank (bank = lane mod 32):
 // the lanes of a wave read at unrelated slots (their streams advance at their own pace), and in a lane-major layout those reads
 // collide three to four deep (measured: 56 % of the LDS's active cycles were bank conflicts).
 struct LeanLds {
     uint32_t ring[CLN_ROW][64];
-    int4 stage[64][4];                  // the turn's 64 x 16 output samples (int4 [row][piece ^ swizzle])
+    int4 stage[2][64][4];               // two turns' 64 x 16 output samples: int4 [tile][row ^ tile][piece ^ swizzle] (cln_mine)
+    uint64_t rowp[64];                  // where the wave's rows are (bit 0: a dump slot -- the turn's sample index is not added)
 };
 #define CLN_AT(col, slot) ((col)[(slot) * 64u])        // dword `slot` of the lane whose column `col` is
 
@@ -70,10 +72,17 @@ __device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t
 }
 // once per turn: land what was requested a turn ago, request what fits now (three granules: 24 bits per code sustained -- a
 // verbatim subframe of 17-bit samples takes 272 bits per turn)
-__device__ __forceinline__ void cln_pump(const clx_buf& buf, LRing& g, uint32_t* row, uint32_t p) {
+// (The landing waits for EVERYTHING the wave has in flight -- the compiler cannot count across the branches: s_waitcnt vmcnt(0) --,
+// the turn's tile stores included, which are issued right in front of it.  Landing in front of the stores instead, when all that is
+// in flight is a whole turn old, makes one run alone 4 % faster and a saturated machine 9 % slower (one merged launch of nine runs:
+// 1.27 -> 1.39 ms; tools/gpu_ab_sat.sh): the wait is what paces the waves' stores.)
+__device__ __forceinline__ void cln_land(LRing& g, uint32_t* row) {
     if (g.np >= 1u) { cln_put(row, g.fs, g.pa); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
     if (g.np >= 2u) { cln_put(row, g.fs, g.pb); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
     if (g.np >= 3u) { cln_put(row, g.fs, g.pc); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    g.np = 0;
+}
+__device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32_t p) {
     const uint32_t d = (p - 1u) >> 5;                                   // the oldest dword a window may still read
     const int32_t room = (int32_t)(CLN_RING + d - g.fill);                // slots that hold dwords before d
     g.np = 0;
@@ -142,26 +151,72 @@ __device__ __forceinline__ int32_t cln_careful_code(LaneReader& r, LCur& c, uint
     return x;
 }
 
-// what a lane needs to move "its" 16 bytes of every turn's tile: store k moves rows 16k .. 16k+15, four lanes per row
+// ---- the output side ------------------------------------------------------------------------------------------------------
+// A turn leaves 64 bytes per row in the stage; TWO turns' tiles leave for HBM together, as whole 128-byte lines: eight adjacent
+// lanes write one row's line, a store instruction covers eight rows, eight instructions the pair of tiles.  (Measured, 180 000 rows
+// of 16 KiB written by 2 813 waves: 64 bytes x 16 rows per instruction 3.15 TB/s, 128 bytes x 8 rows 4.95 TB/s -- and the
+// saturated kernel was within 20 % of the former's time: profiles/r03_ubench_storeshape.txt)
+// Stage layout: tile t's row r sits at row position r ^ t, its 16-byte piece p at p ^ ((r >> 1) & 3): the lanes' writes (one row
+// each) and the movers' reads (eight lanes = pieces 0-3 of tile 0 and of tile 1 of one row) both touch every bank group once.
+__device__ __forceinline__ int4* cln_mine(int4* stage0, uint32_t t0, int lane) {        // this lane's row in the tile of sample index t0
+    const uint32_t t = (t0 >> 4) & 1u;
+    return stage0 + t * 256u + (((uint32_t)lane ^ t) * 4u);
+}
 struct LMover {
-    int32_t* rq[4];            // row start + this lane's piece (or the dump slot of a row that does not exist)
-    uint32_t adv;              // bit k: rq[k] is a real row (the turn's sample index is added), else a dump slot
+    const uint64_t* rowp;      // LeanLds::rowp
     bool all_real;             // wave-uniform: every row of the wave exists
 };
-__device__ __forceinline__ void cln_store_tile(const int4* tile, const LMover& M, uint32_t t0, int lane) {
+// the pair of tiles that starts at sample index t0 (a multiple of 32)
+__device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
     clx_wave_sync();
-    const int4 w0 = tile[lane], w1 = tile[64 + lane], w2 = tile[128 + lane], w3 = tile[192 + lane];
-    if (M.all_real) clx_store4x16(M.rq[0] + t0, M.rq[1] + t0, M.rq[2] + t0, M.rq[3] + t0, w0, w1, w2, w3);
-    else clx_store4x16(M.rq[0] + ((M.adv & 1u) ? t0 : 0u), M.rq[1] + ((M.adv & 2u) ? t0 : 0u), M.rq[2] + ((M.adv & 4u) ? t0 : 0u),
-                       M.rq[3] + ((M.adv & 8u) ? t0 : 0u), w0, w1, w2, w3);
+    const uint32_t h = (uint32_t)lane >> 3, q = (uint32_t)lane & 7u, t = q >> 2;
+    const int4* const src = stage0 + t * 256u + ((h ^ t) * 4u) + ((q & 3u) ^ ((h >> 1) & 3u));      // + 32 int4 per instruction (8 rows)
+    const uint64_t* const rp = M.rowp + h;
+    const uint64_t toff = 4ull * t0 + 16ull * q, doff = 16ull * q;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int4 w[4];
+        uint64_t a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = src[32 * (4 * half + j)]; a[j] = rp[8 * (4 * half + j)]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = M.all_real ? a[j] + toff : (a[j] & 1ull) ? (a[j] & ~1ull) + doff : a[j] + toff;
+        clx_store4x16(reinterpret_cast<int32_t*>(a[0]), reinterpret_cast<int32_t*>(a[1]), reinterpret_cast<int32_t*>(a[2]), reinterpret_cast<int32_t*>(a[3]),
+                      w[0], w[1], w[2], w[3]);
+    }
     clx_wave_sync();
 }
-// The stage holds one turn's tile; it leaves for HBM at the START of the next turn (and when the kernel ends), so that the stores
-// are a whole turn old when the next counted wait on the vector-memory counter comes (the ring's refill, landed a turn after it
-// was requested): nothing in the steady state waits for a store's round trip.
-struct LTile { bool pending; uint32_t t0; };
-__device__ __forceinline__ void cln_flush(LTile& T, const int4* tile, const LMover& M, int lane) {
-    if (T.pending) { cln_store_tile(tile, M, T.t0, lane); T.pending = false; }          // (wave-uniform)
+// a lone tile 0 (the block's last 16 samples when the block size is an odd multiple of 16): 64 bytes x 16 rows per instruction
+__device__ __forceinline__ void cln_store_single(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
+    clx_wave_sync();
+    const uint32_t h = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+    int4 w[4];
+    uint64_t a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r = 16u * (uint32_t)k + h;
+        w[k] = stage0[r * 4u + (q ^ ((r >> 1) & 3u))];
+        const uint64_t rp = M.rowp[r];
+        a[k] = (rp & 1ull) ? (rp & ~1ull) + 16ull * q : rp + 4ull * t0 + 16ull * q;
+    }
+    clx_store4x16(reinterpret_cast<int32_t*>(a[0]), reinterpret_cast<int32_t*>(a[1]), reinterpret_cast<int32_t*>(a[2]), reinterpret_cast<int32_t*>(a[3]),
+                  w[0], w[1], w[2], w[3]);
+    clx_wave_sync();
+}
+// A finished pair leaves at the START of the turn after it (and what is left when the kernel ends): the stores then sit right in
+// front of the ring's landing, whose wait (s_waitcnt vmcnt(0): the compiler cannot count across the branches) paces them -- see
+// cln_land.  n: tiles in the stage that have not left (0, 1: tile 0 of a pair, 2), t0: the first one's sample index.
+struct LTile { uint32_t n; uint32_t t0; };
+__device__ __forceinline__ void cln_done(LTile& T, uint32_t t0) {                 // the tile of sample index t0 is in the stage
+    if ((t0 & 16u) == 0u) { T.n = 1u; T.t0 = t0; } else T.n = 2u;
+}
+__device__ __forceinline__ void cln_flush(LTile& T, const int4* stage0, const LMover& M, int lane) {
+    if (T.n == 2u) { cln_store_pair(stage0, M, T.t0, lane); T.n = 0u; }          // (wave-uniform)
+}
+__device__ __forceinline__ void cln_flush_all(LTile& T, const int4* stage0, const LMover& M, int lane) {
+    if (T.n == 2u) cln_store_pair(stage0, M, T.t0, lane);
+    else if (T.n == 1u) cln_store_single(stage0, M, T.t0, lane);
+    T.n = 0u;
 }
 
 // j-th coefficient (applies to s[i-1-j]) out of the packed form: C[q] = (c[2q] << 16) | (c[2q+1] & 0xffff)
@@ -171,7 +226,7 @@ __device__ __forceinline__ int32_t cln_coef(const uint32_t (&C)[NP], int j) {
 }
 
 // stereo decorrelation of the turn's sixteen samples (clx_lfinish, clx_lanes.hip) into the stage
-__device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Finish& F, int4* tile, int lane, uint32_t sw) {
+__device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Finish& F, int4* mine, uint32_t sw) {
     int32_t s[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = s0[i];
@@ -185,26 +240,19 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Fini
             const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
             int32_t y[4];
             clx_ms_short4(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
-            tile[(uint32_t)lane * 4u + ((uint32_t)b ^ sw)] = make_int4(y[0], y[1], y[2], y[3]);
+            mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
         }
     } else if (F.any_decor) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
+            const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
             int32_t y[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int32_t mine = s[4 * b + i];
-                const int32_t other = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);       // lane ^ 1
-                const uint32_t P = (uint32_t)(F.p_other ? other : mine);
-                const uint32_t R = (uint32_t)(F.r_other ? other : mine) & F.rmask;
-                const uint32_t mm = (P << F.s1) | (R & F.bit);
-                y[i] = (int32_t)(mm + ((R ^ F.sg) - F.sg)) >> F.s1;
-            }
-            tile[(uint32_t)lane * 4u + ((uint32_t)b ^ sw)] = make_int4(y[0], y[1], y[2], y[3]);
+            clx_decor4(m, y, F.dsg, F.drm, F.dc, F.s1, F.pmask);        // (exact below 2^29: part of the turn's range check)
+            mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
         }
     } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) tile[(uint32_t)lane * 4u + ((uint32_t)b ^ sw)] = make_int4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
+        for (int b = 0; b < 4; ++b) mine[(uint32_t)b ^ sw] = make_int4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
     }
 }
 
@@ -227,7 +275,7 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Fini
 template <int NP, int MODE, bool EDGE, int FORM, int HN>
 __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[HN], const uint32_t (&C)[NP],
                                               const int32_t (&CW)[2 * NP], uint32_t shift, uint32_t e1, uint32_t e3, int32_t lim, uint32_t per, uint32_t rice2,
-                                              uint32_t limit, bool live, const LKind& K, const Finish& F, int4* tile, int lane, uint32_t sw) {
+                                              uint32_t limit, bool live, const LKind& K, const Finish& F, int4* mine, uint32_t sw) {
     constexpr bool WIDE = FORM == 1, SPLIT = FORM == 2;
     constexpr int NH = 2 * NP - 1;                    // pairs carried from turn to turn
     static_assert(HN == (SPLIT ? 2 * NH : 2 * NP), "history registers");
@@ -255,9 +303,11 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
     uint32_t pw = c.p;
     int32_t S16[16];
     const uint32_t pb = 4u + rice2, esc = rice2 ? 31u : 15u;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        // a partition that starts exactly here: its parameter comes first (subframe.rs:314-319 / 362-367)
+    // The four's Rice codes are decoded first (that fixes where the next four starts), the next four's window is requested from the
+    // ring, and only then does the predictor run over the four samples: the LDS round trip hides behind it.
+    uint32_t wa, wb, wc, wd;
+    // a partition that starts exactly at a four: its parameter comes first (subframe.rs:314-319 / 362-367)
+    auto edge = [&]() {
         if (EDGE) {
             const bool at = c.pcnt == 0u;
             if (clx_any(at)) {
@@ -273,24 +323,28 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             bad = bad || c.pcnt < 4u;                 // (a partition edge inside the four codes: the slow turn's)
         }
         c.pcnt -= 4u;
-        const uint32_t kk = c.k & 31u;
-        // register window: 128 bits from bit c.p on
+    };
+    // register window: 128 bits from bit c.p on
+    auto window = [&]() {
         pw = c.p;
-        uint32_t wa, wb, wc, wd;
-        {
-            const uint32_t s = cln_slot(g, (c.p - 1u) >> 5);
-            const uint32_t w0 = CLN_AT(row, s), w1 = CLN_AT(row, s + 1u), w2 = CLN_AT(row, s + 2u), w3 = CLN_AT(row, s + 3u), w4 = CLN_AT(row, s + 4u);
-            const uint32_t sh = 0u - c.p;             // v_alignbit takes the low five bits: (32 - p % 32) % 32
-            wa = clx_alignbit(w0, w1, sh); wb = clx_alignbit(w1, w2, sh); wc = clx_alignbit(w2, w3, sh); wd = clx_alignbit(w3, w4, sh);
-        }
+        const uint32_t s = cln_slot(g, (c.p - 1u) >> 5);
+        const uint32_t w0 = CLN_AT(row, s), w1 = CLN_AT(row, s + 1u), w2 = CLN_AT(row, s + 2u), w3 = CLN_AT(row, s + 3u), w4 = CLN_AT(row, s + 4u);
+        const uint32_t sh = 0u - c.p;                 // v_alignbit takes the low five bits: (32 - p % 32) % 32
+        wa = clx_alignbit(w0, w1, sh); wb = clx_alignbit(w1, w2, sh); wc = clx_alignbit(w2, w3, sh); wd = clx_alignbit(w3, w4, sh);
+    };
+    edge(); window();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t kk = c.k & 31u, k4 = c.k, c14 = c1;
         uint32_t shsum = 0;
+        uint32_t X[4];
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * b + ii;
             // one Rice code (subframe.rs:337-341): z zeros, a one, k remainder bits = 32 - sh bits
+            // (v_ffbh + v_min; a sentinel bit under the code instead of the clamp measured no faster: tools/gpu_ab.sh)
             const uint32_t z = (uint32_t)__clz((int)wa);
-            int32_t sh = (int32_t)(c1 - z);
-            const uint32_t u = (z << kk) | clx_bfe(wa, (uint32_t)sh, c.k);
+            int32_t sh = (int32_t)(c14 - z);
+            const uint32_t u = (z << kk) | clx_bfe(wa, (uint32_t)sh, k4);
             uint32_t xr = (u >> 1) ^ (0u - (u & 1u));                      // rice_to_signed (subframe.rs:157-170)
             if (MODE == 0) msh = sh < msh ? sh : msh;
             else {
@@ -303,6 +357,16 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             }
             shsum += (uint32_t)sh;
             wa = clx_alignbit(wa, wb, (uint32_t)sh); wb = clx_alignbit(wb, wc, (uint32_t)sh); wc = clx_alignbit(wc, wd, (uint32_t)sh); wd = clx_alignbit(wd, 0u, (uint32_t)sh);
+            X[ii] = xr;
+        }
+        CLX_OPAQUE(msh);                                          // (folded per four: no shift count of the block stays live for the vote)
+        c.p += MODE == 0 ? 128u - shsum : ((128u - shsum) & K.bitmask);
+        if (b < 3) { edge(); window(); }
+        CLN_SCHED_FENCE();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * b + ii;
+            const uint32_t xr = X[ii];
             // predictor, oldest tap first: only the last term depends on the sample before
             int32_t acc = 0;
             int32_t pred;
@@ -333,11 +397,10 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             hi = s > hi ? s : hi; lo = s < lo ? s : lo;
             S16[i] = s;
         }
-        CLX_OPAQUE(msh); CLX_OPAQUE(hi); CLX_OPAQUE(lo);         // (folded per four: no shift count of the block stays live for the vote)
-        c.p += MODE == 0 ? 128u - shsum : ((128u - shsum) & K.bitmask);
+        CLX_OPAQUE(hi); CLX_OPAQUE(lo);
     }
     // stereo decorrelation and the stage: the wave-uniform choice of the form once per turn
-    cln_finish16(S16, F, tile, lane, sw);
+    cln_finish16(S16, F, mine, sw);
     // what was decoded is what the stream holds iff no code was longer than its window register, the last window lay inside the
     // ring's filled part and nothing reached past the end of the frame; the predictor was exact iff the outputs (the next turn's
     // history) stayed inside the range
@@ -384,14 +447,14 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
                                          uint32_t per, uint32_t rice2,
                                          uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane) {
 
-    int4* const tile = stage - 4 * lane;                 // the wave's 64 x 4 staging slots seen as one tile
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;      // (eight neighbouring lanes' 16-byte stage stores then cover all 32 banks)
     bool slow = true;                                    // H holds i32 samples (the prologue leaves them so)
     bool ring_ok = false;
     uint32_t nslow = 0;
     for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
         const bool live = n != 0u && !r.err;
-        cln_flush(T, tile, M, lane);                     // the turn before's tile
+        cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
+        int4* const mine = cln_mine(stage, t0, lane);
         if (slow) {
             // back to the lean turns as soon as every live lane's history fits the packed form
             bool in = true;
@@ -404,7 +467,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             }
         }
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
-        else cln_pump(buf, g, row, cur.p);
+        else { cln_land(g, row); cln_request(buf, g, cur.p); }
         const bool was_slow = slow;                      // (no lean turn is tried: the history does not fit the packed form)
         int done = 0;
         bool refilled = false;                           // the ring was refilled on the spot once in this turn (a lane outran it)
@@ -412,12 +475,12 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
           again_lean:
             if (mode == 0 || NP == 2) {                // (NP == 2 is only run with mode 0)
                 // a partition edge inside the turn?  (lanes that decode nothing never say yes; cur.pcnt of the others is exact)
-                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
-                else                                 done = cln_lean_turn<NP, 0, false, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
+                else                                 done = cln_lean_turn<NP, 0, false, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
             }
-            else                      done = cln_lean_turn<NP, 1, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            else                      done = cln_lean_turn<NP, 1, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
             if (done > 0) {
-                T.pending = true; T.t0 = t0;
+                cln_done(T, t0);
                 CLX_STAT(50, 1);
                 continue;
             }
@@ -440,9 +503,9 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             for (int j = 0; j < 2 * NP; ++j) in24 = in24 && (int32_t)H[j] < lim24 && (int32_t)H[j] >= -lim24;
             if (__all(in24 || !live || order == 0u)) {
               again_wide:
-                const int dw = cln_lean_turn<NP, 1, true, 1>(row, g, cur, H, C, CW, shift, 0u, 0u, lim24, per, rice2, r.limit, live, K, F, tile, lane, sw);
+                const int dw = cln_lean_turn<NP, 1, true, 1>(row, g, cur, H, C, CW, shift, 0u, 0u, lim24, per, rice2, r.limit, live, K, F, mine, sw);
                 if (dw > 0) {
-                    T.pending = true; T.t0 = t0;
+                    cln_done(T, t0);
                     CLX_STAT(58, 1);
                     continue;
                 }
@@ -452,7 +515,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
         CLX_STAT(51, 1);
         if (++nslow > CLN_SLOW_BUDGET && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // (wave-uniform; not when the end is near anyway)
         // ---- slow turn: sixteen samples one by one, generic reader, i64 predictor (taps beyond the order are zero)
-        int32_t* const ys = reinterpret_cast<int32_t*>(stage);
+        int32_t* const ys = reinterpret_cast<int32_t*>(mine);
 #pragma unroll 1
         for (uint32_t ii = 0; ii < 16u; ++ii) {
             int32_t x = 0;
@@ -467,7 +530,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             const int32_t v = clx_lfinish(s, F);
             ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
         }
-        T.pending = true; T.t0 = t0;
+        cln_done(T, t0);
         ring_ok = false;                                  // the position moved without the ring
     }
     return true;
@@ -528,7 +591,6 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
                                            const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2,
                                            uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane) {
     constexpr int NH = 2 * NP - 1;
-    int4* const tile = stage - 4 * lane;
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
     const uint32_t e1 = shift <= 12u ? 12u - shift : 0u, e2 = shift <= 12u ? shift : 12u, e3 = shift <= 12u ? 0u : shift - 12u;
     uint32_t H[2 * NH];
@@ -548,15 +610,16 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
     uint32_t nslow = 0;
     for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
         const bool live = n != 0u && !r.err;
-        cln_flush(T, tile, M, lane);                     // the turn before's tile
+        cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
+        int4* const mine = cln_mine(stage, t0, lane);
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
-        else cln_pump(buf, g, row, cur.p);
+        else { cln_land(g, row); cln_request(buf, g, cur.p); }
         {
             bool refilled = false;
           again:
-            const int done = cln_lean_turn<NP, 1, true, 2>(row, g, cur, H, C, CW, e2, e1, e3, lim, per, rice2, r.limit, live, K, F, tile, lane, sw);
+            const int done = cln_lean_turn<NP, 1, true, 2>(row, g, cur, H, C, CW, e2, e1, e3, lim, per, rice2, r.limit, live, K, F, mine, sw);
             if (done > 0) {
-                T.pending = true; T.t0 = t0;
+                cln_done(T, t0);
                 CLX_STAT(9, 1);
                 continue;
             }
@@ -567,7 +630,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         // ---- slow turn: sixteen samples one by one, generic reader, i64 predictor (taps beyond the order are zero)
         int32_t U[2 * NP];
         cln_unpack12<NP>(H, U);
-        int32_t* const ys = reinterpret_cast<int32_t*>(stage);
+        int32_t* const ys = reinterpret_cast<int32_t*>(mine);
 #pragma unroll 1
         for (uint32_t ii = 0; ii < 16u; ++ii) {
             int32_t x = 0;
@@ -587,7 +650,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         for (int j = 0; j < 2 * NP; ++j) in = in && U[j] < lim && U[j] >= -lim;
         if (!__all(in || !live || order == 0u)) return false;
         cln_pack12<NP>(U, H);
-        T.pending = true; T.t0 = t0;
+        cln_done(T, t0);
         ring_ok = false;                                  // the position moved without the ring
     }
     return true;
@@ -691,21 +754,13 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     const uint32_t nmax = bs0;
     const uint32_t n = active ? bs : 0u;
 
-    // ---- the rows this lane moves (four lanes per row, 16 rows per store), dump slots for rows that do not exist
+    // ---- where the wave's rows are (cln_store_pair), dump slots for rows that do not exist
     LMover M;
     {
-        const uint32_t pc = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 3) & 3u);       // piece ^ swizzle of row (lane >> 2): ((row >> 1) & 3)
-        int32_t* const dump = dump_all + (size_t)slot * 16u;
-        M.adv = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int src = k * 16 + (lane >> 2);
-            const uint64_t ro = __shfl((unsigned long long)(rowp - out), src, 64);
-            const bool real = __shfl((int)(active ? 1 : 0), src, 64) != 0;
-            M.rq[k] = real ? out + ro + 4u * pc : dump + 4 * k;
-            M.adv |= real ? (1u << k) : 0u;
-        }
-        M.all_real = __all(M.adv == 15u);
+        L.rowp[lane] = active ? (uint64_t)(uintptr_t)rowp : ((uint64_t)(uintptr_t)(dump_all + (size_t)slot * 32u) | 1ull);
+        M.rowp = L.rowp;
+        M.all_real = __all(active);
+        clx_wave_sync();
     }
     const Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
 
@@ -726,8 +781,8 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         else { S.phase = 0u; S.trans_at = h.order; }
     }
     const uint32_t i0 = (omax + 4u + 15u) & ~15u;           // 16 or 32 (SPLIT: up to 48) (<= bs)
-    LTile T = { false, 0u };
-    int32_t* const ys = reinterpret_cast<int32_t*>(L.stage[lane]);
+    LTile T = { 0u, 0u };
+    int4* const stage0 = &L.stage[0][0][0];
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
 #pragma unroll 1
     for (uint32_t i = 0; i < i0; ++i) {
@@ -738,9 +793,9 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
-        if ((i & 15u) == 0u) cln_flush(T, L.stage[0], M, lane);
-        ys[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
-        if ((i & 15u) == 15u) { T.pending = true; T.t0 = i & ~15u; }
+        if ((i & 15u) == 0u) cln_flush(T, stage0, M, lane);
+        reinterpret_cast<int32_t*>(cln_mine(stage0, i, lane))[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
+        if ((i & 15u) == 15u) cln_done(T, i & ~15u);
     }
     // ---- steady state
     const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
@@ -762,12 +817,12 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         if constexpr (SPLIT) {
             // the split evaluation needs sum|c| < 2^19 (S.lim >= 4096) -- any <= 32 coefficients of <= 15 bits but the all -2^14 row
             if (__any(lv && S.order != 0u && S.lim < 4096)) done = false;
-            else if (omax <= 12u) done = cln_run24<6, OMAX>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, F, M, T, lane);
-            else                  done = cln_run24<16, OMAX>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, F, M, T, lane);
+            else if (omax <= 12u) done = cln_run24<6, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane);
+            else                  done = cln_run24<16, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane);
         } else {
-            if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
-            else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
-            else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], L.stage[lane], n, i0, nmax, K, mode, F, M, T, lane);
+            if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane);
+            else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane);
+            else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane);
         }
         if (!done) {                                       // given up: clx_k_lanes decodes the group
             if (lane == 0) taken[blockIdx.x] = 0u;
@@ -775,7 +830,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
             return;
         }
     }
-    cln_flush(T, L.stage[0], M, lane);                      // the last turn's tile
+    cln_flush_all(T, stage0, M, lane);                      // what is still in the stage
     // ---- trailing parameters of empty partitions are part of the stream (they move the next subframe / the CRC)
     if (n != 0u && !S.r.err && S.transitioned) {
         while (!S.r.err && S.parts_left != 0u) { (void)clx_lread_rice_param(S.r, S.rice2); S.parts_left -= 1u; }
@@ -786,14 +841,14 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     }
 }
 
-extern "C" __global__ __launch_bounds__(64)
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
                 int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;
     cln_kernel<false>(L, runs, frames, slot_frame, n_slots, dump_all);
 }
 
-extern "C" __global__ __launch_bounds__(64)
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 void clx_k_lean24(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
                   int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;

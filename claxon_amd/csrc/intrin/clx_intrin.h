@@ -11,6 +11,8 @@ __device__ __forceinline__ uint32_t clx_alignbit(uint32_t hi, uint32_t lo, uint3
 __device__ __forceinline__ uint32_t clx_bfe(uint32_t src, uint32_t offset, uint32_t width) {
     return __builtin_amdgcn_ubfe(src, offset, width);
 }
+// nothing is scheduled across this point (the compiler otherwise orders a basic block by its own latency model)
+#define CLX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // v_perm_b32: byte i of the result is byte sel[8i+7:8i] of the 8-byte value {hi, lo} (selectors 0-3: lo, 4-7: hi)
 __device__ __forceinline__ uint32_t clx_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // v_mad_i32_i24: low 32 bits of sext24(a)*sext24(b) + c.  Inline asm so that the accumulation stays a chain in
@@ -179,6 +181,43 @@ __device__ __forceinline__ void clx_ms_short4(const int32_t (&y)[4], int32_t (&o
                  "v_add_u32_dpp %3, %8, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
                  : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
                  : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(sgn), "v"(c));
+}
+// Any stereo decorrelation (frame.rs:319-389) of four samples, or none, by per-lane constants: in a pair of lanes (channel 0 in the
+// even one) the value that is added or subtracted is always the odd lane's and the value it is applied to the even lane's, so
+//     out = (even & pmask) + ((((odd ^ sg) & rmask) + c) >> s1)
+// covers mid/side (both lanes: rmask = pmask = ~0, s1 = 1, sg / c = 0 / 1 in the even lane, ~0 / 2 in the odd one), left/side
+// (even: rmask = 0; odd: sg = ~0, c = 1 -- left - side), right/side (even: side + right; odd: pmask = 0 -- its own value is the
+// odd one) and lanes without a partner (even: rmask = 0; odd: pmask = 0), while nothing wraps in the mid/side form (below 2^29:
+// the caller's range check).  Six instructions per sample, two of them DPP.
+__device__ __forceinline__ void clx_decor4(const int32_t (&y)[4], int32_t (&out)[4], uint32_t sg, uint32_t rmask, uint32_t c, uint32_t s1, uint32_t pmask) {
+    uint32_t t, e;
+    asm volatile("s_nop 1\n\t"
+                 "v_xor_b32_dpp %4, %6, %10 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32_dpp %5, %6, %14 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32 %4, %4, %11\n\t"
+                 "v_add_u32 %4, %4, %12\n\t"
+                 "v_ashrrev_i32 %4, %13, %4\n\t"
+                 "v_add_u32 %0, %5, %4\n\t"
+                 "v_xor_b32_dpp %4, %7, %10 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32_dpp %5, %7, %14 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32 %4, %4, %11\n\t"
+                 "v_add_u32 %4, %4, %12\n\t"
+                 "v_ashrrev_i32 %4, %13, %4\n\t"
+                 "v_add_u32 %1, %5, %4\n\t"
+                 "v_xor_b32_dpp %4, %8, %10 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32_dpp %5, %8, %14 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32 %4, %4, %11\n\t"
+                 "v_add_u32 %4, %4, %12\n\t"
+                 "v_ashrrev_i32 %4, %13, %4\n\t"
+                 "v_add_u32 %2, %5, %4\n\t"
+                 "v_xor_b32_dpp %4, %9, %10 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32_dpp %5, %9, %14 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_and_b32 %4, %4, %11\n\t"
+                 "v_add_u32 %4, %4, %12\n\t"
+                 "v_ashrrev_i32 %4, %13, %4\n\t"
+                 "v_add_u32 %3, %5, %4"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t), "=&v"(e)
+                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(sg), "v"(rmask), "v"(c), "v"(s1), "v"(pmask));
 }
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at lds_base + 16*lane (no VGPR
 // round trip, asynchronous, counted by vmcnt).  Inline asm on purpose: hipcc drains vmcnt(0) before the next LDS read

@@ -267,8 +267,8 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  *   - usually the lane kernels, fused build.  One run of those is a serial chain per subframe on a fraction of the machine, and
  *     the machine runs only a handful of kernels from different queues side by side -- so consecutive submissions are MERGED:
  *     they wait until a few of them are there (or until somebody flushes / asks for results) and go out as ONE grid whose second
- *     dimension is the submission, on three internal streams in turn (the scan stage of one launch overlaps the decode stage of
- *     another).  Every submission has its own scratch buffers and results.  No environment variable is involved: three internal
+ *     dimension is the submission, on two internal streams in turn (the scan stage of one launch overlaps the decode stage of
+ *     another).  Every submission has its own scratch buffers and results.  No environment variable is involved: two internal
  *     streams fit HIP's default number of hardware queues.
  *   - the wave kernels, four in flight on internal streams of their own, for small batches of short codes.
  * A submission starts no earlier than everything queued on `stream` when it (or a later one merged with it) was submitted.  Give
@@ -277,12 +277,12 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  * clx_batch_flush: work enqueued on `stream` after it sees every submission finished; clx_batch_results and
  * clx_batch_interleave flush by themselves; clx_batch_results returns the LAST submission's results. */
 #ifndef CLX_SUBMIT_DEPTH
-#define CLX_SUBMIT_DEPTH 12     /* the most submissions any batch keeps in flight */
+#define CLX_SUBMIT_DEPTH 24     /* the most submissions any batch keeps in flight */
 #endif
 int  clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
                       int32_t* d_out, void* stream);
-/* How many submissions THIS batch keeps in flight, i.e. how many output buffers to rotate over: 4 for the wave kernels, 12 for
- * the lane kernels (three merged launches of four), 1 where a submission is a plain run. */
+/* How many submissions THIS batch keeps in flight, i.e. how many output buffers to rotate over: 4 for the wave kernels, 24 for
+ * the lane kernels (two merged launches of twelve), 1 where a submission is a plain run. */
 int  clx_batch_submit_depth(const clx_batch* b);
 int  clx_batch_submit_lanes(const clx_batch* b);      /* 1: its pipelined submissions run the fused lane kernels */
 int  clx_batch_flush(clx_batch* b, void* stream);

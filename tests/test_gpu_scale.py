@@ -149,11 +149,11 @@ def test_pipelined_submissions_of_the_lane_kernels(oracle, ctx):
     the fused ones, twelve in flight on the library's streams with a set of scratch buffers each (clx_select_path, `pipelined`;
     clx_batch_submit_depth) -- with a plain run in between, on the same batch.  All of it against the oracle."""
     import torch
-    w = synth.config5_unique(12288)
+    w = synth.config5_unique(6144)
     descs = pc.workload_descs(w)
     d_arena = torch.from_numpy(w.arena).to("cuda:0")
     batch = ctx.plan(descs, w.out_offs, verify_crc=True)
-    assert batch.submit_depth == cx.SUBMIT_DEPTH == 12 and batch.submit_lanes
+    assert batch.submit_depth == cx.SUBMIT_DEPTH == 24 and batch.submit_lanes
     outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(batch.submit_depth + 1)]
     torch.cuda.synchronize()
     for i in range(2 * batch.submit_depth + 3):

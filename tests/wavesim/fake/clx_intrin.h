@@ -49,6 +49,7 @@ static inline uint4 clx_buf_load16(const clx_buf& b, uint32_t byte_off) {     //
 #define clx_ms_pair4(y, out, sgn, nsg, one) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_pair_(__LINE__, (y)[q_], (sgn), (nsg), (one)); } while (0)
 #define clx_any(p) (wavesim::any_(__LINE__, (p) ? 1 : 0) != 0)
 #define CLX_OPAQUE(x) ((void)(x))
+#define CLX_SCHED_BARRIER() ((void)0)
 static inline void clx_store4x16(int32_t* p0, int32_t* p1, int32_t* p2, int32_t* p3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
     *reinterpret_cast<int4*>(p0) = w0; *reinterpret_cast<int4*>(p1) = w1; *reinterpret_cast<int4*>(p2) = w2; *reinterpret_cast<int4*>(p3) = w3;
 }
@@ -58,6 +59,12 @@ static inline int32_t clx_ms_short_(int line, int32_t y, uint32_t sgn, uint32_t 
     return (int32_t)(mid + (uint32_t)((int32_t)((side ^ sgn) + c) >> 1));
 }
 #define clx_ms_short4(y, out, sgn, c) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_short_(__LINE__, (y)[q_], (sgn), (c)); } while (0)
+static inline int32_t clx_decor_(int line, int32_t y, uint32_t sg, uint32_t rmask, uint32_t c, uint32_t s1, uint32_t pmask) {
+    const uint32_t odd = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xF5, 0xF, 0xF, false);       // quad_perm [1,1,3,3]
+    const uint32_t even = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xA0, 0xF, 0xF, false);      // quad_perm [0,0,2,2]
+    return (int32_t)((even & pmask) + (uint32_t)((int32_t)(((odd ^ sg) & rmask) + c) >> s1));
+}
+#define clx_decor4(y, out, sg, rmask, c, s1, pmask) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_decor_(__LINE__, (y)[q_], (sg), (rmask), (c), (s1), (pmask)); } while (0)
 // LDS-DMA in the simulator: synchronous copy; the "LDS address" is simply the host pointer of the shared object.
 static inline uintptr_t clx_lds_addr(const void* p) { return (uintptr_t)p; }
 static inline void clx_glds16(const void* gsrc, uintptr_t lds_base) {

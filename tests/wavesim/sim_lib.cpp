@@ -35,7 +35,7 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
         // CLX_LANES_FUSED: the fused kernels; otherwise the two-wave one
         if (flags & CLX_LANES_FUSED) {
-            std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
+            std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 32 + 16);
             // the lean kernel first (it marks the groups it decodes with this run's generation number), unless the caller
             // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
             if (lean) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
