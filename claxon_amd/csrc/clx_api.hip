@@ -308,6 +308,7 @@ struct clx_batch {
     // results / flushes); merged launches rotate over three internal streams, so that the scan stage of one overlaps the
     // decode stage of the other.  Flights are only the runs' scratch buffers here.
     enum { kMerge = CLX_SUBMIT_MERGE, kStreams = CLX_SUBMIT_STREAMS, kMaxStreams = 6 };
+    bool merge_tuned = false;
     int merge = kMerge, n_streams = kStreams;          // (CLX_TUNE_MERGE / CLX_TUNE_STREAMS in the environment override them: tuning only)
     struct Pending { const uint8_t* arena; size_t arena_len; int32_t* out; int flight; };
     std::vector<Pending> pend;
@@ -423,6 +424,13 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
 int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
     const int st = batch_plan_(b, frames, n, out_sample_offsets, flags);
     if (st != CLX_OK) { b->n = 0; b->n_slots = 0; b->n_multi = 0; b->planned_arena_len = (size_t)-1; }      // a failed plan leaves an empty batch, not a half-updated one
+    if (!b->merge_tuned) {
+        // runs per merged launch: twelve while that stays below ~24 000 waves of 64 subframes, fewer for larger batches (125 000 stereo
+        // frames per run: 6 x 2 in flight 2.35 ms per run, 12 x 2 3.40, 1 x 2 2.64 -- profiles/r03_merge_sweep.txt)
+        const uint64_t groups = (b->n_slots + 63) / 64;
+        const uint64_t m = groups ? 24576ull / groups : (uint64_t)clx_batch::kMerge;
+        b->merge = (int)std::min<uint64_t>(std::max<uint64_t>(m, 1), (uint64_t)clx_batch::kMerge);
+    }
     return st;
 }
 int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
@@ -514,7 +522,7 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     {   // tuning knobs (measurement only; the defaults are compiled in): runs per merged launch, internal streams
         const char* em = std::getenv("CLX_TUNE_MERGE"); const char* es = std::getenv("CLX_TUNE_STREAMS");
         const int m = em ? std::atoi(em) : 0, st = es ? std::atoi(es) : 0;
-        if (m >= 1 && m <= CLX_MAX_MERGE) b->merge = m;
+        if (m >= 1 && m <= CLX_MAX_MERGE) { b->merge = m; b->merge_tuned = true; }
         if (st >= 1 && st <= clx_batch::kMaxStreams) b->n_streams = st;
         if (b->merge * b->n_streams > clx_batch::kDepthLanes) b->n_streams = std::max(1, clx_batch::kDepthLanes / b->merge);
     }

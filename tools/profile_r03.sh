@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 rocprofv3 evidence (run through gpurun).  For the bench workload (config 3, the kernels of the TIMED steps: fused lane
-# kernels with the lean 16-bit tier): kernel trace + stats of steps one at a time, of ONE merged launch of six steps, and of the
+# kernels with the lean 16-bit tier): kernel trace + stats of steps one at a time, of ONE merged launch of twelve steps, and of the
 # pipelined steps (the timed mode); HBM counters and SQ instruction / wait counters in separate --pmc passes.  For configs 2 / 4 / 5:
 # kernel stats and HBM counters of steps one at a time.  Outputs under gpurun_out/prof_r03_<name>/; summaries go to profiles/.
 # usage: tools/profile_r03.sh [names...]     names: config3 config2 config4 config5 (default: all)
@@ -31,13 +31,13 @@ for NAME in $NAMES; do
   done
   python $REPO/tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
   if [ "$NAME" = config3 ]; then
-    echo "== config3: one merged launch of six steps at a time"
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/merged6" -o t -- python $REPO/tools/merge_probe.py 6 5 > "$OUT/merged6.log" 2>&1
+    echo "== config3: one merged launch of twelve steps at a time"
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/merged12" -o t -- python $REPO/tools/merge_probe.py 12 5 > "$OUT/merged12.log" 2>&1
     echo "== config3: kernel trace of the pipelined steps (the timed mode)"
     timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pipe" -o t -- python $REPO/bench.py --steps 48 --warmup 12 --no-cpu-baseline --no-extras > "$OUT/pipe.log" 2>&1
     python $REPO/tools/trace_pipelined.py "$OUT/pipe" > "$OUT/pipelined_trace.txt" 2>&1
     for set in "FETCH_SIZE" "WRITE_SIZE"; do
-      timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/merged6_$set" -o p -- python $REPO/tools/merge_probe.py 6 3 > "$OUT/merged6_$set.log" 2>&1
+      timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/merged12_$set" -o p -- python $REPO/tools/merge_probe.py 12 3 > "$OUT/merged12_$set.log" 2>&1
     done
   fi
   tail -8 "$OUT/summary.txt"
