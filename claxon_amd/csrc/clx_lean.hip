@@ -1,24 +1,26 @@
-// clx_lean.hip -- the lean build of the fused lane kernel (D): what 16-bit audio is made of, and nothing else.
+// clx_lean.hip -- the lean builds of the fused lane kernel (D): what 16-bit (and 24-bit) audio is made of, and nothing else.
 //
-//   DL clx_k_lean   one lane per subframe like clx_k_lanes (clx_lanes.hip), for the waves of 64 subframes in which every live
-//                   lane decodes a Rice-coded FIXED / LPC subframe of at most 12 taps of <= 16-bit audio (the side channel has
-//                   17), in 16-byte aligned rows of one common block size that is a multiple of 16.  Such a wave marks its group
-//                   as taken; clx_k_lanes / clx_k_lanes_hi skip taken groups and decode every other one as before.
+//   DL  clx_k_lean    one lane per subframe like clx_k_lanes (clx_lanes.hip), for the waves of 64 subframes in which every live
+//                     lane decodes a subframe of <= 16-bit audio (the side channel has 17) with at most 12 taps, in 16-byte aligned
+//                     rows of one common block size that is a multiple of 16.  Such a wave marks its group as taken; the kernels
+//                     behind it skip taken groups.
+//   DL4 clx_k_lean24  the same for <= 24-bit audio (25) and <= 32 taps, on the groups clx_k_lean left: the split form of the
+//                     turn (two v_dot2 chains on 12 / 16-bit pieces of every sample instead of 64-bit multiply-adds).
 //
-// Why a second build: clx_k_lanes carries every tier of every case in one register allocation (195 VGPRs: two waves per SIMD) and
-// spends ~40 instructions per sample.  This one keeps ONE fast tier and one slow one:
+// Why more builds: clx_k_lanes carries every tier of every case in one register allocation (195 VGPRs: two waves per SIMD) and
+// spends ~40 instructions per sample (148 with the i64 predictor).  These keep ONE fast tier and one slow one:
 //   * lean turn, 16 samples: four register windows of four Rice codes each (one LDS read per window, funnel shifts between
 //     the codes); the predictor on 16-bit packed history, two taps per v_dot2_i32_i16 (subframe.rs:559-582's loop; exact while
 //     every history sample lies in [-2^15, 2^15) and sum|c| * 2^15 < 2^31 -- checked on the data per turn, not assumed);
-//     mid/side etc. through DPP; the turn's 64 x 16 samples leave as 64-byte row segments, 16 rows per store instruction.
-//     It decodes first and asks afterwards: one wave vote per turn.
+//     stereo decorrelation through DPP; two turns' 64 x 16 samples leave together as whole 128-byte lines, 8 rows per store
+//     instruction.  It decodes first and asks afterwards: one wave vote per turn.
 //   * slow turn, 16 samples: a rolled per-sample loop over the generic reader with the i64 predictor (subframe.rs:586-614's
 //     arithmetic), which handles every rare case in line -- partition edges inside a four, escape codes, codes longer than
 //     32 bits, the end of the frame, history outside the 16-bit range.  The wave returns to lean turns as soon as every
 //     lane's history is back inside.
 // The history lives in ONE register array that holds packed pairs (lean) or i32 samples (slow), converted where the tier
 // changes; coefficients stay packed (the slow tier unpacks them per tap).  Per-lane LDS: a ring of CLN_RING stream dwords
-// (+ 4 mirrored) and the 64-byte output stage.
+// (+ 4 mirrored), 128 bytes of output stage and the row's address.
 //
 // Mirrors the reference read for read like clx_k_lanes: subframe.rs:29-91, 184-228, 236-380, 492-516, 651-721; frame.rs:319-389.
 #ifndef CLN_RING

@@ -198,8 +198,9 @@ enum {
     CLX_K2_LATENCY      = 1u << 8,
     CLX_K2_THROUGHPUT   = 1u << 9,
     /* The fused lane build runs clx_k_lean first (the 16-bit tier: waves of <= 16-bit FIXED / LPC subframes of at most 12 taps in
-     * aligned rows) and the general kernels on the groups it leaves.  This flag leaves clx_k_lean out: every group goes through
-     * the general kernels (test and comparison target). */
+     * aligned rows), then clx_k_lean24 (the split tier: <= 24 bits, <= 32 taps) when the batch holds frames of more than 16 bits,
+     * and the general kernels on the groups those leave.  This flag leaves the tiers out: every group goes through the general
+     * kernels (test and comparison target). */
     CLX_LANES_GENERAL   = 1u << 10
 };
 
