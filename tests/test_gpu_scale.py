@@ -121,6 +121,45 @@ def test_bench_configuration_against_the_oracle(oracle, ctx):
     bl.close(); batch.close()
 
 
+def test_config4_at_scale_against_the_oracle(oracle, ctx):
+    """BASELINE configs[3] at its full size: 10 000 stereo 4096-sample 24-bit frames, 32 taps of 15 bits, Rice2, wasted bits, every
+    channel assignment -- pipelined submissions (the split tier clx_k_lean24 behind the scan), every buffer, status, message and end
+    bit against the oracle; and one profiled run: the split tier decoded every group."""
+    import torch
+    w = synth.config4(10000)
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True)
+    depth = min(batch.submit_depth, 6)
+    assert batch.submit_lanes
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(depth)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(batch.submit_depth + 3):
+        batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.array_equal(res["status"], r["statuses"]) and np.all(res["status"] == cx.OK)
+    assert np.array_equal(res["msg"], r["msgs"])
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    d_ref = torch.from_numpy(ref).to("cuda:0")
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o, d_ref)), "output buffer %d differs from the oracle" % k
+    assert np.array_equal(ref, w.pcm)
+    bl = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED)
+    bl.set_profiling(True)
+    outs[0].fill_(0x13131313)
+    bl.run(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    torch.cuda.synchronize()
+    kt = bl.kernel_times()
+    assert {"clx_k_scan", "clx_k_lean24", "clx_k_lanes", "clx_k_finalize", "clx_k_crc16"} <= set(kt) and "clx_k_lean" not in kt, sorted(kt)
+    assert kt["clx_k_lanes"] < 0.05 * kt["clx_k_lean24"], kt         # (ms: clx_k_lanes + _hi only looked at the taken flags)
+    assert bool(torch.equal(outs[0], d_ref))
+    bl.close(); batch.close()
+
+
 def test_forced_builds_at_scale(oracle, ctx, big3):
     """The builds the thresholds would not pick at this size, forced by flag on the same 12 288 frames."""
     w = pc.head(big3, 12288)
