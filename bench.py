@@ -25,7 +25,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# (No HIP environment variable is set here: the timed steps go out as merged launches on three internal streams of the library,
+# (No HIP environment variable is set here: the timed steps go out as merged launches (up to twelve steps per grid) on two internal streams of the library,
 # which HIP's default number of hardware queues covers.  GPU_MAX_HW_QUEUES, if the caller sets it, is carried in the line.)
 
 import numpy as np  # noqa: E402

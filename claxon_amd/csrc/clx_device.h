@@ -46,7 +46,9 @@ struct clx_sf_desc {
 
 // Lane path: one launch may decode several RUNS of the same planned batch -- the same frame descriptors against different arenas
 // and output buffers (consecutive submissions merged into one grid: blockIdx.y picks the run).  What differs between the runs:
+#ifndef CLX_MAX_MERGE
 #define CLX_MAX_MERGE 12
+#endif
 struct clx_run {
     const uint8_t* arena;    // the run's compressed frames
     uint64_t alloc_len;      // bytes readable from `arena` (the padded allocation)
