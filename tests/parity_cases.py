@@ -344,6 +344,15 @@ def lean_workload(scale=1):
                     fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 13)), 10, int(g.integers(0, 2)))
                 return (L, R), fp
             family(bs, 32, 2, mk_g)
+    # (j) last: a wave with idle lanes (10 subframes) and an odd number of tiles -- the dump slots of the pair stores and of the
+    #     lone last tile's store
+    def mk_j(i):
+        (L, R), g = music(i, 48)
+        fp = S.FrameParams(i % 4, 0, i)
+        for c in range(2):
+            fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 13)), 11, int(g.integers(0, 2)))
+        return (L, R), fp
+    family(48, 5, 2, mk_j)
     return synth.concat("lean tiers", ws)
 
 
@@ -476,6 +485,14 @@ def lean24_workload(scale=1):
                 fp.sf[c] = S.sf(S.SF_LPC, 32, 15, 3)
             return (L, R), fp
         family(1024, 32, 2, 24, mk_i)
+    # (j) last: a wave with idle lanes and an odd number of tiles
+    def mk_j(i):
+        (L, R), g = music(i, 80, 24)
+        fp = S.FrameParams(i % 4, 0, i)
+        for c in range(2):
+            fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 33)), 12, int(g.integers(0, 2)))
+        return (L, R), fp
+    family(80, 3, 2, 24, mk_j)
     return synth.concat("lean24 tiers", ws)
 
 
