@@ -304,9 +304,9 @@ struct clx_batch {
     // Lane path, fused build: consecutive submissions are MERGED into one launch (grid.y = the runs; kernels take a clx_runs table).
     // The machine runs only a handful of kernels from different queues side by side however many queues there are (measured:
     // about six), and one run of these kernels is a serial chain per subframe on a fraction of the machine -- so filling it takes one
-    // grid that holds many runs, not many streams.  Submissions wait in `pend` until kMerge of them are there (or somebody asks for
-    // results / flushes); merged launches rotate over three internal streams, so that the scan stage of one overlaps the
-    // decode stage of the other.  Flights are only the runs' scratch buffers here.
+    // grid that holds many runs, not many streams.  Submissions wait in `pend` until `merge` of them are there (kMerge, fewer for very
+    // large batches: batch_plan; or until somebody asks for results / flushes); merged launches rotate over two internal streams,
+    // so that the scan stage of one overlaps the decode stage of the other.  Flights are only the runs' scratch buffers here.
     enum { kMerge = CLX_SUBMIT_MERGE, kStreams = CLX_SUBMIT_STREAMS, kMaxStreams = 6 };
     bool merge_tuned = false;
     int merge = kMerge, n_streams = kStreams;          // (CLX_TUNE_MERGE / CLX_TUNE_STREAMS in the environment override them: tuning only)

@@ -9,7 +9,7 @@ out = sys.argv[1]
 
 
 def find(pattern):
-    # (the passes of the profile proper: trace/ and pmc<N>/; side experiments in the same directory -- merged6*, pipe -- are not mixed in)
+    # (the passes of the profile proper: trace/ and pmc<N>/; side experiments in the same directory -- merged12*, pipe -- are not mixed in)
     fs = sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
     keep = [f for f in fs if os.path.basename(os.path.dirname(f)).startswith(("trace", "pmc"))]
     return keep or fs
