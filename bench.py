@@ -163,6 +163,32 @@ def main():
         bl.close()
         path_tag = "_lanes"
 
+    # ---- the launch shape of the TIMED steps, one launch at a time: the library merges consecutive submissions into one grid
+    #      (batch.submit_depth / 2 runs per launch); its kernels' durations with nothing beside them, HIP events on the internal
+    #      stream they are launched on (clx_batch_set_profiling(b, 2)) -- what `rocprofv3 --kernel-trace --stats` of
+    #      tools/merge_probe.py shows (profiles/r03_config3_merged12_kernel_stats.csv)
+    merged = None
+    if pipelined and batch.submit_lanes:
+        n_merge = max(1, depth // 2)
+        batch.set_profiling(2)
+        acc = {}
+        reps = 3
+        for rep in range(reps + 1):
+            for i in range(n_merge):
+                batch.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), stream)
+            batch.flush(stream)
+            torch.cuda.synchronize()
+            if rep:
+                for name, ms in batch.kernel_times().items():
+                    acc[name] = acc.get(name, 0.0) + ms / reps
+        batch.set_profiling(False)
+        if acc:
+            tot = float(sum(acc.values()))
+            merged = {"runs_per_launch": n_merge, "kernel_ms": {k: round(v, 4) for k, v in acc.items()}, "ms_per_run": round(tot / n_merge, 4),
+                      "achieved": round(w.algorithmic_bytes * n_merge / (tot * 1e-3) / 1e9, 1),
+                      "frac": round(w.algorithmic_bytes * n_merge / (tot * 1e-3) / 1e9 / PEAK_GBS, 4),
+                      "note": "ONE merged launch at a time (its kernels one after the other, nothing beside them); the timed steps keep two such launches in flight on two streams"}
+
     # the timed steps write into buffers that were cleared after the gate: what is compared afterwards is what THEY wrote
     for o in outs:
         o.zero_()
@@ -206,6 +232,8 @@ def main():
                                     "note": "one of the path's kernels; the path's bytes over its time alone would overstate it"},
                 "step_achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_GBS, 4)}
+    if merged:
+        roofline["merged_launch"] = merged
     if prof and prof.get("insts"):
         # What actually bounds these kernels: the SIMDs' instruction issue.  A SIMD of gfx950 takes one vector
         # instruction per ~4.2 cycles whatever it is (2.3 for the simplest: mov / add / logic / shift), a scalar one between vector

@@ -628,7 +628,8 @@ class Batch:
         return res
 
     def set_profiling(self, on=True):
-        lib().clx_batch_set_profiling(self._h, 1 if on else 0)
+        """True / 1: plain runs with per-kernel events; 2: pipelined submissions, events around the kernels of each merged launch."""
+        lib().clx_batch_set_profiling(self._h, int(on) if not isinstance(on, bool) else (1 if on else 0))
 
     def kernel_ms(self, kernel):
         ms = C.c_float(0)

@@ -275,12 +275,13 @@ struct clx_batch {
     uint32_t* d_errkey = nullptr;
     uint64_t* d_endbits = nullptr;
     uint32_t* d_taken = nullptr;     // per group of 64 slots: the generation number of the run in which clx_k_lean decoded it
-    bool profiling = false;
+    bool profiling = false, profile_merged = false;
     enum { kMaxKernels = 8 };
     hipEvent_t ev[kMaxKernels + 1] = {};
     const char* kname[kMaxKernels] = {};
     int n_kernels = 0;
     bool ev_valid = false;
+    int ev_runs = 1;                  // runs in the launch the events belong to (1 for a plain run)
     hipStream_t last_stream = nullptr;
     size_t planned_arena_len = 0;
     // Pipelined submissions (clx_batch_submit): up to kDepth submissions in flight, each a whole run (Rice stage, predictor stage,
@@ -535,7 +536,8 @@ extern "C" uint64_t clx_batch_slots(const clx_batch* b) { return b ? b->n_slots 
 
 extern "C" int clx_batch_set_profiling(clx_batch* b, int enable) {
     if (!b) return CLX_API_ERROR;
-    b->profiling = enable != 0;
+    b->profiling = enable == 1;            // 1: every submission is a plain run with an event in front of each kernel
+    b->profile_merged = enable == 2;       // 2: pipelined submissions as usual, events around the kernels of each MERGED launch
     b->ev_valid = false;
     return CLX_OK;
 }
@@ -737,8 +739,14 @@ int launch_pending(clx_batch* b) {
         b->m_outs[k].push_back(P.out);
         b->flight_launch_stream[P.flight] = k;
     }
-    const auto no_mark = [](const char*) { return true; };
-    if (!launch_lanes(b, runs, n_runs, false, ms, no_mark)) return CLX_API_ERROR;
+    int nk = 0;
+    auto mark = [&](const char* name) -> bool {          // (clx_batch_set_profiling(b, 2): an event in front of each kernel, one behind the last)
+        if (!b->profile_merged) return true;
+        if (name) b->kname[nk] = name;
+        return hip_ok(ctx, hipEventRecord(b->ev[nk++], ms), "hipEventRecord");
+    };
+    if (!launch_lanes(b, runs, n_runs, false, ms, mark)) return CLX_API_ERROR;
+    if (b->profile_merged) { if (!mark(nullptr)) return CLX_API_ERROR; b->n_kernels = nk - 1; b->ev_valid = true; b->ev_runs = (int)n_runs; }
     HIP_TRY(ctx, hipEventRecord(b->m_done[k], ms));
     b->m_recorded[k] = true; b->m_unwaited[k] = true;
     b->pend.clear();

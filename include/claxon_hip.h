@@ -297,8 +297,10 @@ int  clx_batch_results(clx_batch* b, clx_frame_result* results);
 int  clx_batch_interleave(clx_batch* b, const int32_t* d_planar, void* d_pcm, uint32_t sample_bytes, void* stream);
 /* Number of predictor slots (subframes incl. alignment padding) in the plan. */
 uint64_t clx_batch_slots(const clx_batch* b);
-/* Per-kernel HIP-event timing of the LAST run made with profiling enabled: kernels are numbered in
- * launch order (clx_batch_kernel_name gives the name; NULL past the last one). */
+/* Per-kernel HIP-event timing: kernels are numbered in launch order (clx_batch_kernel_name gives the name; NULL past the last
+ * one).  enable = 1: every clx_batch_run / clx_batch_submit is a plain run with an event in front of each kernel (the LAST run's
+ * durations are kept); enable = 2: pipelined submissions go out as usual and the events bracket the kernels of each MERGED launch
+ * of the lane kernels (the LAST launch's durations are kept: submit, clx_batch_flush, synchronise, read); 0: off. */
 int  clx_batch_set_profiling(clx_batch* b, int enable);
 int  clx_batch_kernel_ms(clx_batch* b, int kernel, float* ms);
 const char* clx_batch_kernel_name(const clx_batch* b, int kernel);

@@ -34,7 +34,7 @@ for NAME in $NAMES; do
     echo "== config3: one merged launch of twelve steps at a time"
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/merged12" -o t -- python $REPO/tools/merge_probe.py 12 5 > "$OUT/merged12.log" 2>&1
     echo "== config3: kernel trace of the pipelined steps (the timed mode)"
-    timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pipe" -o t -- python $REPO/bench.py --steps 48 --warmup 12 --no-cpu-baseline --no-extras > "$OUT/pipe.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pipe" -o t -- python $REPO/bench.py --steps 48 --warmup 12 --no-cpu-baseline --no-extras > "$OUT/pipe.log" 2>&1
     python $REPO/tools/trace_pipelined.py "$OUT/pipe" > "$OUT/pipelined_trace.txt" 2>&1
     for set in "FETCH_SIZE" "WRITE_SIZE"; do
       timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/merged12_$set" -o p -- python $REPO/tools/merge_probe.py 12 3 > "$OUT/merged12_$set.log" 2>&1
