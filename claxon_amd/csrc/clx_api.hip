@@ -588,8 +588,12 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
     const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
     if (b->n_multi) {
         if (!mark("clx_k_scan")) return false;
-        hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64), n_runs), dim3(64), 0, stream, runs,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi);
+        if (b->flags & CLX_LANES_GENERAL)         // (the round-2 build of the scan, with the round-2 decode kernels: the comparison target)
+            hipLaunchKernelGGL(clx_k_scan_general, dim3((unsigned)((b->n_multi + 63) / 64), n_runs), dim3(64), 0, stream, runs,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi);
+        else
+            hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64), n_runs), dim3(64), 0, stream, runs,
+                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi);
     }
     if (!split) {
         // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them

@@ -293,8 +293,8 @@ __device__ __forceinline__ void clx_win_skip(Win& w, uint32_t nb) {
 // P: locate subframes 1..C-1 of every multi-channel frame
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames,
-                const uint32_t* __restrict__ multi, uint32_t n_multi) {
+void clx_k_scan_general(const clx_runs runs, const clx_dev_frame* __restrict__ frames,
+                        const uint32_t* __restrict__ multi, uint32_t n_multi) {
     __shared__ struct { uint32_t ring[64][CLX_ROW]; } L;        // (the ring only: 10 KiB per wave instead of LanesLds' 14 -- more of them fit beside the decode waves)
     const clx_run& R = runs.r[blockIdx.y];
     const uint8_t* const arena = R.arena;

@@ -153,6 +153,205 @@ __device__ __forceinline__ int32_t cln_careful_code(LaneReader& r, LCur& c, uint
     return x;
 }
 
+// ---- P: the scan in the lean kernels' form --------------------------------------------------------------------------------
+// clx_k_scan: one lane per multi-channel frame walks channels 0 .. C-2 (headers + the LENGTH of every Rice code, no output) to find
+// the bit at which each later subframe starts -- subframe c+1 begins where subframe c ends, there is no length field
+// (frame.rs:705-742).  The round-2 build (clx_k_scan_general, clx_lanes.hip: lane-major ring, blocks of four codes with a vote
+// each) cost 14 vector instructions per code; this one runs the lean kernels' turn without its predictor and output: the
+// slot-major ring, sixteen codes per turn (four register windows of four codes; per code v_ffbh, v_min, one subtraction, half a
+// v_min3, one addition and one and a half v_alignbit), one vote per turn, the careful reader for everything rare.
+// One turn of sixteen code lengths.  Returns 1 (cursor advanced for the live lanes), 0 (a rare case: the careful steps'), -2
+// (nothing but the ring having run dry).
+template <bool EDGE>
+__device__ __forceinline__ int cln_scan_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t per, uint32_t rice2, uint32_t limit, bool live) {
+    LCur c = cur;
+    if (!live) c.pcnt = 0x7fffff00u;                  // (lanes that skip nothing never meet a partition edge)
+    uint32_t c1 = 31u - c.k;
+    CLX_OPAQUE(c1);
+    bool bad = false;
+    int32_t msh = 0;                                  // the smallest "bits left of the window after the code" -- negative: a code > 32 bits
+    uint32_t pw = c.p;
+    const uint32_t pb = 4u + rice2, esc = rice2 ? 31u : 15u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (EDGE) {                                   // a partition that starts exactly here: its parameter comes first
+            const bool at = c.pcnt == 0u;
+            if (clx_any(at)) {
+                const uint32_t pv = cln_peek32(row, g, c.p);
+                if (at) {
+                    c.k = pv >> (32u - pb);
+                    bad = bad || c.k == esc || c.parts == 0u || c.next == 0u;
+                    c.p += pb; c.parts -= 1u; c.pcnt = c.next; c.next = per;
+                    c1 = 31u - c.k;
+                }
+                CLX_OPAQUE(c1);
+            }
+            bad = bad || c.pcnt < 4u;                 // (a partition edge inside the four codes: the careful steps')
+        }
+        c.pcnt -= 4u;
+        pw = c.p;
+        uint32_t wa, wb, wc, wd;
+        {
+            const uint32_t s = cln_slot(g, (c.p - 1u) >> 5);
+            const uint32_t w0 = CLN_AT(row, s), w1 = CLN_AT(row, s + 1u), w2 = CLN_AT(row, s + 2u), w3 = CLN_AT(row, s + 3u), w4 = CLN_AT(row, s + 4u);
+            const uint32_t sh = 0u - c.p;
+            wa = clx_alignbit(w0, w1, sh); wb = clx_alignbit(w1, w2, sh); wc = clx_alignbit(w2, w3, sh); wd = clx_alignbit(w3, w4, sh);
+        }
+        uint32_t shsum = 0;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t z = (uint32_t)__clz((int)wa);
+            const int32_t sh = (int32_t)(c1 - z);     // 32 - (z + 1 + k): what is left of the window behind the code
+            msh = sh < msh ? sh : msh;
+            shsum += (uint32_t)sh;
+            wa = clx_alignbit(wa, wb, (uint32_t)sh); wb = clx_alignbit(wb, wc, (uint32_t)sh); wc = clx_alignbit(wc, wd, (uint32_t)sh); wd = clx_alignbit(wd, 0u, (uint32_t)sh);
+        }
+        CLX_OPAQUE(msh);
+        c.p += 128u - shsum;
+    }
+    const bool covered = ((pw - 1u) >> 5) + 5u <= g.fill && c.p <= limit;
+    const bool ok = !live || (!bad && msh >= 0 && covered);
+    if (__all(ok)) {
+        const uint32_t p_in = cur.p;
+        cur = c;
+        if (!live) cur.p = p_in;
+        return 1;
+    }
+    if (__any(live && (bad || msh < 0 || c.p > limit))) return 0;
+    return -2;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ multi, uint32_t n_multi) {
+    __shared__ struct { uint32_t ring[CLN_ROW][64]; } L;        // (the ring only: 7 KiB per wave -- they fit beside the decode waves)
+    const clx_run& R = runs.r[blockIdx.y];
+    const uint8_t* const arena = R.arena;
+    const uint64_t arena_alloc_len = R.alloc_len;
+    uint32_t* const sf_start = R.sf_start;
+    uint32_t* const errkey = R.errkey;
+    const int lane = (int)threadIdx.x;
+    uint32_t* const row = &L.ring[0][lane];
+    const uint32_t t = blockIdx.x * 64u + (uint32_t)lane;
+    const bool active = t < n_multi;
+    const uint32_t f = active ? multi[t] : 0u;
+    clx_dev_frame fr;
+    fr.byte_off = 0; fr.out_off = 0; fr.limit_bits = 0; fr.first_slot = 0; fr.header_bytes = 0; fr.block_size = 0;
+    fr.n_channels = 0; fr.channel_assignment = 0; fr.bps = 1; fr.flags = 0;
+    if (active) fr = frames[f];
+    LaneReader r;
+    r.arena = arena;
+    r.origin = (uint32_t)(fr.byte_off & ~15ull);
+    const uint32_t o = 8u * (uint32_t)(fr.byte_off & 15ull);
+    r.limit = o + fr.limit_bits;
+    r.pos = o + 8u * (uint32_t)fr.header_bytes;
+    r.err = active ? ((r.pos > r.limit) ? CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF) : 0u) : 1u;
+    // (the ring addresses the arena with 32-bit offsets through a buffer descriptor: a frame whose window could reach beyond them
+    //  takes the careful steps only -- the lane path is not selected for arenas of 4 GiB anyway)
+    const bool ring_able = (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
+    const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
+    LRing g;
+    g.origin = r.origin; g.fill = 0; g.fs = 0; g.np = 0; g.pa = make_uint4(0u, 0u, 0u, 0u); g.pb = g.pa; g.pc = g.pa;
+    LKind KR;                                            // (the careful reader's view: every lane skips Rice codes)
+    KR.rice = true; KR.verb = false; KR.bitmask = 0xffffffffu; KR.ricemask = 0xffffffffu; KR.verbmask = 0u; KR.cor = 0u; KR.vsh = 0u; KR.vshm = 0u;
+    const uint32_t bs = fr.block_size;
+    uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
+    uint32_t nch_max = nch;
+#pragma unroll
+    for (int sx = 32; sx >= 1; sx >>= 1) { const uint32_t a = __shfl_xor(nch_max, sx, 64); nch_max = a > nch_max ? a : nch_max; }
+
+    for (uint32_t ch = 0; ch < nch_max; ++ch) {
+        const bool on = ch < nch && !r.err;
+        // ---- headers (per lane, generic reader)
+        uint32_t codes = 0, first = 0, per = 0, parts_left = 0, rice2 = 0, order = 0;
+        if (on) {
+            const SfHead h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
+            if (!r.err) {
+                if (h.kind == 0u) (void)clx_lread(r, h.sf_bps);
+                else if (h.kind == 1u) {
+                    if ((uint64_t)r.pos + (uint64_t)bs * h.sf_bps > (uint64_t)r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                    else r.pos += bs * h.sf_bps;
+                } else {
+                    if (bs < h.order) r.err = CLX_LERR(CLX_FORMAT_ERROR, h.kind == 2u ? CLX_MSG_FIXED_ORDER_GT_BLOCK : CLX_MSG_LPC_ORDER_GT_BLOCK);
+                    if (!r.err) {
+                        if (r.pos + h.order * h.sf_bps > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                        else r.pos += h.order * h.sf_bps;
+                    }
+                    if (!r.err && h.kind == 3u) {
+                        const uint32_t pm1 = clx_lread(r, 4);
+                        if (!r.err && pm1 == 15u) r.err = CLX_LERR(CLX_FORMAT_ERROR, CLX_MSG_QLP_PRECISION_INVALID);
+                        const uint32_t sh = clx_lread(r, 5);
+                        if (!r.err && (sh & 0x10u)) r.err = CLX_LERR(CLX_UNSUPPORTED, CLX_MSG_NEGATIVE_QLP_SHIFT);
+                        if (!r.err) {
+                            if (r.pos + h.order * (pm1 + 1u) > r.limit) r.err = CLX_LERR(CLX_IO_ERROR, CLX_MSG_UNEXPECTED_EOF);
+                            else r.pos += h.order * (pm1 + 1u);
+                        }
+                    }
+                    if (!r.err) {
+                        const ResHead rh = clx_lparse_residual_header(r, bs, h.order);
+                        if (!r.err) { codes = bs - h.order; first = rh.per - h.order; per = rh.per; parts_left = rh.n_part; rice2 = rh.rice2; order = h.order; }
+                    }
+                }
+            }
+        }
+        // ---- all Rice codes of this subframe: only their lengths matter here
+        uint32_t left = r.err ? 0u : codes;                 // codes still to skip
+        LCur cur = { on ? r.pos : 32u, 0u, 0u, first, parts_left };      // (a lane that scans nothing rides along from a harmless position)
+        // (one careful step: partition parameters, codes of any length, the end of the frame -- cln_careful_code's)
+        // Partitions end at multiples of their length in SAMPLES: the first (-order mod 16) codes go one by one, so that the turns
+        // below start on multiples of 16 samples -- in every lane, whatever the orders of the subframes the lanes scan.
+        {
+            uint32_t pre = (0u - order) & 15u;
+            pre = pre < left ? pre : left;
+#pragma unroll 1
+            for (; __any(pre != 0u); ) {
+                if (pre != 0u) { (void)cln_careful_code(r, cur, per, rice2, KR); left -= 1u; pre = r.err ? 0u : pre - 1u; }
+            }
+            if (r.err) left = 0u;
+        }
+        bool ring_ok = false;
+#pragma unroll 1
+        while (__any(left >= 16u && !r.err)) {
+            const bool has = left >= 16u && !r.err;          // this lane has sixteen codes to skip
+            const bool live = has && ring_able;
+            const LCur keep = cur;                           // (a lane without them rides along where it is: its ring stays consistent)
+            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
+            else { cln_land(g, row); cln_request(buf, g, cur.p); }
+            int done = 0;
+            bool refilled = false;
+            if (__all(live || !has)) {
+              again:
+                if (clx_any(live && cur.pcnt < 16u)) done = cln_scan_turn<true>(row, g, cur, per, rice2, r.limit, live);
+                else                                 done = cln_scan_turn<false>(row, g, cur, per, rice2, r.limit, live);
+                if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; goto again; }
+            }
+            if (!has) cur = keep;                            // (its tail is still to come: nothing of the ride may stick)
+            if (done > 0) { if (has) left -= 16u; continue; }
+            // sixteen careful steps (rolled) for the lanes that have them
+#pragma unroll 1
+            for (int ii = 0; ii < 16; ++ii) {
+                if (has && !r.err) { (void)cln_careful_code(r, cur, per, rice2, KR); left -= 1u; }
+            }
+            if (r.err) left = 0u;
+            ring_ok = false;                                // the positions moved without the ring
+        }
+        // the tail (fewer than sixteen codes), one by one
+#pragma unroll 1
+        while (__any(left != 0u && !r.err)) {
+            if (left != 0u && !r.err) { (void)cln_careful_code(r, cur, per, rice2, KR); left -= 1u; }
+        }
+        if (on && !r.err) r.pos = cur.p;
+        parts_left = cur.parts;
+        // partition parameters that belong to empty partitions at the very end (order == block size: subframe.rs:509, 706)
+        if (on && !r.err) {
+            while (!r.err && parts_left != 0u) { (void)clx_lread_rice_param(r, rice2); parts_left -= 1u; }
+        }
+        if (on) {
+            if (r.err) clx_report_error(errkey, f, ch, r.err);
+            else sf_start[fr.first_slot + ch + 1u] = r.pos;
+        }
+    }
+}
+
 // ---- the output side ------------------------------------------------------------------------------------------------------
 // A turn leaves 64 bytes per row in the stage; TWO turns' tiles leave for HBM together, as whole 128-byte lines: eight adjacent
 // lanes write one row's line, a store instruction covers eight rows, eight instructions the pair of tiles.  (Measured, 180 000 rows

@@ -32,7 +32,10 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         runs.r[0].arena = arena; runs.r[0].alloc_len = alloc_len + 16; runs.r[0].out = out; runs.r[0].sf_start = sf_start.data();
         runs.r[0].errkey = errkey.data(); runs.r[0].end_bits = endbits.data(); runs.r[0].taken = lean ? taken.data() : nullptr;
         runs.r[0].results = results; runs.r[0].gen = 7u;
-        if (n_multi) SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
+        if (n_multi) {
+            if (flags & CLX_LANES_GENERAL) SIM_LAUNCH(clx_k_scan_general, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
+            else SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
+        }
         // CLX_LANES_FUSED: the fused kernels; otherwise the two-wave one
         if (flags & CLX_LANES_FUSED) {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 32 + 16);
