@@ -3,7 +3,7 @@
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
-O=$REPO/gpurun_out/r03v; mkdir -p $O
+O=$REPO/gpurun_out/launch_width; mkdir -p $O
 for M in 1 2 3 4 6 8 9 10 12; do
   CLX_TUNE_MERGE=$M CLX_TUNE_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m$M -o t -- python $REPO/tools/merge_probe.py $M 4 > $O/m$M.log 2>&1
   python - $O/m$M $M <<'PY'

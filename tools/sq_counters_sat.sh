@@ -2,7 +2,7 @@
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
-O=$REPO/gpurun_out/r03w; mkdir -p $O
+O=$REPO/gpurun_out/sq_sat; mkdir -p $O
 timeout 120 rocprofv3 -L > $O/avail.txt 2>&1
 grep -o "SQ_[A-Z0-9_]*" $O/avail.txt | sort -u | tr '\n' ' ' > $O/sq_names.txt
 wc -w $O/sq_names.txt
