@@ -83,3 +83,32 @@ def test_submit_matches_run(setup, flags, crc):
     check(w, outs[0], res, ref, r, crc)
     check(w, outs[1], res, ref, r, crc)
     b.close()
+
+
+def test_merged_launch_profiling(setup):
+    """clx_batch_set_profiling(b, 2): pipelined submissions go out as usual and the per-kernel events bracket the kernels of the
+    merged launch (what bench.py's roofline.merged_launch reports); the outputs are still exact and profiling can be switched off."""
+    import torch
+    ctx, w, descs, d_arena, ref, r = setup
+    b = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED)
+    depth = b.submit_depth
+    assert depth > 1 and b.submit_lanes
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(depth // 2)]
+    torch.cuda.synchronize()
+    b.set_profiling(2)
+    assert b.submit_depth == depth                                  # (mode 1 would turn submissions into plain runs)
+    for o in outs:
+        b.submit(d_arena.data_ptr(), w.arena_len, o.data_ptr())
+    b.flush()
+    torch.cuda.synchronize()
+    kt = b.kernel_times()
+    assert "clx_k_finalize" in kt and "clx_k_crc16" in kt and ("clx_k_lean" in kt or "clx_k_lean24" in kt or "clx_k_lanes" in kt), sorted(kt)
+    assert all(v >= 0.0 for v in kt.values())
+    res = b.results()
+    for o in outs:
+        check(w, o, res, ref, r, True)
+    b.set_profiling(False)
+    b.submit(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    res = b.results()
+    check(w, outs[0], res, ref, r, True)
+    b.close()
