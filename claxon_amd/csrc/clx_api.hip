@@ -266,7 +266,8 @@ struct clx_batch {
     int32_t* d_dump = nullptr;       // 128 bytes per lane for out-of-row stores (the wave kernels and clx_k_lanes use 64 of them)
     // lane path
     bool lanes = false;              // clx_batch_run uses the lane kernels
-    bool lanes_planned = false;      // their plan data (d_slot_frame, d_multi, scratch) exists: run or submit may use them
+    bool lanes_planned = false;      // their plan data (d_slot_frame, d_multi, scratch) exists (plan_lanes_data)
+    bool lanes_submit = false;       // pipelined submissions take the lane kernels (unless a flag says otherwise)
     uint32_t* d_slot_frame = nullptr;
     uint32_t* d_multi = nullptr;
     size_t n_multi = 0;
@@ -420,6 +421,29 @@ template <typename T> bool grow(clx_ctx* ctx, T** p, size_t* cap, size_t need, c
     *cap = want;
     return true;
 }
+// The lane kernels' plan data for the batch as planned: slot -> frame map, the multi-channel frames, the scratch of flight 0.
+int plan_lanes_data(clx_batch* b) {
+    clx_ctx* ctx = b->ctx;
+    if (b->lanes_planned) return CLX_OK;
+    const size_t n = b->n, ns = b->n_slots ? (size_t)b->n_slots : 1, nf = n ? n : 1;
+    std::vector<uint32_t> slot_frame(ns), multi(nf);
+    b->n_multi = clx_plan_lanes(b->h_frames.data(), n, b->n_slots, slot_frame.data(), multi.data());
+    b->any_bps_le16 = b->any_bps_gt16 = false;
+    for (size_t i = 0; i < n; ++i) { if (b->h_frames[i].bps <= 16u) b->any_bps_le16 = true; else b->any_bps_gt16 = true; }
+    if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
+        !grow(ctx, &b->d_multi, &b->cap[5], nf * sizeof(uint32_t), "hipMalloc multi") ||
+        !grow(ctx, &b->d_sf_start, &b->cap[6], ns * sizeof(uint32_t), "hipMalloc sf_start") ||
+        !grow(ctx, &b->d_errkey, &b->cap[7], nf * sizeof(uint32_t), "hipMalloc errkey") ||
+        !grow(ctx, &b->d_endbits, &b->cap[8], nf * sizeof(uint64_t), "hipMalloc endbits") ||
+        !grow(ctx, &b->d_taken, &b->cap[9], ((ns + 63) / 64) * sizeof(uint32_t), "hipMalloc taken") ||
+        !hip_ok(ctx, hipMemset(b->d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "memset taken") ||
+        !hip_ok(ctx, hipMemset(b->d_sf_start, 0xff, ns * sizeof(uint32_t)), "memset sf_start") ||
+        !hip_ok(ctx, hipMemset(b->d_errkey, 0xff, nf * sizeof(uint32_t)), "memset errkey") ||
+        !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
+        !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) return CLX_API_ERROR;
+    b->lanes_planned = true;
+    return CLX_OK;
+}
 // (Re)plan `b` for a list of frames: host-side planning, kernel selection, device buffers (reused when they are large enough).
 int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags);
 int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
@@ -469,25 +493,11 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
         const size_t lanes64 = ((ns + 127) / 128) * 128;
         if (!grow(ctx, &b->d_dump, &b->cap[3], lanes64 * 32 * sizeof(int32_t), "hipMalloc dump")) return CLX_API_ERROR;      // (128 bytes per lane: clx_k_lean's)
     }
-    // (the lane kernels' plan data: when either a run or a pipelined submission may use them)
-    b->lanes_planned = b->lanes || ((flags & CLX_PATH_WAVES) == 0 && b->choice_submit.lanes);
-    if (b->lanes_planned) {
-        std::vector<uint32_t> slot_frame(ns), multi(nf);
-        b->n_multi = clx_plan_lanes(b->h_frames.data(), n, slot, slot_frame.data(), multi.data());
-        b->any_bps_le16 = b->any_bps_gt16 = false;
-        for (size_t i = 0; i < n; ++i) { if (b->h_frames[i].bps <= 16u) b->any_bps_le16 = true; else b->any_bps_gt16 = true; }
-        if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
-            !grow(ctx, &b->d_multi, &b->cap[5], nf * sizeof(uint32_t), "hipMalloc multi") ||
-            !grow(ctx, &b->d_sf_start, &b->cap[6], ns * sizeof(uint32_t), "hipMalloc sf_start") ||
-            !grow(ctx, &b->d_errkey, &b->cap[7], nf * sizeof(uint32_t), "hipMalloc errkey") ||
-            !grow(ctx, &b->d_endbits, &b->cap[8], nf * sizeof(uint64_t), "hipMalloc endbits") ||
-            !grow(ctx, &b->d_taken, &b->cap[9], ((ns + 63) / 64) * sizeof(uint32_t), "hipMalloc taken") ||
-            !hip_ok(ctx, hipMemset(b->d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "memset taken") ||
-            !hip_ok(ctx, hipMemset(b->d_sf_start, 0xff, ns * sizeof(uint32_t)), "memset sf_start") ||
-            !hip_ok(ctx, hipMemset(b->d_errkey, 0xff, nf * sizeof(uint32_t)), "memset errkey") ||
-            !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
-            !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) return CLX_API_ERROR;
-    }
+    // (the lane kernels' plan data: now when a run uses them, else with the first pipelined submission -- plan_lanes_data: one-shot
+    //  decodes of a few frames, which run the wave kernels, do not pay for it)
+    b->lanes_submit = (flags & CLX_PATH_WAVES) == 0 && b->choice_submit.lanes;
+    b->lanes_planned = false;
+    if (b->lanes && plan_lanes_data(b) != CLX_OK) return CLX_API_ERROR;
     // (a re-planned batch starts over: nothing of the previous plan may be in flight -- the caller's contract)
     for (int i = 0; i < clx_batch::kDepth; ++i) {
         clx_batch::Flight& F = b->flight[i];
@@ -832,7 +842,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
 namespace {
 // which kernels a pipelined submission uses, and how many submissions it keeps in flight
 bool submit_wants_lanes(const clx_batch* b) {
-    return (b->flags & CLX_PATH_LANES) ? true : (b->flags & CLX_PATH_WAVES) ? false : (b->lanes_planned && b->choice_submit.lanes);
+    return (b->flags & CLX_PATH_LANES) ? true : (b->flags & CLX_PATH_WAVES) ? false : b->lanes_submit;
 }
 }  // namespace
 
@@ -873,6 +883,7 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
     }
     if (want_lanes) {
         // ---- fused lane kernels: the submission joins the pending ones; kMerge of them go out as one launch (launch_pending)
+        if (plan_lanes_data(b) != CLX_OK) return CLX_API_ERROR;       // (with the batch's first pipelined submission when no run needed it)
         if (!F.d_sf_start) {
             if (slot == 0) { F.d_sf_start = b->d_sf_start; F.d_errkey = b->d_errkey; F.d_endbits = b->d_endbits; F.d_taken = b->d_taken; }
             else {

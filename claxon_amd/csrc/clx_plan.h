@@ -48,12 +48,10 @@ static inline long clx_plan_frames(const clx_frame_desc* frames, size_t n, const
 //   16-bit, ~5 bits per sample (configs 2 and 3)                                     lanes from ~52 000 subframes (28 000 when mono:
 //                                                                                    no scan pass for the later channels)
 // and between the two lane builds the two-wave one while its workgroups still get a CU each (longer for 24-bit audio).
-// `pipelined`: the batch is one of several in flight (clx_batch_submit).  There a run of the fused lane kernels -- one serial chain
-// per subframe on a fraction of the machine's registers, 0.85-1.3 ms however few subframes -- has eleven others beside it, and
-// the question is throughput: the lane kernels (fused build) unless the batches are small AND of short codes, where the wave
-// kernels' four in flight are ahead (measured with a hardware queue per stream, profiles/r02_bench_configs_sweep_d.txt):
-//   24-bit audio, or >= ~8.5 compressed bits per sample                               lanes always
-//   ~5 bits per sample (configs 2 and 3)                                              lanes from ~10 000 subframes (5 000 when mono)
+// `pipelined`: the batch is one of several in flight (clx_batch_submit).  There up to twelve runs of the fused lane kernels go out
+// as ONE grid (round 3: merged launches), and that form is ahead of the wave kernels' four in flight at every size measured
+// (tools/path_threshold_sweep.sh, profiles/r03_path_sweep.txt: 600 .. 5 000 frames of configs 2 and 3, 3.6x .. 4.4x; round 2's
+// unmerged runs had lost to the wave kernels below ~10 000 subframes of short codes): the lane kernels always.
 // `bytes` = sum of the frames' max_bytes when those are real frame lengths (0 = unknown, e.g. "to the end of the stream").
 struct clx_path_choice { bool lanes, lanes_split; };
 static inline clx_path_choice clx_select_path(uint64_t slots, uint64_t samples, uint64_t bytes, bool heavy, bool all_mono, bool pipelined = false) {
@@ -61,11 +59,12 @@ static inline clx_path_choice clx_select_path(uint64_t slots, uint64_t samples, 
     double rate = (samples && bytes) ? 8.0 * (double)bytes / (double)samples : 7.5;      // compressed bits per sample
     if (rate > 32.0) rate = 7.5;                                                          // not frame lengths: unknown
     double threshold;
-    if (heavy) threshold = pipelined ? 0.0 : 3000.0;       // (a quarter or more of the samples are wider than 16 bits)
+    if (pipelined) threshold = 0.0;
+    else if (heavy) threshold = 3000.0;                    // (a quarter or more of the samples are wider than 16 bits)
     else {
         // at <= 6.5 / >= 8.5 bits per sample
-        const double lo = pipelined ? (all_mono ? 5000.0 : 10000.0) : (all_mono ? 28000.0 : 52000.0);
-        const double hi = pipelined ? 0.0 : (all_mono ? 14000.0 : 20000.0);
+        const double lo = all_mono ? 28000.0 : 52000.0;
+        const double hi = all_mono ? 14000.0 : 20000.0;
         const double t = rate <= 6.5 ? 0.0 : rate >= 8.5 ? 1.0 : (rate - 6.5) / 2.0;
         threshold = lo + (hi - lo) * t;
     }

@@ -271,7 +271,8 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  *     dimension is the submission, on two internal streams in turn (the scan stage of one launch overlaps the decode stage of
  *     another).  Every submission has its own scratch buffers and results.  No environment variable is involved: two internal
  *     streams fit HIP's default number of hardware queues.
- *   - the wave kernels, four in flight on internal streams of their own, for small batches of short codes.
+ *   - the wave kernels, four in flight on internal streams of their own: only when CLX_PATH_WAVES asks for them or the arena is
+ *     4 GiB or more (the merged lane launches are ahead at every batch size measured).
  * A submission starts no earlier than everything queued on `stream` when it (or a later one merged with it) was submitted.  Give
  * the submissions in flight different `d_out` buffers, i.e. rotate over clx_batch_submit_depth(b) of them (re-using a buffer is
  * legal: the submission then goes out after the earlier one that writes it).  Submissions may stay pending until

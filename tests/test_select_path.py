@@ -34,17 +34,19 @@ def test_selection_follows_the_measurements():
 
 
 def test_selection_with_several_batches_in_flight():
-    """clx_batch_submit (profiles/r02_bench_configs_sweep_d.txt, columns `sub`): eight runs of the fused lane kernels side by side
-    fill the machine, so they are the choice unless the batches are small and of short codes."""
+    """clx_batch_submit: up to twelve runs of the fused lane kernels go out as one grid, which is ahead of the wave kernels' four in
+    flight at every size measured (profiles/r03_path_sweep.txt; round 2's unmerged runs lost to them on small batches of short codes)."""
     p = dict(pipelined=True)
-    assert choose(2500, 1, 5.67, **p)[0] == "waves"                   # config 2: 0.082 (waves) against 0.109 ms
-    assert choose(10000, 1, 5.67, **p)[0] == "lanes"                  # 0.167 against 0.129
-    assert choose(2500, 2, 5.03, **p)[0] == "waves"                   # config 3: 0.136 against 0.171
-    assert choose(10000, 2, 5.03, **p)[0] == "lanes"                  # 0.303 against 0.230
-    assert choose(1250, 2, 9.8, wide=True, **p)[0] == "lanes"         # config 4: 0.566 against 0.353
-    assert choose(10000, 2, 9.8, wide=True, **p)[0] == "lanes"        # 1.340 against 0.707
-    assert choose(1250, 2, 9.5, **p)[0] == "lanes"                    # config 5: 0.404 against 0.217
-    assert choose(10000, 2, 9.5, **p)[0] == "lanes"                   # 0.779 against 0.307
+    assert choose(600, 1, 5.67, **p)[0] == "lanes"                    # config 2: 0.023 (lanes, merged) against 0.099 ms
+    assert choose(2500, 1, 5.67, **p)[0] == "lanes"                   # 0.025 against 0.110
+    assert choose(10000, 1, 5.67, **p)[0] == "lanes"
+    assert choose(600, 2, 5.03, **p)[0] == "lanes"                    # config 3: 0.038 against 0.137
+    assert choose(2500, 2, 5.03, **p)[0] == "lanes"                   # 0.047 against 0.154
+    assert choose(10000, 2, 5.03, **p)[0] == "lanes"
+    assert choose(1250, 2, 9.8, wide=True, **p)[0] == "lanes"         # config 4
+    assert choose(10000, 2, 9.8, wide=True, **p)[0] == "lanes"
+    assert choose(1250, 2, 9.5, **p)[0] == "lanes"                    # config 5
+    assert choose(10000, 2, 9.5, **p)[0] == "lanes"
 
 
 def test_unknown_frame_lengths_take_the_middle():
