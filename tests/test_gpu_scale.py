@@ -184,8 +184,8 @@ def test_baseline_configs_default_selection(oracle, ctx, make, expect, forbid):
 
 
 def test_pipelined_submissions_of_the_lane_kernels(oracle, ctx):
-    """12 288 config-5 frames with flags 0: one run at a time takes the two-wave lane kernels (test above), pipelined submissions
-    the fused ones, twelve in flight on the library's streams with a set of scratch buffers each (clx_select_path, `pipelined`;
+    """6 144 config-5 frames with flags 0: one run at a time takes the library's choice for a run, pipelined submissions the fused
+    lane kernels, 24 in flight (two merged launches of twelve) with a set of scratch buffers each (clx_select_path, `pipelined`;
     clx_batch_submit_depth) -- with a plain run in between, on the same batch.  All of it against the oracle."""
     import torch
     w = synth.config5_unique(6144)
