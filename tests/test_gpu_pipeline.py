@@ -112,3 +112,34 @@ def test_merged_launch_profiling(setup):
     res = b.results()
     check(w, outs[0], res, ref, r, True)
     b.close()
+
+
+def test_small_batch_choices(setup):
+    """flags 0 on a small batch: one run at a time takes the wave kernels (the lower latency), pipelined submissions the merged lane
+    kernels (round 3: ahead at every size) -- and the lane kernels' plan data, made with the first submission, serves both orders."""
+    import torch
+    ctx, w, descs, d_arena, ref, r = setup
+    b = ctx.plan(descs, w.out_offs, verify_crc=True)
+    assert b.submit_lanes and b.submit_depth == cx.SUBMIT_DEPTH
+    out = torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    b.set_profiling(True)
+    b.run(d_arena.data_ptr(), w.arena_len, out.data_ptr())
+    torch.cuda.synchronize()
+    assert "clx_k_residual" in b.kernel_times()                     # a plain run of this batch: wave kernels
+    b.set_profiling(2)
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(3)]
+    for o in outs:
+        b.submit(d_arena.data_ptr(), w.arena_len, o.data_ptr())
+    b.flush()
+    torch.cuda.synchronize()
+    kt = b.kernel_times()
+    assert "clx_k_residual" not in kt and "clx_k_finalize" in kt, sorted(kt)      # the merged launch: lane kernels
+    res = b.results()
+    for o in outs:
+        check(w, o, res, ref, r, True)
+    b.set_profiling(False)
+    b.run(d_arena.data_ptr(), w.arena_len, out.data_ptr())
+    res = b.results()
+    check(w, out, res, ref, r, True)
+    b.close()
