@@ -1,5 +1,8 @@
 #!/bin/bash
 # A/B of two (or more) builds of the library on one box: tools/gpu_ab.sh "A B" rounds -- bench lines alternate between the builds
+# (a build X is claxon_amd/libclaxon_hip_X.so:  CLAXON_HIP_LIB=$PWD/claxon_amd/libclaxon_hip_X.so CLX_EXTRA_FLAGS="-D..." python -c
+#  "import claxon_amd as cx; cx.build(force=True)"  -- built .so files travel to the GPU box with the snapshot; box-to-box noise is
+#  +-5 % on pipelined steps, so only builds that alternate on ONE box are compared)
 set -u
 cd "$(dirname "$0")/.."
 VARS=${1:-"A B"}; ROUNDS=${2:-3}
