@@ -485,6 +485,27 @@ def lean24_workload(scale=1):
                 fp.sf[c] = S.sf(S.SF_LPC, 32, 15, 3)
             return (L, R), fp
         family(1024, 32, 2, 24, mk_i)
+    # (k) one wave of 24-bit and 16-bit frames side by side (clx_k_lean leaves it for the 24-bit lanes' sake), and (l) one of
+    #     eight-channel frames (independent channels: no partner lanes)
+    for bits in (24, 16):
+        def mk_k(i, bits=bits):
+            (L, R), g = music(i, 1024, bits)
+            fp = S.FrameParams(i % 4, 0, i)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 13)), 12, int(g.integers(0, 4)))
+            return (L, R), fp
+        family(1024, 16, 2, bits, mk_k)
+    def mk_l(i):
+        chans = []
+        g = None
+        for c in range(4):
+            (L, R), g = music(8 * i + c, 512, 24, loud=0.5)
+            chans += [L, R]
+        fp = S.FrameParams(0, 0, i)
+        for c in range(8):
+            fp.sf[c] = S.sf(S.SF_LPC if c % 3 else S.SF_FIXED, int(g.integers(1, 5)) if c % 3 == 0 else int(g.integers(1, 33)), 13, int(g.integers(0, 3)))
+        return chans, fp
+    family(512, 8, 8, 24, mk_l)
     # (j) last: a wave with idle lanes and an odd number of tiles
     def mk_j(i):
         (L, R), g = music(i, 80, 24)
