@@ -51,6 +51,11 @@ def main():
     ap.add_argument("--path", choices=["auto", "waves", "lanes", "lanes-fused", "lanes-general"], default="auto",
                     help="kernel path (default: library's choice); lanes-general = the fused lane build without the 16-bit tier clx_k_lean")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process group backend for the barrier and the MAX / SUM reductions (nccl = RCCL)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="how often the timed region of --steps steps is repeated: `value` is the median region, min / max are carried beside it")
+    ap.add_argument("--devices", default="",
+                    help="comma-separated device index per local rank (default: rank r on device r); `--gpus 2 --devices 0,0 --backend gloo` "
+                         "rehearses the N-rank path -- spawn, process group, barrier, reductions, one line -- on ONE GPU")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no decode: only the launcher, the rank plan and the cross-rank reductions (CPU, gloo); prints a line with value null")
     args = ap.parse_args()
@@ -71,19 +76,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev_index = _device_of(args.devices, local_rank)
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    ctx = cx.Context(local_rank, wait_s=120)   # waits for the device to appear; raises if there is none
-    dev = torch.device("cuda", local_rank)
+    ctx = cx.Context(dev_index, wait_s=120)   # waits for the device to appear; raises if there is none
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    # (gloo reduces host tensors; RCCL device tensors)
+    red_dev = dev if (world == 1 or args.backend == "nccl") else None
 
     # ---- this rank's share of the job's frame index
     t_gen = time.time()
@@ -193,19 +201,27 @@ def main():
     for o in outs:
         o.zero_()
     torch.cuda.synchronize()
-    elapsed_local = elapsed = timed(batch, args.steps, pipelined)
-    # whole-job figures: MAX elapsed over ranks, SUM of samples per step, SUM of failed frames (must be 0)
+    # The timed region -- exactly --steps steps between barrier + synchronize on both sides, MAX over the ranks -- is repeated
+    # --repeats times (a median and a minimum, not one sample): `value` is the MEDIAN region.
+    regions, regions_local = [], []
+    samples_all = w.total_samples
+    for _ in range(max(1, args.repeats)):
+        el_local = timed(batch, args.steps, pipelined)
+        # whole-job figures: MAX elapsed over ranks, SUM of samples per step
+        el, samples_all, _ = shard.reduce_job(dist if world > 1 else None, el_local, w.total_samples, 0, device=red_dev)
+        regions.append(el); regions_local.append(el_local)
     res = batch.results()
     if not outputs_exact(outs[:min(len(outs), args.steps)]):
         raise SystemExit("bench: a timed step did not reproduce the source PCM; refusing to report a number")
-    elapsed, samples_all, n_bad = shard.reduce_job(dist if world > 1 else None, elapsed, w.total_samples,
-                                                   int((res["status"] != 0).sum()), device=dev)
+    _, _, n_bad = shard.reduce_job(dist if world > 1 else None, 0.0, 0, int((res["status"] != 0).sum()), device=red_dev)      # SUM of failed frames (must be 0)
     if n_bad:
         raise SystemExit("bench: %d frames failed to decode in the timed region" % n_bad)
+    elapsed = float(np.median(regions))
+    elapsed_local = float(np.median(regions_local))
     ms_per_step = 1e3 * elapsed / args.steps
     value = samples_all / (ms_per_step * 1e-3) / 1e6
     # every rank's own step time and share (all_gather of three numbers): how even the ranks were
-    per_rank = _gather_floats(dist if world > 1 else None, [1e3 * elapsed_local / args.steps, float(w.algorithmic_bytes), float(w.n)], world, device=dev)
+    per_rank = _gather_floats(dist if world > 1 else None, [1e3 * elapsed_local / args.steps, float(w.algorithmic_bytes), float(w.n)], world, device=red_dev)
     if world > 1:      # algorithmic bytes: max over ranks / mean
         algs = [r[1] for r in per_rank]
         shard_info["imbalance"] = round(max(algs) / (sum(algs) / len(algs)) - 1.0, 5)
@@ -232,6 +248,10 @@ def main():
                                     "note": "one of the path's kernels; the path's bytes over its time alone would overstate it"},
                 "step_achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 "step_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_GBS, 4)}
+    # every rank's own fraction (its algorithmic bytes over its own step time): the line's `frac` is rank 0's share over the job's time
+    fr = [r[1] / (r[0] * 1e-3) / 1e9 / PEAK_GBS for r in per_rank if r[0] > 0]
+    if fr:
+        roofline["per_rank_frac"] = {"min": round(min(fr), 4), "max": round(max(fr), 4)}
     if merged:
         roofline["merged_launch"] = merged
     if prof and prof.get("insts"):
@@ -274,6 +294,8 @@ def main():
            "bit_exact": True, "bit_exact_checked": "every output buffer vs the source PCM before the timed steps, and again -- on buffers cleared in between -- after them",
            "crc16_in_step": bool(with_crc), "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
            "steps_in_flight": depth if pipelined else 1, "distinct_input_copies_in_flight": len(arenas),
+           "merged_launches_per_region": _launch_sizes(args.steps, batch.submit_depth) if (pipelined and batch.submit_lanes) else None,
+           "devices": args.devices or None,
            "value_basis": ("throughput of consecutive steps (one 10 000-frame batch each), up to %d in flight on the library's internal streams; "
                            "config.one_step_at_a_time is a single batch's latency" % depth) if pipelined else "one step at a time",
            "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
@@ -281,13 +303,17 @@ def main():
         "metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "repeats": len(regions), "timed_region_s": round(elapsed, 6),
+        "ms_per_step_min": round(1e3 * min(regions) / args.steps, 4), "ms_per_step_max": round(1e3 * max(regions) / args.steps, 4),
+        "value_min": round(samples_all / (max(regions) / args.steps) / 1e6, 1), "value_max": round(samples_all / (min(regions) / args.steps) / 1e6, 1),
+        "value_basis": "median of `repeats` timed regions of `steps` steps each (every region: barrier + synchronize on both sides, MAX over ranks)",
         "dtype": "i32 (i64 LPC accumulate)", "data": "synthetic", "config": cfg, "roofline": roofline,
     }
 
     if pipelined and not args.no_extras:
         # ---- the same steps one at a time (clx_batch_run: nothing of step i+1 starts before step i has finished)
         el_1 = timed(batch, args.steps, False)
-        el_1, samples_1, _ = shard.reduce_job(dist if world > 1 else None, el_1, w.total_samples, 0, device=dev)
+        el_1, samples_1, _ = shard.reduce_job(dist if world > 1 else None, el_1, w.total_samples, 0, device=red_dev)
         ms_1 = 1e3 * el_1 / args.steps
         cfg["one_step_at_a_time"] = {"value": round(samples_1 / (ms_1 * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_1, 4),
                                      "frac": round(alg_bytes / (ms_1 * 1e-3) / 1e9 / PEAK_GBS, 4),
@@ -303,7 +329,7 @@ def main():
         torch.cuda.synchronize()
         rc = bc.results()
         el_c = timed(bc, args.steps, pipelined)
-        el_c, samples_c, bad_c = shard.reduce_job(dist if world > 1 else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=dev)
+        el_c, samples_c, bad_c = shard.reduce_job(dist if world > 1 else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=red_dev)
         bc.close()
         if bad_c == 0:
             ms_c = 1e3 * el_c / args.steps
@@ -313,13 +339,29 @@ def main():
         cfg["wave_kernels_pipelined"] = _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
     if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
         cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (at N > 1 too, on rank 0's share, behind the timed regions: north_star wants the CPU path timed in the same run at every N;
+        #  the other ranks wait at the end)
         out["cpu_baseline"] = _cpu_baseline(w)
     if rank == 0:
         print(json.dumps(out))
     batch.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _device_of(devices, local_rank):
+    """--devices "0,0": local rank r runs on device devices[r]; default: device r."""
+    if not devices:
+        return local_rank
+    ds = [int(x) for x in devices.split(",") if x.strip() != ""]
+    return ds[local_rank % len(ds)]
+
+
+def _launch_sizes(steps, depth):
+    """How the steps of one timed region go out: the library merges consecutive submissions, depth / 2 per grid (two streams)."""
+    m = max(1, depth // 2)
+    return [m] * (steps // m) + ([steps % m] if steps % m else [])
 
 
 def _rank_share(args, synth, shard, sh_world, sh_rank, generate=True):
@@ -707,10 +749,28 @@ def _pmc_traffic(workload, frames):
         with open(p) as f:
             e = json.load(f).get("%s_frames_%d" % (workload, frames))
         if e:
+            # the counters belong to the kernel sources they were taken with: an entry from other sources is refused, not quoted
+            have = kernel_source_sha16()
+            if e.get("kernel_src_sha16") != have:
+                return None, "STALE: %s was taken with kernel sources %s, these are %s (tools/profile_r04.sh + tools/update_traffic.py renew it)" % (
+                    e.get("source"), e.get("kernel_src_sha16"), have), None
             return e.get("path_bytes"), e.get("source"), e
     except Exception:
         pass
     return None, None, None
+
+
+def kernel_source_sha16():
+    """sha256 over the kernel sources (claxon_amd/csrc/*.hip, *.h, intrin/*.h), first 16 hex digits."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "claxon_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) + glob.glob(os.path.join(base, "intrin", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":

@@ -96,7 +96,7 @@ EXPORTS = [
 
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_lanes.hip", "clx_lean.hip", "clx_device.h", "clx_plan.h",
+    srcs = [os.path.join(_CSRC, f) for f in ("clx_api.hip", "clx_kernels.hip", "clx_lanes.hip", "clx_lean.hip", "clx_device.h", "clx_crct.h", "clx_plan.h",
                                             os.path.join("intrin", "clx_intrin.h"), os.path.join("intrin", "clx_k2_dot2.h"), os.path.join("host", "claxon.hpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "claxon_hip.h"))
     if (not force and os.path.exists(LIB_PATH)

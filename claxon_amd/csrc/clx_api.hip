@@ -17,6 +17,7 @@
 #include <string>
 #include <memory>
 #include <vector>
+#include <unordered_map>
 #include <thread>
 
 #include "clx_plan.h"
@@ -254,7 +255,7 @@ struct clx_batch {
     bool all_narrow_aligned = false;                   // every frame: bps <= 16, rows 16-byte aligned and a multiple of 4 samples long
     clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
     hipEvent_t ev_up = nullptr; bool up_in_flight = false; // recorded behind the staging's H2D copy: the staging is rewritten only after it
-    size_t cap[10] = {};             // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits, d_taken
+    size_t cap[12] = {};             // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits, d_taken, d_crc_part, d_crc_todo
     size_t n = 0;
     uint64_t n_slots = 0;
     uint32_t flags = 0;
@@ -276,6 +277,8 @@ struct clx_batch {
     uint32_t* d_errkey = nullptr;
     uint64_t* d_endbits = nullptr;
     uint32_t* d_taken = nullptr;     // per group of 64 slots: the generation number of the run in which clx_k_lean decoded it
+    clx_crc_part* d_crc_part = nullptr;      // per slot: the lean kernels' lanes' shares of their frames' CRC-16 (tagged with the run's generation number)
+    uint32_t* d_crc_todo = nullptr;  // per frame: clx_k_finalize -> clx_k_crc16_runs
     bool profiling = false, profile_merged = false;
     enum { kMaxKernels = 8 };
     hipEvent_t ev[kMaxKernels + 1] = {};
@@ -295,11 +298,13 @@ struct clx_batch {
         clx_frame_result* d_results = nullptr;
         uint32_t* d_sf_start = nullptr; uint32_t* d_errkey = nullptr; uint64_t* d_endbits = nullptr;   // lane kernels' scratch
         uint32_t* d_taken = nullptr; uint32_t gen = 0;     // groups clx_k_lean took (marked with the run's generation number, never cleared)
+        clx_crc_part* d_crc_part = nullptr; uint32_t* d_crc_todo = nullptr;
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
         hipEvent_t ev_rice = nullptr, ev_side = nullptr;   // Rice stage done | the submission's kernels on side_stream done
         bool side_pending = false, side_recorded = false;
         bool pending = false;                    // submitted, nobody has been made to wait for it yet
         bool sfd_stale = true;                   // d_sfd holds something other than a previous run's descriptors
+        bool scratch_stale = false;              // a launch that used the lane kernels' scratch failed half way: clx_k_finalize may not have left it cleared
         const int32_t* out = nullptr;            // where the pending submission writes
     } flight[kDepth];
     hipStream_t side_stream = nullptr;                 // CRC and left-over predictor kernels of the submissions in flight (launch_waves)
@@ -311,15 +316,21 @@ struct clx_batch {
     // so that the scan stage of one overlaps the decode stage of the other.  Flights are only the runs' scratch buffers here.
     enum { kMerge = CLX_SUBMIT_MERGE, kStreams = CLX_SUBMIT_STREAMS, kMaxStreams = 6 };
     bool merge_tuned = false;
-    int merge = kMerge, n_streams = kStreams;          // (CLX_TUNE_MERGE / CLX_TUNE_STREAMS in the environment override them: tuning only)
+    int merge = kMerge, n_streams = kStreams;          // (builds with -DCLX_TUNING let CLX_TUNE_MERGE / CLX_TUNE_STREAMS override them)
     struct Pending { const uint8_t* arena; size_t arena_len; int32_t* out; int flight; };
     std::vector<Pending> pend;
     hipStream_t pend_stream = nullptr;                 // the caller's stream the pending submissions came in on
     hipStream_t mstream[kMaxStreams] = {};
-    hipEvent_t m_in[kMaxStreams] = {}, m_done[kMaxStreams] = {};
-    bool m_recorded[kMaxStreams] = {}, m_unwaited[kMaxStreams] = {};   // m_done[k] was recorded | nobody has been made to wait for it yet
-    std::vector<const int32_t*> m_outs[kMaxStreams];   // outputs the latest launch on each stream writes
-    int flight_launch_stream[CLX_SUBMIT_DEPTH] = {};   // stream of the merged launch that used a flight's scratch last, -1 none
+    // An event behind each of a stream's last kEvRing launches: a later launch on ANOTHER stream that re-uses an output buffer or a
+    // scratch set waits for exactly the launch that used it last -- not for whatever that stream has been given since (a region of
+    // 20 steps goes out as 12 + 8: waiting for the other stream's LATEST launch would run the two one after the other).
+    enum { kEvRing = 4 };
+    hipEvent_t m_in[kMaxStreams] = {}, m_done[kMaxStreams][kEvRing] = {};
+    uint64_t m_count[kMaxStreams] = {};                // launches made on each stream (launch c's event sits in slot (c - 1) % kEvRing)
+    bool m_unwaited[kMaxStreams] = {};                 // nobody has been made to wait for the stream's latest launch yet
+    struct LaunchRef { int stream; uint64_t count; };
+    std::unordered_map<const int32_t*, LaunchRef> out_writer;   // output buffer -> the merged launch that wrote it last
+    LaunchRef flight_launch[CLX_SUBMIT_DEPTH] = {};    // the merged launch that used a flight's scratch last (count 0: none)
     uint64_t n_merged = 0;
     uint64_t n_submitted = 0;
     int last_slot = -1;              // flight of the most recent pipelined submission (-1: the last run was a plain clx_batch_run)
@@ -372,9 +383,19 @@ extern "C" void clx_destroy(clx_ctx* ctx) {
 
 extern "C" const char* clx_last_error(const clx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
+namespace { int launch_pending(clx_batch* b); }
 extern "C" void clx_batch_destroy(clx_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);      // (by value: a batch destroyed after its context must not look into it)
+    // (accepted submissions that still wait for company go out before the streams are drained below -- the buffers they write
+    //  are the caller's)
+    if (!b->pend.empty()) {
+        clx_ctx scratch_ctx;                   // (the batch's own context may be gone: errors of this launch have nowhere to go)
+        scratch_ctx.device = b->device;
+        b->ctx = &scratch_ctx;
+        (void)launch_pending(b);
+        b->ctx = nullptr;
+    }
     if (b->d_frames) (void)hipFree(b->d_frames);
     if (b->d_sfd) (void)hipFree(b->d_sfd);
     if (b->d_results) (void)hipFree(b->d_results);
@@ -385,12 +406,14 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_errkey) (void)hipFree(b->d_errkey);
     if (b->d_endbits) (void)hipFree(b->d_endbits);
     if (b->d_taken) (void)hipFree(b->d_taken);
+    if (b->d_crc_part) (void)hipFree(b->d_crc_part);
+    if (b->d_crc_todo) (void)hipFree(b->d_crc_todo);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
     for (int k = 0; k < clx_batch::kMaxStreams; ++k) {
         if (b->mstream[k]) { (void)hipStreamSynchronize(b->mstream[k]); (void)hipStreamDestroy(b->mstream[k]); }
         if (b->m_in[k]) (void)hipEventDestroy(b->m_in[k]);
-        if (b->m_done[k]) (void)hipEventDestroy(b->m_done[k]);
+        for (auto& e : b->m_done[k]) if (e) (void)hipEventDestroy(e);
     }
     for (int i = 0; i < clx_batch::kDepth; ++i) {
         clx_batch::Flight& F = b->flight[i];
@@ -405,6 +428,8 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
         if (i != 0 && F.d_errkey) (void)hipFree(F.d_errkey);
         if (i != 0 && F.d_endbits) (void)hipFree(F.d_endbits);
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
+        if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
+        if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
     }
     if (b->ev_up) { (void)hipEventSynchronize(b->ev_up); (void)hipEventDestroy(b->ev_up); }
     if (b->h_up) (void)hipHostFree(b->h_up);
@@ -436,7 +461,10 @@ int plan_lanes_data(clx_batch* b) {
         !grow(ctx, &b->d_errkey, &b->cap[7], nf * sizeof(uint32_t), "hipMalloc errkey") ||
         !grow(ctx, &b->d_endbits, &b->cap[8], nf * sizeof(uint64_t), "hipMalloc endbits") ||
         !grow(ctx, &b->d_taken, &b->cap[9], ((ns + 63) / 64) * sizeof(uint32_t), "hipMalloc taken") ||
+        !grow(ctx, &b->d_crc_part, &b->cap[10], ns * sizeof(clx_crc_part), "hipMalloc crc_part") ||
+        !grow(ctx, &b->d_crc_todo, &b->cap[11], nf * sizeof(uint32_t), "hipMalloc crc_todo") ||
         !hip_ok(ctx, hipMemset(b->d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "memset taken") ||
+        !hip_ok(ctx, hipMemset(b->d_crc_part, 0, ns * sizeof(clx_crc_part)), "memset crc_part") ||
         !hip_ok(ctx, hipMemset(b->d_sf_start, 0xff, ns * sizeof(uint32_t)), "memset sf_start") ||
         !hip_ok(ctx, hipMemset(b->d_errkey, 0xff, nf * sizeof(uint32_t)), "memset errkey") ||
         !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
@@ -446,6 +474,7 @@ int plan_lanes_data(clx_batch* b) {
 }
 // (Re)plan `b` for a list of frames: host-side planning, kernel selection, device buffers (reused when they are large enough).
 int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags);
+int launch_pending(clx_batch* b);
 int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
     const int st = batch_plan_(b, frames, n, out_sample_offsets, flags);
     if (st != CLX_OK) { b->n = 0; b->n_slots = 0; b->n_multi = 0; b->planned_arena_len = (size_t)-1; }      // a failed plan leaves an empty batch, not a half-updated one
@@ -460,6 +489,13 @@ int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint6
 }
 int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
     clx_ctx* ctx = b->ctx;
+    if (!b->pend.empty()) {
+        // submissions that were accepted (CLX_OK) but still wait for company: they go out under the plan they were made for, and
+        // are waited for here -- their scratch is released below
+        if (launch_pending(b) != CLX_OK) return CLX_API_ERROR;
+        for (int k = 0; k < clx_batch::kMaxStreams; ++k)
+            if (b->mstream[k] && !hip_ok(ctx, hipStreamSynchronize(b->mstream[k]), "hipStreamSynchronize")) return CLX_API_ERROR;
+    }
     b->n = n; b->flags = flags;
     b->h_descs.assign(frames, frames + n);
     b->h_frames.resize(n ? n : 1);
@@ -507,16 +543,19 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
         if (i != 0 && F.d_errkey) (void)hipFree(F.d_errkey);
         if (i != 0 && F.d_endbits) (void)hipFree(F.d_endbits);
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
-        F.d_taken = nullptr; F.gen = 0;
+        if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
+        if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
+        F.d_taken = nullptr; F.gen = 0; F.d_crc_part = nullptr; F.d_crc_todo = nullptr;
         if (i == 0) F.d_results = nullptr;
-        F.d_sfd = nullptr; F.d_results = nullptr; F.d_sf_start = nullptr; F.d_errkey = nullptr; F.d_endbits = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.out = nullptr;   // (side_recorded stays: the event is still there)
+        F.d_sfd = nullptr; F.d_results = nullptr; F.d_sf_start = nullptr; F.d_errkey = nullptr; F.d_endbits = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.scratch_stale = false; F.out = nullptr;   // (side_recorded stays: the event is still there)
     }
     b->last_slot = -1;
     b->planned_arena_len = (size_t)-1;
     b->ev_valid = false;
     b->pend.clear();
-    for (int k = 0; k < clx_batch::kMaxStreams; ++k) { b->m_unwaited[k] = false; b->m_outs[k].clear(); }
-    for (int& f : b->flight_launch_stream) f = -1;
+    for (int k = 0; k < clx_batch::kMaxStreams; ++k) b->m_unwaited[k] = false;
+    b->out_writer.clear();
+    for (auto& f : b->flight_launch) f = clx_batch::LaunchRef{ 0, 0 };
     return CLX_OK;
 }
 }  // namespace
@@ -530,13 +569,16 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
     clx_batch* b = new (std::nothrow) clx_batch();
     if (!b) return CLX_API_ERROR;
     b->ctx = ctx; b->device = ctx->device;
-    {   // tuning knobs (measurement only; the defaults are compiled in): runs per merged launch, internal streams
+#ifdef CLX_TUNING
+    {   // tuning knobs of the measurement builds (-DCLX_TUNING: tools/gpu_ab_sat.sh, tools/merge_sweep.sh); the product build reads
+        // no environment variable: runs per merged launch, internal streams
         const char* em = std::getenv("CLX_TUNE_MERGE"); const char* es = std::getenv("CLX_TUNE_STREAMS");
         const int m = em ? std::atoi(em) : 0, st = es ? std::atoi(es) : 0;
         if (m >= 1 && m <= CLX_MAX_MERGE) { b->merge = m; b->merge_tuned = true; }
         if (st >= 1 && st <= clx_batch::kMaxStreams) b->n_streams = st;
         if (b->merge * b->n_streams > clx_batch::kDepthLanes) b->n_streams = std::max(1, clx_batch::kDepthLanes / b->merge);
     }
+#endif
     if (batch_plan(b, frames, n, out_sample_offsets, flags) != CLX_OK) { clx_batch_destroy(b); return CLX_API_ERROR; }
     *out = b;
     return CLX_OK;
@@ -649,14 +691,20 @@ clx_run make_run(const clx_batch* b, const clx_batch::Flight& F, const uint8_t* 
     R.arena = d_arena; R.alloc_len = (((uint64_t)arena_len + 15ull) & ~15ull) + 16ull;      // claxon_hip.h: the allocation covers this
     R.out = d_out; R.sf_start = F.d_sf_start; R.errkey = F.d_errkey; R.end_bits = F.d_endbits;
     R.taken = (lean && !(b->flags & CLX_LANES_GENERAL)) ? F.d_taken : nullptr;
-    R.results = F.d_results; R.gen = F.gen; R.pad = 0;
+    R.results = F.d_results; R.gen = F.gen;
+    R.crc_part = F.d_crc_part; R.crc_todo = F.d_crc_todo;
+    R.flags = (b->flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u;
     return R;
 }
 void launch_stage1_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
                          hipStream_t stream) {
     // CLX_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer K1 waves per CU -- the measurement knob behind DESIGN.md's
     // "lower occupancy is strictly worse" (32 -> 16 waves per CU: 0.28 -> 0.39 ms); not used otherwise
+#ifdef CLX_TUNING
     static const unsigned k1_pad = [] { const char* e = std::getenv("CLX_K1_LDS_PAD"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
+#else
+    const unsigned k1_pad = 0u;
+#endif
     hipLaunchKernelGGL(clx_k_residual, dim3((unsigned)b->n), dim3(64), k1_pad, stream,
                        d_arena, alloc_len, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, d_out, d_sfd, d_results);
 }
@@ -724,34 +772,58 @@ int launch_pending(clx_batch* b) {
     if (!b->mstream[k]) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&b->mstream[k], hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&b->m_in[k], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&b->m_done[k], hipEventDisableTiming));
+        for (auto& e : b->m_done[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     hipStream_t ms = b->mstream[k];
     // behind everything queued so far on the stream the submissions came in on (their inputs)
     HIP_TRY(ctx, hipEventRecord(b->m_in[k], b->pend_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ms, b->m_in[k], 0));
-    // (this stream's previous launch is ahead of this one in the stream) the latest launch on ANOTHER stream must be waited for when
-    // it writes an output buffer this launch writes, or used a scratch set this launch uses (only after partial launches: flights
-    // are handed out in rotation, `merge` at a time, and merge * n_streams of them make a full round)
-    for (int j = 0; j < b->n_streams; ++j) {
-        if (j == k || !b->m_recorded[j]) continue;
-        bool other = false;
+    // (this stream's earlier launches are ahead of this one in the stream) a launch on ANOTHER stream must be waited for when it was
+    // the last one to write one of this launch's output buffers -- however many launches ago -- or to use a scratch set this launch
+    // uses (only after partial launches: flights are handed out in rotation, `merge` at a time, and merge * n_streams of them make
+    // a full round)
+    {
+        uint64_t need[clx_batch::kMaxStreams] = {};      // per stream: the latest of its launches this one depends on
         for (const auto& P : b->pend) {
-            if (b->flight_launch_stream[P.flight] == j) other = true;
-            for (const int32_t* o : b->m_outs[j]) if (o == P.out) other = true;
+            const clx_batch::LaunchRef fl = b->flight_launch[P.flight];
+            if (fl.count && fl.stream != k) need[fl.stream] = std::max(need[fl.stream], fl.count);
+            const auto it = b->out_writer.find(P.out);
+            if (it != b->out_writer.end() && it->second.stream != k) need[it->second.stream] = std::max(need[it->second.stream], it->second.count);
         }
-        if (other) HIP_TRY(ctx, hipStreamWaitEvent(ms, b->m_done[j], 0));
+        for (int j = 0; j < clx_batch::kMaxStreams; ++j) {
+            if (!need[j]) continue;
+            // (an event that has been recorded again since stands for a later launch of the same stream: still correct)
+            const uint64_t c = b->m_count[j] - need[j] < (uint64_t)clx_batch::kEvRing ? need[j] : b->m_count[j];
+            HIP_TRY(ctx, hipStreamWaitEvent(ms, b->m_done[j][(c - 1) % clx_batch::kEvRing], 0));
+        }
+    }
+    // (the staging upload of the plan went out on whichever caller stream made that submission)
+    if (b->up_in_flight) HIP_TRY(ctx, hipStreamWaitEvent(ms, b->ev_up, 0));
+    if (b->out_writer.size() > 4096u) {        // (a caller that never re-uses a buffer: forget the old ones behind a full ordering point)
+        for (int a = 0; a < clx_batch::kMaxStreams; ++a)
+            for (int j = 0; j < clx_batch::kMaxStreams; ++j)
+                if (a != j && b->mstream[a] && b->m_count[j])
+                    HIP_TRY(ctx, hipStreamWaitEvent(b->mstream[a], b->m_done[j][(b->m_count[j] - 1) % clx_batch::kEvRing], 0));
+        b->out_writer.clear();
     }
     clx_runs runs;
     std::memset(&runs, 0, sizeof runs);
-    b->m_outs[k].clear();
     unsigned n_runs = 0;
     for (const auto& P : b->pend) {
         clx_batch::Flight& F = b->flight[P.flight];
-        if (++F.gen == 0u) { HIP_TRY(ctx, hipMemsetAsync(F.d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), ms)); F.gen = 1u; }
+        if (++F.gen == 0u) {       // (the generation number wrapped: nothing stale may look current)
+            HIP_TRY(ctx, hipMemsetAsync(F.d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), ms));
+            HIP_TRY(ctx, hipMemsetAsync(F.d_crc_part, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_crc_part), ms));
+            F.gen = 1u;
+        }
+        if (F.scratch_stale) {     // (clx_k_finalize leaves the scratch cleared behind every run that gets that far)
+            HIP_TRY(ctx, hipMemsetAsync(F.d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), ms));
+            HIP_TRY(ctx, hipMemsetAsync(F.d_errkey, 0xff, std::max<size_t>(b->n, 1) * sizeof(uint32_t), ms));
+            F.scratch_stale = false;
+        }
         runs.r[n_runs++] = make_run(b, F, P.arena, P.arena_len, P.out, true);
-        b->m_outs[k].push_back(P.out);
-        b->flight_launch_stream[P.flight] = k;
+        b->out_writer[P.out] = clx_batch::LaunchRef{ k, b->m_count[k] + 1 };
+        b->flight_launch[P.flight] = clx_batch::LaunchRef{ k, b->m_count[k] + 1 };
     }
     int nk = 0;
     auto mark = [&](const char* name) -> bool {          // (clx_batch_set_profiling(b, 2): an event in front of each kernel, one behind the last)
@@ -759,20 +831,27 @@ int launch_pending(clx_batch* b) {
         if (name) b->kname[nk] = name;
         return hip_ok(ctx, hipEventRecord(b->ev[nk++], ms), "hipEventRecord");
     };
-    if (!launch_lanes(b, runs, n_runs, false, ms, mark)) return CLX_API_ERROR;
+    const bool launched = launch_lanes(b, runs, n_runs, false, ms, mark) && hipGetLastError() == hipSuccess;
+    if (!launched) {
+        // what went out of it has used the flights' scratch and may never reach clx_k_finalize: cleared again before the next use
+        for (const auto& P : b->pend) b->flight[P.flight].scratch_stale = true;
+        b->pend.clear();
+        ctx->last_error = "a merged launch of the lane kernels failed";
+        return CLX_API_ERROR;
+    }
     if (b->profile_merged) { if (!mark(nullptr)) return CLX_API_ERROR; b->n_kernels = nk - 1; b->ev_valid = true; b->ev_runs = (int)n_runs; }
-    HIP_TRY(ctx, hipEventRecord(b->m_done[k], ms));
-    b->m_recorded[k] = true; b->m_unwaited[k] = true;
+    ++b->m_count[k];
+    HIP_TRY(ctx, hipEventRecord(b->m_done[k][(b->m_count[k] - 1) % clx_batch::kEvRing], ms));
+    b->m_unwaited[k] = true;
     b->pend.clear();
     ++b->n_merged;
-    HIP_TRY(ctx, hipGetLastError());
     return CLX_OK;
 }
 // make `stream` wait for every pipelined submission that nobody has waited for yet (what is pending is launched first)
 int wait_flights(clx_batch* b, hipStream_t stream) {
     if (launch_pending(b) != CLX_OK) return CLX_API_ERROR;
     for (int k = 0; k < clx_batch::kMaxStreams; ++k)
-        if (b->m_unwaited[k]) { HIP_TRY(b->ctx, hipStreamWaitEvent(stream, b->m_done[k], 0)); b->m_unwaited[k] = false; }
+        if (b->m_unwaited[k]) { HIP_TRY(b->ctx, hipStreamWaitEvent(stream, b->m_done[k][(b->m_count[k] - 1) % clx_batch::kEvRing], 0)); b->m_unwaited[k] = false; }
     for (auto& F : b->flight)
         if (F.pending) {
             HIP_TRY(b->ctx, hipStreamWaitEvent(stream, F.ev_done, 0));
@@ -811,11 +890,25 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         const bool split = (b->flags & CLX_LANES_SPLIT) ? true : (b->flags & CLX_LANES_FUSED) ? false : b->choice.lanes_split;
         clx_batch::Flight& F0 = b->flight[0];
         F0.d_results = b->d_results; F0.d_sf_start = b->d_sf_start; F0.d_errkey = b->d_errkey; F0.d_endbits = b->d_endbits; F0.d_taken = b->d_taken;
-        if (++F0.gen == 0u) { HIP_TRY(ctx, hipMemsetAsync(b->d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), stream)); F0.gen = 1u; }
+        F0.d_crc_part = b->d_crc_part; F0.d_crc_todo = b->d_crc_todo;
+        if (++F0.gen == 0u) {
+            HIP_TRY(ctx, hipMemsetAsync(b->d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), stream));
+            HIP_TRY(ctx, hipMemsetAsync(b->d_crc_part, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_crc_part), stream));
+            F0.gen = 1u;
+        }
+        if (F0.scratch_stale) {
+            HIP_TRY(ctx, hipMemsetAsync(b->d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream));
+            HIP_TRY(ctx, hipMemsetAsync(b->d_errkey, 0xff, std::max<size_t>(b->n, 1) * sizeof(uint32_t), stream));
+            F0.scratch_stale = false;
+        }
         clx_runs runs;
         std::memset(&runs, 0, sizeof runs);
         runs.r[0] = make_run(b, F0, d_arena, arena_len, d_out, !split);
-        if (!launch_lanes(b, runs, 1u, split, stream, mark)) return CLX_API_ERROR;
+        if (!launch_lanes(b, runs, 1u, split, stream, mark) || hipGetLastError() != hipSuccess) {
+            F0.scratch_stale = true;
+            ctx->last_error = "a launch of the lane kernels failed";
+            return CLX_API_ERROR;
+        }
     } else {
         // (K1 writes every slot of every frame on every run; the slots that only pad a stereo pair to an even index are cleared once)
         clx_batch::Flight& F0 = b->flight[0];
@@ -870,7 +963,8 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         if (b->flags & CLX_PATH_LANES) { ctx->last_error = "CLX_PATH_LANES needs arena_len < 4 GiB"; return CLX_API_ERROR; }
         want_lanes = false;
     }
-    const int depth = clx_batch_submit_depth(b);
+    // (a batch that only defaulted to the lane kernels and cannot use them on this arena runs the wave kernels, with THEIR depth)
+    const int depth = (!want_lanes && submit_wants_lanes(b)) ? ((b->flags & CLX_K2_THROUGHPUT) ? 1 : (int)clx_batch::kDepthWaves) : clx_batch_submit_depth(b);
     if (depth <= 1) return clx_batch_run(b, d_arena, arena_len, d_out, stream_);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
@@ -885,8 +979,12 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         // ---- fused lane kernels: the submission joins the pending ones; kMerge of them go out as one launch (launch_pending)
         if (plan_lanes_data(b) != CLX_OK) return CLX_API_ERROR;       // (with the batch's first pipelined submission when no run needed it)
         if (!F.d_sf_start) {
-            if (slot == 0) { F.d_sf_start = b->d_sf_start; F.d_errkey = b->d_errkey; F.d_endbits = b->d_endbits; F.d_taken = b->d_taken; }
+            if (slot == 0) { F.d_sf_start = b->d_sf_start; F.d_errkey = b->d_errkey; F.d_endbits = b->d_endbits; F.d_taken = b->d_taken;
+                             F.d_crc_part = b->d_crc_part; F.d_crc_todo = b->d_crc_todo; }
             else {
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_crc_part, ns * sizeof(clx_crc_part)));
+                HIP_TRY(ctx, hipMalloc((void**)&F.d_crc_todo, nf * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMemset(F.d_crc_part, 0, ns * sizeof(clx_crc_part)));
                 HIP_TRY(ctx, hipMalloc((void**)&F.d_sf_start, ns * sizeof(uint32_t)));
                 HIP_TRY(ctx, hipMalloc((void**)&F.d_errkey, nf * sizeof(uint32_t)));
                 HIP_TRY(ctx, hipMalloc((void**)&F.d_endbits, nf * sizeof(uint64_t)));

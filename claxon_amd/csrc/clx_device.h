@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include "clx_crct.h"
+
 struct clx_dev_frame {
     uint64_t byte_off;       // frame start (sync code) in the arena
     uint64_t out_off;        // sample index of channel 0 in `out`
@@ -58,13 +60,16 @@ struct clx_run {
     uint64_t* end_bits;      // scratch: end bit per frame
     uint32_t* taken;         // per group of 64 slots: == gen when clx_k_lean decoded the group in this run
     clx_frame_result* results;
+    clx_crc_part* crc_part;  // scratch, per predictor slot: what the lean kernels' lanes found of their frame's CRC-16 (clx_crct.h)
+    uint32_t* crc_todo;      // scratch, per frame: clx_k_finalize -> clx_k_crc16_runs: 1 = the stand-alone kernel has to check this frame
     uint32_t gen;
-    uint32_t pad;
+    uint32_t flags;          // CLX_RUN_CRC: the frames' CRC-16 is verified (the decode lanes gather it, clx_k_finalize judges it)
 };
+#define CLX_RUN_CRC 1u
 struct clx_runs { clx_run r[CLX_MAX_MERGE]; };       // passed to the kernels by value
 
 #ifdef __cplusplus
-static_assert(sizeof(clx_run) == 72, "clx_run layout");
+static_assert(sizeof(clx_run) == 88, "clx_run layout");
 static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
 static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
 // K1 writes the 16 bytes in front of `coef` as one store: {out_base | n, lim_log2, flags | order, shift, wasted, decor}

@@ -1411,8 +1411,10 @@ __constant__ K3Rom clx_k3_rom = clx_make_k3_rom();
 // are taken in rounds of 1 KiB that END at the frame's end -- lane L the 16 bytes [1024 r + 16 L, +16) of the round -- so the
 // first round starts in front of the frame: those bytes count as zeros, which a CRC with initial value 0 does not see
 // (crc.rs:109-112).  Every position then has a multiplier that does not depend on the frame's length.
+// `todo` (lane path): which frames are still to be checked -- the lean kernels' lanes gather the CRC of the frames they decode
+// themselves (clx_crct.h), clx_k_finalize has judged those.
 __device__ __forceinline__ void clx_crc16_frames(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
-                                                 clx_frame_result* __restrict__ results) {
+                                                 clx_frame_result* __restrict__ results, const uint32_t* __restrict__ todo) {
     __shared__ K3Rom T;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&clx_k3_rom);
@@ -1423,6 +1425,7 @@ __device__ __forceinline__ void clx_crc16_frames(const uint8_t* __restrict__ are
     const int lane = (int)threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, n_waves = gridDim.x * 4u;
     for (uint32_t f = blockIdx.x * 4u + wave; f < n_frames; f += n_waves) {
+        if (todo != nullptr && todo[f] == 0u) continue;                      // wave-uniform
         const clx_dev_frame fr = frames[f];
         const clx_frame_result r = results[f];
         if (r.status != CLX_OK || (fr.flags & 1u)) continue;                 // wave-uniform
@@ -1476,13 +1479,13 @@ __device__ __forceinline__ void clx_crc16_frames(const uint8_t* __restrict__ are
 extern "C" __global__ __launch_bounds__(256)
 void clx_k_crc16(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
                  clx_frame_result* __restrict__ results) {
-    clx_crc16_frames(arena, frames, n_frames, results);
+    clx_crc16_frames(arena, frames, n_frames, results, nullptr);
 }
 // the same for the runs of a merged lane-path launch (blockIdx.y picks the run)
 extern "C" __global__ __launch_bounds__(256)
 void clx_k_crc16_runs(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_frames) {
     const clx_run& R = runs.r[blockIdx.y];
-    clx_crc16_frames(R.arena, frames, n_frames, R.results);
+    clx_crc16_frames(R.arena, frames, n_frames, R.results, (R.flags & CLX_RUN_CRC) ? R.crc_todo : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1507,6 +1507,34 @@ void clx_k_finalize(const clx_runs runs, const clx_dev_frame* __restrict__ frame
         }
     }
     else { r.status = (int32_t)((key >> 16) & 0xffu); r.msg = key & 0xffffu; r.end_bit = 0; }
+    // the frame's CRC-16 (frame.rs:752-763) from what the lean kernels' lanes gathered of it (clx_crct.h): every subframe's lane has
+    // left its share's remainder for THIS run, the shares tile the frame, and the frame ends where its descriptor says -- otherwise
+    // (a group the general kernels decoded, a descriptor that only bounds the frame) clx_k_crc16_runs checks the frame
+    if (R.flags & CLX_RUN_CRC) {
+        uint32_t todo = 0u;
+        if (r.status == CLX_OK && !(fr.flags & 1u)) {
+            todo = 1u;
+            if (((r.end_bit + 7ull) & ~7ull) + 16ull == (uint64_t)fr.limit_bits) {
+                bool all = true;
+                uint32_t sum = 0u, par = 0u, at = 0u;
+                const uint32_t nch = fr.n_channels;
+                const uint32_t dend = R.crc_part[fr.first_slot + nch - 1u].db;
+                for (uint32_t c = 0; c < nch; ++c) {
+                    const clx_crc_part p = R.crc_part[fr.first_slot + c];
+                    all = all && p.gen == R.gen && p.da == at && p.db >= p.da && p.db <= dend;
+                    if (!all) break;
+                    at = p.db;
+                    sum ^= clx_crct_shift(p.rx & 0x7fffu, dend - p.db);
+                    par ^= p.rx >> 31;
+                }
+                if (all) {
+                    todo = 0u;
+                    if (sum != 0u || par != 0u) { r.status = CLX_FORMAT_ERROR; r.msg = CLX_MSG_FRAME_CRC_MISMATCH; }
+                }
+            }
+        }
+        R.crc_todo[f] = todo;
+    }
     R.results[f] = r;
     // leave the run's scratch as the next run expects to find it (nothing else reads it after this kernel): no error yet, no later
     // subframe located yet -- the host clears it once, when it is allocated

@@ -53,22 +53,70 @@ struct LRing {
     uint32_t np;            // granules requested at the last pump (0..3), in pa / pb / pc
     uint4 pa, pb, pc;
 };
-__device__ __forceinline__ void cln_put(uint32_t* row, uint32_t s, const uint4 v) {
+// ---- the frame's CRC-16, gathered by the decode lanes from the words they put into their rings anyway (clx_crct.h: the frame's
+// polynomial modulo x^15 + x + 1 and its parity, eight cheap instructions per word, no table).  A lane's share is the words
+// [da, db) of its frame -- from the granule in which its subframe starts to the granule in which the next one does; the first
+// channel's from the frame's first granule, the last channel's to the frame's end -- so that the shares of a frame's lanes tile
+// the frame.  Granules are taken in order, each once: `next` is the word the share has been taken up to.  What does not come
+// through the ring (the prologue's bytes, what a slow turn walked over, the end of the share) is fetched again (cln_crc_catchup).
+#define CLN_CRC_NONE 0xfffffff0u
+struct LCrc {
+    clx_crct c;
+    uint32_t next;          // [da, next) has been taken (a multiple of 4)
+    uint32_t db;            // the end of the share (a multiple of 4: whole granules); CLN_CRC_NONE: the lane gathers nothing that is kept
+};
+__device__ __forceinline__ void cln_crc_take(LCrc& C, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+    clx_crct_word(C.c, b0); clx_crct_word(C.c, b1); clx_crct_word(C.c, b2); clx_crct_word(C.c, b3);
+}
+// the granules [next, upto) straight from the arena
+__device__ __forceinline__ void cln_crc_catchup(const clx_buf& buf, uint32_t origin, LCrc& C, uint32_t upto) {
+#pragma unroll 1
+    while (C.next < upto) {
+        const uint4 v = clx_buf_load16(buf, origin + 4u * C.next);
+        cln_crc_take(C, __builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+        C.next += 4u;
+    }
+}
+// one granule of which only the bytes [lo, hi) count (the frame's first and last granule: its neighbours' bytes read as zeros)
+__device__ __forceinline__ void cln_crc_take_masked(LCrc& C, const uint4 v, uint32_t lo, uint32_t hi) {
+    const uint32_t w[4] = { __builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w) };
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        // bytes 4j .. 4j+3 of the granule are the word's bytes from the top down
+        const uint32_t a = lo > 4u * j ? (lo - 4u * j < 4u ? lo - 4u * j : 4u) : 0u;        // leading bytes to drop
+        const uint32_t b = hi > 4u * j ? (hi - 4u * j < 4u ? hi - 4u * j : 4u) : 0u;        // bytes up to which to keep
+        const uint32_t ma = a >= 4u ? 0u : 0xffffffffu >> (8u * a);
+        const uint32_t mb = b >= 4u ? 0xffffffffu : ~(0xffffffffu >> (8u * b));
+        clx_crct_word(C.c, w[j] & ma & mb);
+    }
+}
+// mode: 0 no CRC; 1 the granule is the share's next one and lies inside it (the wave has checked that for all that land this turn);
+// 2 ask per granule.  f: the granule's first word.
+__device__ __forceinline__ void cln_put(uint32_t* row, uint32_t s, const uint4 v, LCrc& C, uint32_t f, int mode) {
     const uint32_t b0 = __builtin_bswap32(v.x), b1 = __builtin_bswap32(v.y), b2 = __builtin_bswap32(v.z), b3 = __builtin_bswap32(v.w);
     CLN_AT(row, s) = b0; CLN_AT(row, s + 1u) = b1; CLN_AT(row, s + 2u) = b2; CLN_AT(row, s + 3u) = b3;
     if (s == 0u) { CLN_AT(row, CLN_RING) = b0; CLN_AT(row, CLN_RING + 1u) = b1; CLN_AT(row, CLN_RING + 2u) = b2; CLN_AT(row, CLN_RING + 3u) = b3; }
+    if (mode == 1) cln_crc_take(C, b0, b1, b2, b3);
+    else if (mode == 2) {
+        if (f == C.next && f + 4u <= C.db) { cln_crc_take(C, b0, b1, b2, b3); C.next = f + 4u; }
+    }
 }
 // synchronous fill from the granule that holds dword `d` (the start of the steady state, and after a slow turn)
-__device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t* row, uint32_t d) {
+__device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t* row, uint32_t d, LCrc& C, bool crc) {
     const uint32_t f0 = d & ~3u;
     const uint32_t s0 = f0 % CLN_RING;
+    if (crc) {
+        // what lies between the share's taken part and the ring's new start never comes through the ring
+        if (C.db == CLN_CRC_NONE) C.next = f0;
+        else cln_crc_catchup(buf, g.origin, C, f0 < C.db ? f0 : C.db);
+    }
 #pragma unroll
     for (uint32_t h = 0; h < CLN_RING / 4u; h += 3u) {          // three granules at a time: the loads' registers are short-lived
         uint4 t[3];
 #pragma unroll
         for (uint32_t q = 0; q < 3u; ++q) if (h + q < CLN_RING / 4u) t[q] = clx_buf_load16(buf, g.origin + 4u * (f0 + 4u * (h + q)));
 #pragma unroll
-        for (uint32_t q = 0; q < 3u; ++q) if (h + q < CLN_RING / 4u) cln_put(row, cln_wrap(s0 + 4u * (h + q)), t[q]);
+        for (uint32_t q = 0; q < 3u; ++q) if (h + q < CLN_RING / 4u) cln_put(row, cln_wrap(s0 + 4u * (h + q)), t[q], C, f0 + 4u * (h + q), crc ? 2 : 0);
     }
     g.fill = f0 + CLN_RING; g.fs = s0; g.np = 0;
 }
@@ -78,10 +126,13 @@ __device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t
 // the turn's tile stores included, which are issued right in front of it.  Landing in front of the stores instead, when all that is
 // in flight is a whole turn old, makes one run alone 4 % faster and a saturated machine 9 % slower (one merged launch of nine runs:
 // 1.27 -> 1.39 ms; tools/gpu_ab_sat.sh): the wait is what paces the waves' stores.)
-__device__ __forceinline__ void cln_land(LRing& g, uint32_t* row) {
-    if (g.np >= 1u) { cln_put(row, g.fs, g.pa); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
-    if (g.np >= 2u) { cln_put(row, g.fs, g.pb); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
-    if (g.np >= 3u) { cln_put(row, g.fs, g.pc); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+__device__ __forceinline__ void cln_land(LRing& g, uint32_t* row, LCrc& C, bool crc) {
+    // (one vote per turn instead of a question per granule: up to three granules land, all of them the shares' next ones)
+    const int mode = !crc ? 0 : __all(C.next == g.fill && g.fill + 12u <= C.db) ? 1 : 2;
+    if (g.np >= 1u) { cln_put(row, g.fs, g.pa, C, g.fill, mode); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    if (g.np >= 2u) { cln_put(row, g.fs, g.pb, C, g.fill, mode); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    if (g.np >= 3u) { cln_put(row, g.fs, g.pc, C, g.fill, mode); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    if (mode == 1) C.next = g.fill;
     g.np = 0;
 }
 __device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32_t p) {
@@ -251,6 +302,8 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
     const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
     LRing g;
     g.origin = r.origin; g.fill = 0; g.fs = 0; g.np = 0; g.pa = make_uint4(0u, 0u, 0u, 0u); g.pb = g.pa; g.pc = g.pa;
+    LCrc NC;                                             // (the scan gathers no CRC: the decode lanes read the same bytes again)
+    NC.c.r = 0u; NC.c.x = 0u; NC.next = 0u; NC.db = CLN_CRC_NONE;
     LKind KR;                                            // (the careful reader's view: every lane skips Rice codes)
     KR.rice = true; KR.verb = false; KR.bitmask = 0xffffffffu; KR.ricemask = 0xffffffffu; KR.verbmask = 0u; KR.cor = 0u; KR.vsh = 0u; KR.vshm = 0u;
     const uint32_t bs = fr.block_size;
@@ -314,15 +367,15 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
             const bool has = left >= 16u && !r.err;          // this lane has sixteen codes to skip
             const bool live = has && ring_able;
             const LCur keep = cur;                           // (a lane without them rides along where it is: its ring stays consistent)
-            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
-            else { cln_land(g, row); cln_request(buf, g, cur.p); }
+            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); ring_ok = true; }
+            else { cln_land(g, row, NC, false); cln_request(buf, g, cur.p); }
             int done = 0;
             bool refilled = false;
             if (__all(live || !has)) {
               again:
                 if (clx_any(live && cur.pcnt < 16u)) done = cln_scan_turn<true>(row, g, cur, per, rice2, r.limit, live);
                 else                                 done = cln_scan_turn<false>(row, g, cur, per, rice2, r.limit, live);
-                if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; goto again; }
+                if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); refilled = true; goto again; }
             }
             if (!has) cur = keep;                            // (its tail is still to come: nothing of the ride may stick)
             if (done > 0) { if (has) left -= 16u; continue; }
@@ -646,7 +699,8 @@ template <int NP>
 __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, uint32_t (&H)[2 * NP],
                                          const uint32_t (&C)[NP], const int32_t (&CW)[2 * NP], uint32_t order, uint32_t shift, int32_t lim, int32_t lim24,
                                          uint32_t per, uint32_t rice2,
-                                         uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane) {
+                                         uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane,
+                                         LCrc& CR, bool crc) {
 
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;      // (eight neighbouring lanes' 16-byte stage stores then cover all 32 banks)
     bool slow = true;                                    // H holds i32 samples (the prologue leaves them so)
@@ -667,8 +721,8 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
                 slow = false;
             }
         }
-        if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
-        else { cln_land(g, row); cln_request(buf, g, cur.p); }
+        if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
+        else { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p); }
         const bool was_slow = slow;                      // (no lean turn is tried: the history does not fit the packed form)
         int done = 0;
         bool refilled = false;                           // the ring was refilled on the spot once in this turn (a lane outran it)
@@ -685,7 +739,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
                 CLX_STAT(50, 1);
                 continue;
             }
-            if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; CLX_STAT(59, 1); goto again_lean; }
+            if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); refilled = true; CLX_STAT(59, 1); goto again_lean; }
             // not this way: the turn is taken again from where it started, on the unpacked history (sign-extended halves)
             uint32_t U[2 * NP];
 #pragma unroll
@@ -710,7 +764,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
                     CLX_STAT(58, 1);
                     continue;
                 }
-                if (dw == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; CLX_STAT(59, 1); goto again_wide; }
+                if (dw == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); refilled = true; CLX_STAT(59, 1); goto again_wide; }
             }
         }
         CLX_STAT(51, 1);
@@ -740,7 +794,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
 // LPC / fixed parameters of a lane after the prologue, in the lean kernel's form
 template <int NP>
 __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LRing& g, uint32_t* row, int4* stage, uint32_t n, uint32_t i0, uint32_t nmax,
-                                        const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane) {
+                                        const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane, LCrc& CR, bool crc) {
     uint32_t C[NP], H[2 * NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) C[q] = ((uint32_t)S.c[2 * q] << 16) | ((uint32_t)S.c[2 * q + 1] & 0xffffu);
@@ -760,7 +814,7 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     // the 24-bit evaluation's range (clx_ltransition), under the same cap for subframes without taps
     const int32_t lim24a = S.order == 0u ? (1 << 29) : S.lim;
     const int32_t lim24 = lim24a < cap ? lim24a : cap;
-    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, CW, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane);
+    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, CW, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
 }
@@ -790,7 +844,8 @@ __device__ __forceinline__ void cln_unpack12(const uint32_t (&H)[2 * (2 * NP - 1
 template <int NP, int OMAX>
 __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, const int32_t (&hist0)[OMAX],
                                            const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2,
-                                           uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane) {
+                                           uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane,
+                                           LCrc& CR, bool crc) {
     constexpr int NH = 2 * NP - 1;
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
     const uint32_t e1 = shift <= 12u ? 12u - shift : 0u, e2 = shift <= 12u ? shift : 12u, e3 = shift <= 12u ? 0u : shift - 12u;
@@ -813,8 +868,8 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         const bool live = n != 0u && !r.err;
         cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
         int4* const mine = cln_mine(stage, t0, lane);
-        if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); ring_ok = true; }
-        else { cln_land(g, row); cln_request(buf, g, cur.p); }
+        if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
+        else { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p); }
         {
             bool refilled = false;
           again:
@@ -824,7 +879,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
                 CLX_STAT(9, 1);
                 continue;
             }
-            if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5); refilled = true; CLX_STAT(12, 1); goto again; }
+            if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); refilled = true; CLX_STAT(12, 1); goto again; }
         }
         CLX_STAT(10, 1);
         if (++nslow > CLN_SLOW_BUDGET && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // (wave-uniform; not when the end is near anyway)
@@ -859,7 +914,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
 
 template <int NP, int OMAX>
 __device__ __forceinline__ bool cln_run24(const clx_buf& buf, LaneState<OMAX>& S, LRing& g, uint32_t* row, int4* stage, uint32_t n, uint32_t i0, uint32_t nmax,
-                                          const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane) {
+                                          const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane, LCrc& CR, bool crc) {
     static_assert(2 * NP <= OMAX, "taps");
     uint32_t C[NP];
 #pragma unroll
@@ -872,7 +927,7 @@ __device__ __forceinline__ bool cln_run24(const clx_buf& buf, LaneState<OMAX>& S
     const int32_t cap = (1 << 29) >> (int)F.wasted;
     const int32_t lim0 = S.order == 0u ? (1 << 29) : S.lim > (1 << 15) ? (1 << 27) : (int32_t)((uint32_t)(S.lim - 1) << 12);
     const int32_t lim = lim0 < cap ? lim0 : cap;
-    const bool done = cln_body24<NP, OMAX>(buf, S.r, g, row, stage, cur, S.hist, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, F, M, T, lane);
+    const bool done = cln_body24<NP, OMAX>(buf, S.r, g, row, stage, cur, S.hist, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, F, M, T, lane, CR, crc);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
 }
@@ -917,6 +972,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         if (sp == 0xffffffffu) active = false;             // an earlier channel failed (the scan reported it): decodes nothing
         else r.pos = sp;
     }
+    const uint32_t pos0 = r.pos;                           // where the lane's subframe starts
     // ---- does this wave qualify?  Every live lane: <= 16-bit audio, a FIXED / LPC subframe of at most 12 taps whose header
     //      parses, the wave's common block size (a multiple of 16, beyond the prologue), a 16-byte aligned row.
     int32_t* const rowp = out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
@@ -944,6 +1000,34 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         return;
     }
     if (lane == 0) taken[blockIdx.x] = gen;
+
+    // ---- the lane's share of its frame's CRC-16 (LCrc): from the granule in which its subframe starts to the granule in which
+    //      the next one does (the scan has said where: sf_start), the last channel's to the end of the frame as the descriptor
+    //      gives it; the first granule of the frame is the first channel's, taken here with the bytes in front of the frame masked
+    const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
+    const bool crc = (R.flags & CLX_RUN_CRC) != 0u;       // wave-uniform
+    LCrc CR;
+    CR.c.r = 0u; CR.c.x = 0u; CR.next = 0u; CR.db = CLN_CRC_NONE;
+    bool crc_mine = false, crc_last = false;
+    uint32_t crc_da = 0u;
+    if (crc && active && !(fr.flags & 1u)) {               // (a bare subframe has no footer)
+        crc_mine = true;
+        crc_last = ch + 1u == (uint32_t)fr.n_channels;
+        const uint32_t eb = (o + fr.limit_bits) >> 3;      // the frame's end, in bytes from the origin
+        uint32_t db = (eb >> 4) << 2;                      // (the last channel: the frame's whole granules; the rest is taken at the end)
+        if (!crc_last) {
+            const uint32_t nsp = sf_start[slot + 1u];
+            if (nsp == 0xffffffffu) crc_mine = false;      // (this subframe does not parse: the frame fails)
+            db = (nsp >> 7) << 2;
+        }
+        if (db < 4u) { if (crc_last) crc_mine = false; db = 4u; }      // (a frame that ends inside its first granule: the stand-alone kernel's)
+        crc_da = ch == 0u ? 0u : (pos0 >> 7) << 2;
+        if (crc_da < 4u && ch != 0u) crc_da = 4u;
+        if (crc_mine) {
+            CR.db = db; CR.next = crc_da;
+            if (ch == 0u) { cln_crc_take_masked(CR, clx_buf_load16(buf, r.origin), (uint32_t)(fr.byte_off & 15ull), 16u); CR.next = 4u; }
+        }
+    }
 
     const uint32_t decor = active ? fr.channel_assignment : 0u;
     const uint32_t pbs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(active ? bs : 0u), 0xB1, 0xF, 0xF, false);
@@ -999,7 +1083,6 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         if ((i & 15u) == 15u) cln_done(T, i & ~15u);
     }
     // ---- steady state
-    const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
     LRing g;
     g.origin = r.origin; g.fill = 0; g.fs = 0; g.np = 0; g.pa = make_uint4(0u, 0u, 0u, 0u); g.pb = g.pa; g.pc = g.pa;
     if (i0 < nmax) {
@@ -1018,12 +1101,12 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         if constexpr (SPLIT) {
             // the split evaluation needs sum|c| < 2^19 (S.lim >= 4096) -- any <= 32 coefficients of <= 15 bits but the all -2^14 row
             if (__any(lv && S.order != 0u && S.lim < 4096)) done = false;
-            else if (omax <= 12u) done = cln_run24<6, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane);
-            else                  done = cln_run24<16, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane);
+            else if (omax <= 12u) done = cln_run24<6, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane, CR, crc);
+            else                  done = cln_run24<16, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane, CR, crc);
         } else {
-            if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane);
-            else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane);
-            else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane);
+            if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
+            else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
+            else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
         }
         if (!done) {                                       // given up: clx_k_lanes decodes the group
             if (lane == 0) taken[blockIdx.x] = 0u;
@@ -1039,6 +1122,22 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     if (active) {
         if (S.r.err) clx_report_error(errkey, f, ch, S.r.err);
         else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(S.r.pos - o);
+    }
+    // ---- the share's remainder goes to clx_k_finalize -- the last channel's only when the frame ends where its descriptor says
+    //      (a descriptor may say "at most": then the stand-alone kernel checks the frame, from the end bit)
+    if (crc) {
+        bool keep = crc_mine && !S.r.err;
+        if (keep && crc_last) keep = ((S.r.pos + 7u) & ~7u) + 16u == o + fr.limit_bits;
+        if (!keep) CR.db = 0u;                              // (nothing to catch up with)
+        cln_crc_catchup(buf, r.origin, CR, CR.db);
+        if (keep) {
+            uint32_t db = CR.db;
+            const uint32_t te = ((o + fr.limit_bits) >> 3) & 15u;
+            if (crc_last && te != 0u) { cln_crc_take_masked(CR, clx_buf_load16(buf, r.origin + 4u * db), 0u, te); db += 4u; }
+            clx_crc_part part;
+            part.gen = gen; part.rx = clx_crct_reduced(CR.c.r) | ((uint32_t)__popc(CR.c.x) << 31); part.da = crc_da; part.db = db;
+            R.crc_part[slot] = part;
+        }
     }
 }
 

@@ -277,7 +277,11 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  * the submissions in flight different `d_out` buffers, i.e. rotate over clx_batch_submit_depth(b) of them (re-using a buffer is
  * legal: the submission then goes out after the earlier one that writes it).  Submissions may stay pending until
  * clx_batch_flush: work enqueued on `stream` after it sees every submission finished; clx_batch_results and
- * clx_batch_interleave flush by themselves; clx_batch_results returns the LAST submission's results. */
+ * clx_batch_interleave flush by themselves; clx_batch_results returns the LAST submission's results.
+ * One batch, one caller stream at a time: a batch's submissions and runs come in on ONE `stream` until a clx_batch_flush /
+ * clx_batch_results on that stream (submissions that arrive on another stream are not merged with pending ones, but what is
+ * already in flight is ordered against the stream it came in on only; distinct batches and contexts are independent).
+ * Accepted submissions are never dropped: re-planning or destroying a batch launches what is still pending first. */
 #ifndef CLX_SUBMIT_DEPTH
 #define CLX_SUBMIT_DEPTH 24     /* the most submissions any batch keeps in flight */
 #endif

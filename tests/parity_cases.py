@@ -543,3 +543,66 @@ def check_footer_read_in_batch(oracle, backend):
         assert [int(x) for x in res["status"]] == [int(x) for x in r["statuses"]]
         assert [int(x) for x in res["msg"]] == [int(x) for x in r["msgs"]]
         assert np.array_equal(out[2 * 4096:2 * 4096 + good.pcm.size], good.pcm)
+
+
+def check_crc_in_batch(oracle, backend, w, seed=77, frac=0.4, loose_every=0):
+    """CRC-16 parity inside a batch: a share of the frames gets bits flipped -- in the payload, in the footer, in the header's
+    neighbourhood -- and the frames that still parse must report "frame CRC mismatch" exactly where the reference does (the lean
+    kernels' lanes gather the CRC of the frames they decode: clx_crct.h).  `loose_every`: every such frame's descriptor only
+    bounds the frame (max_bytes runs into the next frame), as a reader that does not know the frame lengths hands them over."""
+    rng = np.random.default_rng(seed)
+    arena = w.arena.copy()
+    hit = np.zeros(w.n, dtype=bool)
+    for i in range(w.n):
+        if rng.uniform() >= frac:
+            continue
+        hit[i] = True
+        lo, hi = int(w.offs[i]), int(w.offs[i] + w.lens[i])
+        kind = int(rng.integers(0, 4))
+        for _ in range(int(rng.integers(1, 4))):
+            if kind == 0:
+                pos = int(rng.integers(8 * (hi - 2), 8 * hi))             # the footer itself
+            elif kind == 1:
+                pos = int(rng.integers(8 * (hi - 40), 8 * hi))            # near the end: the last subframe's tail
+            else:
+                pos = int(rng.integers(8 * (lo + 8), 8 * hi))             # anywhere behind the header
+            arena[pos >> 3] ^= (0x80 >> (pos & 7))
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)       # (the headers are intact)
+    lens = w.lens.copy()
+    if loose_every:
+        for i in range(0, w.n - 1, loose_every):
+            lens[i] = np.uint32(min(int(w.lens[i]) + 9 + i % 23, int(w.offs[i + 1] + w.lens[i + 1] - w.offs[i])))
+        descs = descs.copy()
+        descs["max_bytes"] = lens
+    out, res = backend.decode(arena, w.arena_len, descs, w.out_offs, True, fill=0x31313131)
+    ref = np.full(out.size, 0x31313131, dtype=np.int32)
+    r = oracle.decode_batch(arena[:w.arena_len], w.offs, lens, out=ref, out_offs=w.out_offs, check_crc=True)
+    st, ms = np.asarray(res["status"]), np.asarray(res["msg"])
+    bad = np.nonzero((st != r["statuses"]) | (ms != r["msgs"]))[0]
+    assert bad.size == 0, [(int(i), int(st[i]), MSG_NAME[int(ms[i])], int(r["statuses"][i]), MSG_NAME[int(r["msgs"][i])]) for i in bad[:6]]
+    n_mismatch = int(np.sum(ms == MSG["CLX_MSG_FRAME_CRC_MISMATCH"]))
+    assert n_mismatch >= max(1, int(hit.sum()) // 4), (n_mismatch, int(hit.sum()))
+    assert np.all(st[~hit] == cx.OK)
+    for i in np.nonzero(st == cx.OK)[0]:
+        a, b = int(w.out_offs[i]), int(w.out_offs[i]) + int(w.channels[i]) * int(w.block_sizes[i])
+        assert np.array_equal(out[a:b], ref[a:b]) and int(res["end_bit"][i]) == int(r["end_bits"][i]), i
+    return n_mismatch
+
+
+def giveup_workload(n=128, seed=4242):
+    """Stereo 16-bit frames of 4608 samples in families of 32 (one wave of 64 subframes each), alternating: partitions of 144 codes
+    (the lean kernels' turns all the way) and partitions of 18 codes (a partition edge inside a four at every other edge: slow turn
+    after slow turn, so the wave gives its group up -- CLN_SLOW_BUDGET -- and the general kernels decode it from the start)."""
+    S = synth
+    bs = 4608
+    pcm = np.empty((n, 2, bs), dtype=np.int32)
+    fps = []
+    for i in range(n):
+        L, R, _ = S.pcm_music_like(seed + i, bs)
+        pcm[i, 0], pcm[i, 1] = L, R
+        fp = S.FrameParams(3 if i % 3 else 0, 0, i)
+        po = 8 if (i // 32) % 2 else 5
+        for c in range(2):
+            fp.sf[c] = S.sf(S.SF_LPC, 8, 12, po)
+        fps.append(fp)
+    return S.encode_frames("give-up families", pcm, 2, bs, 16, fps)

@@ -18,7 +18,7 @@ assert SF_DESC_DTYPE.itemsize == 80
 
 def build(force=False):
     deps = [os.path.join(_DIR, f) for f in ("sim_lib.cpp", "wavesim.h")] + \
-           [os.path.join(_CSRC, f) for f in ("clx_kernels.hip", "clx_lanes.hip", "clx_lean.hip", "clx_device.h", "clx_plan.h")] + \
+           [os.path.join(_CSRC, f) for f in ("clx_kernels.hip", "clx_lanes.hip", "clx_lean.hip", "clx_device.h", "clx_crct.h", "clx_plan.h")] + \
            [os.path.join(_DIR, "fake", "clx_intrin.h"), os.path.join(_DIR, "fake", "clx_k2_dot2.h")]
     if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps):
         return _SO

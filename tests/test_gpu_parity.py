@@ -60,6 +60,15 @@ def test_gpu_footer_read_in_batch(oracle, gpu):
     pc.check_footer_read_in_batch(oracle, gpu)
 
 
+def test_gpu_crc16_in_batch(oracle, gpu):
+    """damaged frames inside batches, CRC-16 verified: "frame CRC mismatch" exactly where the oracle says -- from the decode lanes'
+    own gathering (lean kernels, clx_crct.h) or from the stand-alone kernel, whichever the selection uses"""
+    pc.check_crc_in_batch(oracle, gpu, synth.config3(300))
+    pc.check_crc_in_batch(oracle, gpu, synth.config5_unique(400), seed=3)
+    pc.check_crc_in_batch(oracle, gpu, synth.config4(120), seed=5)
+    pc.check_crc_in_batch(oracle, gpu, synth.config3(300), seed=9, frac=0.1, loose_every=3)
+
+
 def test_gpu_truncations(oracle, gpu):
     pc.check_truncations(oracle, gpu, n_frames=10, cuts_per_frame=24)
 

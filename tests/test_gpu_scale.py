@@ -160,6 +160,127 @@ def test_config4_at_scale_against_the_oracle(oracle, ctx):
     bl.close(); batch.close()
 
 
+def test_config2_at_scale_pipelined_against_the_oracle(oracle, ctx):
+    """BASELINE configs[1] at its full size through pipelined submissions (clx_k_lean without a scan: mono subframes), every buffer
+    against the oracle's decode of the bare subframes."""
+    import torch
+    w = synth.config2(10000)
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    batch = ctx.plan(descs, w.out_offs, verify_crc=False)
+    depth = batch.submit_depth
+    assert batch.submit_lanes and depth > 1
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(depth)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(depth + 7):
+        batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_subframes(w.arena[:w.arena_len], w.offs, w.block_sizes, w.bps, out=ref, out_offs=w.out_offs)
+    assert np.array_equal(res["status"], r["statuses"]) and np.all(res["status"] == cx.OK)
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    d_ref = torch.from_numpy(ref).to("cuda:0")
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o, d_ref)), "output buffer %d differs from the oracle" % k
+    assert np.array_equal(ref, w.pcm)
+    batch.close()
+
+
+def test_rotation_over_more_buffers_than_depth(oracle, ctx):
+    """Thirty output buffers under a depth of twenty-four, two distinct inputs in turn, no flush in between: a merged launch on one
+    internal stream then writes buffers that a launch TWO launches earlier on the other stream wrote (not the latest one there) --
+    the library has to order them (it keeps the last writer of every output buffer), or stale writes of the earlier launch could
+    land on top of the later one's.  Every buffer must hold the decode of the LAST input submitted into it."""
+    import torch
+    ws = [synth.config3(1500), _seeded_config3(1500, 7000)]
+    # both inputs under ONE plan: frame i of either sits at i * S, the descriptors only bound the frames (max_bytes = S)
+    S = (int(max(int(w.lens.max()) for w in ws)) + 31) & ~15
+    n = ws[0].n
+    offs = (np.arange(n, dtype=np.uint64) * np.uint64(S))
+    arenas = []
+    for w in ws:
+        a = np.zeros(n * S + 64, dtype=np.uint8)
+        for i in range(n):
+            a[i * S:i * S + int(w.lens[i])] = w.arena[int(w.offs[i]):int(w.offs[i] + w.lens[i])]
+        arenas.append(a)
+    lens = np.full(n, S, dtype=np.uint32)
+    descs, _ = cx.descs_from_offsets(arenas[0][:n * S], offs, lens, check_crc=False)
+    d2, _ = cx.descs_from_offsets(arenas[1][:n * S], offs, lens, check_crc=False)
+    assert descs.tobytes() == d2.tobytes()
+    refs = []
+    for w, a in zip(ws, arenas):
+        ref = np.zeros(w.pcm.size, dtype=np.int32)
+        r = oracle.decode_batch(a[:n * S], offs, lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+        assert np.all(r["statuses"] == cx.OK) and np.array_equal(ref, w.pcm)
+        refs.append(torch.from_numpy(ref).to("cuda:0"))
+    d_arenas = [torch.from_numpy(a).to("cuda:0") for a in arenas]
+    batch = ctx.plan(descs, ws[0].out_offs, verify_crc=True)
+    assert batch.submit_lanes and batch.submit_depth == cx.SUBMIT_DEPTH
+    nbuf = cx.SUBMIT_DEPTH + 6
+    outs = [torch.full((ws[0].pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(nbuf)]
+    st = torch.cuda.current_stream().cuda_stream
+    last = {}
+    for i in range(2 * nbuf + 15):
+        which = (i * 7 // 3) & 1
+        batch.submit(d_arenas[which].data_ptr(), n * S, outs[i % nbuf].data_ptr(), st)
+        last[i % nbuf] = which
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    assert np.all(res["status"] == cx.OK)
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o, refs[last[k]])), "output buffer %d does not hold the last input submitted into it" % k
+    batch.close()
+
+
+def _seeded_config3(n, first):
+    base = synth.BASE_SEED
+    synth.BASE_SEED = base + first
+    try:
+        return synth.config3(n)
+    finally:
+        synth.BASE_SEED = base
+
+
+def test_lean_give_up_at_scale(oracle, ctx):
+    """10 000 frames of which every other wave gives its group up (parity_cases.giveup_workload: clx_k_lean's slow-turn budget), through
+    pipelined submissions: half the groups are decoded twice -- started by clx_k_lean, abandoned, decoded from the start by
+    clx_k_lanes -- and every sample, status and end bit still matches the oracle (no timing involved)."""
+    import torch
+    w = pc.giveup_workload(10000)
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True)
+    assert batch.submit_lanes
+    depth = min(batch.submit_depth, 4)
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(depth)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(batch.submit_depth + 2):
+        batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.array_equal(res["status"], r["statuses"]) and np.all(res["status"] == cx.OK)
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    d_ref = torch.from_numpy(ref).to("cuda:0")
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o, d_ref)), "output buffer %d differs from the oracle" % k
+    assert np.array_equal(ref, w.pcm)
+    # both kernels really worked: one profiled run
+    bl = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED)
+    bl.set_profiling(True)
+    bl.run(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    torch.cuda.synchronize()
+    kt = bl.kernel_times()
+    assert kt["clx_k_lanes"] > 0.2 * kt["clx_k_lean"], kt              # (the general kernel decoded the given-up half)
+    assert bool(torch.equal(outs[0], d_ref))
+    bl.close(); batch.close()
+
+
 def test_forced_builds_at_scale(oracle, ctx, big3):
     """The builds the thresholds would not pick at this size, forced by flag on the same 12 288 frames."""
     w = pc.head(big3, 12288)

@@ -243,3 +243,49 @@ def test_sim_lean_truncations_and_flips(oracle):
                 g[pos >> 3] ^= (0x80 >> (pos & 7))
             seen.add(pc.assert_same_as_oracle(oracle, sim, g, False, "frame %d flip %d" % (i, trial)))
     assert len(seen) >= 3, seen
+
+
+def test_sim_crc16_gathered_by_the_decode_lanes(oracle):
+    """Round 4: the lean kernels' lanes gather their frames' CRC-16 from the words they stage anyway (clx_crct.h: the frame's polynomial
+    modulo x^15 + x + 1 and its parity -- P = (x + 1)(x^15 + x + 1)), clx_k_finalize judges it, and the stand-alone kernel only
+    checks what is left (`todo`: groups the general kernels decoded, frames whose descriptor only bounds them).  Intact batches:
+    every frame of a taken group is settled by the lanes.  Damaged batches: "frame CRC mismatch" exactly where the oracle says."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    sim = SimBackend(cx.PATH_LANES | cx.LANES_FUSED)
+
+    def counted(f):
+        for i in range(64):
+            stats[i] = 0
+        r = f()
+        return r, int(stats[14]), int(stats[15])            # frames settled by the lanes | left to clx_k_crc16_runs
+
+    for w in (synth.config3(70), synth.config5_unique(96), synth.config4(40)):
+        _, done, todo = counted(lambda: pc.check_workload(oracle, sim, w, verify_crc=True))
+        assert (done, todo) == (w.n, 0), (w.name, done, todo)
+    # a third of the frames damaged: the verdicts match the oracle's; some of them are the lanes' own
+    n, done, todo = counted(lambda: pc.check_crc_in_batch(oracle, sim, synth.config5_unique(96)))
+    assert n >= 10 and done >= 48, (n, done, todo)
+    pc.check_crc_in_batch(oracle, sim, synth.config4(40), seed=5)
+    # descriptors that only bound their frames (max_bytes runs into the next frame): those frames are the stand-alone kernel's
+    n, done, todo = counted(lambda: pc.check_crc_in_batch(oracle, sim, synth.config3(70), seed=9, frac=0.1, loose_every=3))
+    assert todo >= 23, (done, todo)
+    pc.check_crc_in_batch(oracle, sim, pc.lean_workload(), seed=11, loose_every=5)
+
+
+def test_sim_groups_given_up_by_the_lean_kernel(oracle):
+    """Every other wave of parity_cases.giveup_workload keeps needing the slow turn and gives its group up: the general kernels decode
+    it from its start (rows rewritten), the frames' CRC-16 goes to the stand-alone kernel -- and everything still matches the oracle."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for i in range(64):
+        stats[i] = 0
+    w = pc.giveup_workload(128)
+    pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
+    given_up, taken = stats[57] // 64, stats[52]
+    assert (given_up, taken) == (2, 2), (given_up, taken)                  # four waves: two stay with clx_k_lean, two are given up
+    assert (stats[14], stats[15]) == (64, 64), (stats[14], stats[15])      # CRC-16: the lanes' own gathering | the stand-alone kernel's

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE: runs the production kernel source under the wave simulator.
 #include <vector>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 extern "C" { uint64_t sim_stats[64]; }
 #define CLX_STAT(i, n) (sim_stats[i] += (uint64_t)(n))
 #include "clx_kernels.hip"
@@ -32,6 +34,11 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         runs.r[0].arena = arena; runs.r[0].alloc_len = alloc_len + 16; runs.r[0].out = out; runs.r[0].sf_start = sf_start.data();
         runs.r[0].errkey = errkey.data(); runs.r[0].end_bits = endbits.data(); runs.r[0].taken = lean ? taken.data() : nullptr;
         runs.r[0].results = results; runs.r[0].gen = 7u;
+        std::vector<clx_crc_part> crc_part(n_slots ? n_slots : 1);
+        memset(crc_part.data(), 0, crc_part.size() * sizeof(clx_crc_part));
+        std::vector<uint32_t> crc_todo(n ? n : 1, 0xa5a5a5a5u);
+        runs.r[0].crc_part = crc_part.data(); runs.r[0].crc_todo = crc_todo.data();
+        runs.r[0].flags = (flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u;
         if (n_multi) {
             if (flags & CLX_LANES_GENERAL) SIM_LAUNCH(clx_k_scan_general, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
             else SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
@@ -60,7 +67,12 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, runs, dev.data(), (uint32_t)n);
         // (the scratch is left ready for a next run)
         for (size_t i = 0; i < n; ++i) if (errkey[i] != 0xffffffffu) return CLX_API_ERROR;
-        if (flags & CLX_VERIFY_CRC16) SIM_LAUNCH(clx_k_crc16_runs, (n + 3) / 4, 256, runs, dev.data(), (uint32_t)n);
+        if (flags & CLX_VERIFY_CRC16) {
+            // (how many frames the lean kernels' lanes settled themselves, how many the stand-alone kernel has to check)
+            for (size_t i = 0; i < n; ++i) { if (crc_todo[i] > 1u) return CLX_API_ERROR; sim_stats[14 + crc_todo[i]] += 1;
+                if (getenv("SIM_CRC_DEBUG") && crc_todo[i]) { fprintf(stderr, "todo frame %zu st %d:", i, results[i].status); for (uint32_t c = 0; c < dev[i].n_channels; ++c) { const clx_crc_part& q = crc_part[dev[i].first_slot + c]; fprintf(stderr, " [gen %u rx %08x da %u db %u]", q.gen, q.rx, q.da, q.db); } fprintf(stderr, " endbit %llu limit %u off %llu\n", (unsigned long long)results[i].end_bit, dev[i].limit_bits, (unsigned long long)dev[i].byte_off); } }
+            SIM_LAUNCH(clx_k_crc16_runs, (n + 3) / 4, 256, runs, dev.data(), (uint32_t)n);
+        }
         return CLX_OK;
     }
     SIM_LAUNCH(clx_k_residual, n, 64, arena, alloc_len, dev.data(), (uint32_t)n, out, sfd.data(), results);

@@ -20,9 +20,11 @@ for n, cs in vals.items():
         insts[n] = {"valu": int(mean(cs["SQ_INSTS_VALU"])), "salu": int(mean(cs["SQ_INSTS_SALU"])), "lds": int(mean(cs["SQ_INSTS_LDS"])),
                     "waves": int(mean(cs["SQ_WAVES"]))}
 line = json.loads(open(os.path.join(out, "bench_line.json")).read())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
 p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
 j = json.load(open(p))
 j[key] = {"path_bytes": sum(kern.values()), "kernels": kern, "insts": insts, "algorithmic_bytes": line["roofline"]["algorithmic_bytes_per_launch"],
-          "samples_per_launch": line["config"]["samples_per_step"], "source": source}
+          "samples_per_launch": line["config"]["samples_per_step"], "source": source, "kernel_src_sha16": bench.kernel_source_sha16()}
 json.dump(j, open(p, "w"), indent=1)
 print(key, j[key]["path_bytes"], round(j[key]["path_bytes"] / j[key]["algorithmic_bytes"], 3), {k: v["valu"] for k, v in insts.items()})
