@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-crc", action="store_true", help="time the step WITHOUT the CRC-16 check (secondary figure; `value` verifies by default)")
     ap.add_argument("--path", choices=["auto", "waves", "lanes", "lanes-fused", "lanes-general"], default="auto",
                     help="kernel path (default: library's choice); lanes-general = the fused lane build without the 16-bit tier clx_k_lean")
+    ap.add_argument("--compose", choices=["auto", "on", "off"], default="auto",
+                    help="waves composed by content (clx_k_compose): the library's choice by the descriptors, or forced on / off")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process group backend for the barrier and the MAX / SUM reductions (nccl = RCCL)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="how often the timed region of --steps steps is repeated: `value` is the median region, min / max are carried beside it")
@@ -107,6 +109,7 @@ def main():
     d_out = torch.zeros(w.total_samples, dtype=torch.int32, device=dev)
     path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES, "lanes-fused": cx.PATH_LANES | cx.LANES_FUSED,
             "lanes-general": cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL}[args.path]
+    path |= {"auto": 0, "on": cx.COMPOSE, "off": cx.NO_COMPOSE}[args.compose]
     # `value` is the VERIFIED step: every frame's CRC-16 footer is checked on the device inside it, as the reference does for every
     # frame it decodes (frame.rs:752-763) and as the cpu_baseline leg does; bare subframes (config 2) have no footer
     with_crc = (not w.bare_subframes) and not args.no_crc
@@ -166,7 +169,7 @@ def main():
     if pipelined and batch.submit_lanes and "clx_k_lanes" not in kernel_ms:
         # the pipelined steps run the fused lane kernels while one run at a time takes the wave kernels: the roofline block is
         # about the kernels of the TIMED steps, so their durations are taken from a batch forced onto them
-        bl = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=cx.PATH_LANES | cx.LANES_FUSED)
+        bl = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=cx.PATH_LANES | cx.LANES_FUSED | (path & (cx.COMPOSE | cx.NO_COMPOSE)))
         kernel_ms = _kernel_ms(torch, bl, lambda: bl.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
         bl.close()
         path_tag = "_lanes"
@@ -292,7 +295,7 @@ def main():
            "process_group": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None, "world_size": world},
            "launcher": os.environ.get("CLX_BENCH_LAUNCHER", "external (WORLD_SIZE in the environment)" if world > 1 else "single process"),
            "bit_exact": True, "bit_exact_checked": "every output buffer vs the source PCM before the timed steps, and again -- on buffers cleared in between -- after them",
-           "crc16_in_step": bool(with_crc), "kernel_path": args.path, "gen_seconds": round(gen_s, 1),
+           "crc16_in_step": bool(with_crc), "kernel_path": args.path, "compose": args.compose, "gen_seconds": round(gen_s, 1),
            "steps_in_flight": depth if pipelined else 1, "distinct_input_copies_in_flight": len(arenas),
            "merged_launches_per_region": _launch_sizes(args.steps, batch.submit_depth) if (pipelined and batch.submit_lanes) else None,
            "devices": args.devices or None,

@@ -255,7 +255,7 @@ struct clx_batch {
     bool all_narrow_aligned = false;                   // every frame: bps <= 16, rows 16-byte aligned and a multiple of 4 samples long
     clx_dev_frame* h_up = nullptr; size_t up_cap = 0;      // pinned staging of the uploaded plan
     hipEvent_t ev_up = nullptr; bool up_in_flight = false; // recorded behind the staging's H2D copy: the staging is rewritten only after it
-    size_t cap[12] = {};             // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits, d_taken, d_crc_part, d_crc_todo
+    size_t cap[17] = {};             // bytes allocated for d_frames, d_sfd, d_results, d_dump, d_slot_frame, d_multi, d_sf_start, d_errkey, d_endbits, d_taken, d_crc_part, d_crc_todo
     size_t n = 0;
     uint64_t n_slots = 0;
     uint32_t flags = 0;
@@ -279,8 +279,12 @@ struct clx_batch {
     uint32_t* d_taken = nullptr;     // per group of 64 slots: the generation number of the run in which clx_k_lean decoded it
     clx_crc_part* d_crc_part = nullptr;      // per slot: the lean kernels' lanes' shares of their frames' CRC-16 (tagged with the run's generation number)
     uint32_t* d_crc_todo = nullptr;  // per frame: clx_k_finalize -> clx_k_crc16_runs
+    // waves composed by content (clx_k_compose): the plan's windows, and flight 0's own slot maps and content classes
+    uint32_t* d_first_slot = nullptr;        // per frame: the plan's slot of its first subframe (what clx_dev_frame::first_slot says)
+    clx_window* d_windows = nullptr; size_t n_windows = 0;
+    uint32_t* d_slot_frame_run = nullptr; uint32_t* d_first_slot_run = nullptr; uint32_t* d_fkey = nullptr;
     bool profiling = false, profile_merged = false;
-    enum { kMaxKernels = 8 };
+    enum { kMaxKernels = 10 };
     hipEvent_t ev[kMaxKernels + 1] = {};
     const char* kname[kMaxKernels] = {};
     int n_kernels = 0;
@@ -299,6 +303,7 @@ struct clx_batch {
         uint32_t* d_sf_start = nullptr; uint32_t* d_errkey = nullptr; uint64_t* d_endbits = nullptr;   // lane kernels' scratch
         uint32_t* d_taken = nullptr; uint32_t gen = 0;     // groups clx_k_lean took (marked with the run's generation number, never cleared)
         clx_crc_part* d_crc_part = nullptr; uint32_t* d_crc_todo = nullptr;
+        uint32_t* d_slot_frame = nullptr; uint32_t* d_first_slot = nullptr; uint32_t* d_fkey = nullptr;   // the run's slot maps (its own when waves are composed)
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
         hipEvent_t ev_rice = nullptr, ev_side = nullptr;   // Rice stage done | the submission's kernels on side_stream done
         bool side_pending = false, side_recorded = false;
@@ -408,6 +413,11 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_taken) (void)hipFree(b->d_taken);
     if (b->d_crc_part) (void)hipFree(b->d_crc_part);
     if (b->d_crc_todo) (void)hipFree(b->d_crc_todo);
+    if (b->d_first_slot) (void)hipFree(b->d_first_slot);
+    if (b->d_windows) (void)hipFree(b->d_windows);
+    if (b->d_slot_frame_run) (void)hipFree(b->d_slot_frame_run);
+    if (b->d_first_slot_run) (void)hipFree(b->d_first_slot_run);
+    if (b->d_fkey) (void)hipFree(b->d_fkey);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
     for (int k = 0; k < clx_batch::kMaxStreams; ++k) {
@@ -430,6 +440,7 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
         if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
         if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
+        if (i != 0 && F.d_fkey) { (void)hipFree(F.d_slot_frame); (void)hipFree(F.d_first_slot); (void)hipFree(F.d_fkey); }      // (its own maps)
     }
     if (b->ev_up) { (void)hipEventSynchronize(b->ev_up); (void)hipEventDestroy(b->ev_up); }
     if (b->h_up) (void)hipHostFree(b->h_up);
@@ -451,8 +462,13 @@ int plan_lanes_data(clx_batch* b) {
     clx_ctx* ctx = b->ctx;
     if (b->lanes_planned) return CLX_OK;
     const size_t n = b->n, ns = b->n_slots ? (size_t)b->n_slots : 1, nf = n ? n : 1;
-    std::vector<uint32_t> slot_frame(ns), multi(nf);
+    std::vector<uint32_t> slot_frame(ns), multi(nf), first_slot(nf, 0u);
     b->n_multi = clx_plan_lanes(b->h_frames.data(), n, b->n_slots, slot_frame.data(), multi.data());
+    for (size_t i = 0; i < n; ++i) first_slot[i] = b->h_frames[i].first_slot;
+    // windows whose waves are composed by content (fused build with the lean tiers in front; CLX_COMPOSE / CLX_NO_COMPOSE force it)
+    std::vector<clx_window> windows(nf);
+    const int cmode = (b->flags & (CLX_NO_COMPOSE | CLX_LANES_GENERAL | CLX_LANES_SPLIT)) ? -1 : (b->flags & CLX_COMPOSE) ? 1 : 0;
+    b->n_windows = clx_plan_windows(b->h_frames.data(), n, cmode, windows.data());
     b->any_bps_le16 = b->any_bps_gt16 = false;
     for (size_t i = 0; i < n; ++i) { if (b->h_frames[i].bps <= 16u) b->any_bps_le16 = true; else b->any_bps_gt16 = true; }
     if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
@@ -469,6 +485,18 @@ int plan_lanes_data(clx_batch* b) {
         !hip_ok(ctx, hipMemset(b->d_errkey, 0xff, nf * sizeof(uint32_t)), "memset errkey") ||
         !hip_ok(ctx, hipMemcpy(b->d_slot_frame, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame") ||
         !hip_ok(ctx, hipMemcpy(b->d_multi, multi.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D multi")) return CLX_API_ERROR;
+    if (!grow(ctx, &b->d_first_slot, &b->cap[12], nf * sizeof(uint32_t), "hipMalloc first_slot") ||
+        !hip_ok(ctx, hipMemcpy(b->d_first_slot, first_slot.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D first_slot")) return CLX_API_ERROR;
+    if (b->n_windows) {
+        if (!grow(ctx, &b->d_windows, &b->cap[13], b->n_windows * sizeof(clx_window), "hipMalloc windows") ||
+            !grow(ctx, &b->d_slot_frame_run, &b->cap[14], ns * sizeof(uint32_t), "hipMalloc slot_frame (run)") ||
+            !grow(ctx, &b->d_first_slot_run, &b->cap[15], nf * sizeof(uint32_t), "hipMalloc first_slot (run)") ||
+            !grow(ctx, &b->d_fkey, &b->cap[16], nf * sizeof(uint32_t), "hipMalloc fkey") ||
+            !hip_ok(ctx, hipMemcpy(b->d_windows, windows.data(), b->n_windows * sizeof(clx_window), hipMemcpyHostToDevice), "H2D windows") ||
+            !hip_ok(ctx, hipMemcpy(b->d_slot_frame_run, slot_frame.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D slot_frame (run)") ||
+            !hip_ok(ctx, hipMemcpy(b->d_first_slot_run, first_slot.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D first_slot (run)") ||
+            !hip_ok(ctx, hipMemset(b->d_fkey, 0, nf * sizeof(uint32_t)), "memset fkey")) return CLX_API_ERROR;
+    }
     b->lanes_planned = true;
     return CLX_OK;
 }
@@ -545,7 +573,8 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
         if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
         if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
-        F.d_taken = nullptr; F.gen = 0; F.d_crc_part = nullptr; F.d_crc_todo = nullptr;
+        if (i != 0 && F.d_fkey) { (void)hipFree(F.d_slot_frame); (void)hipFree(F.d_first_slot); (void)hipFree(F.d_fkey); }
+        F.d_taken = nullptr; F.gen = 0; F.d_crc_part = nullptr; F.d_crc_todo = nullptr; F.d_slot_frame = nullptr; F.d_first_slot = nullptr; F.d_fkey = nullptr;
         if (i == 0) F.d_results = nullptr;
         F.d_sfd = nullptr; F.d_results = nullptr; F.d_sf_start = nullptr; F.d_errkey = nullptr; F.d_endbits = nullptr; F.pending = false; F.side_pending = false; F.sfd_stale = true; F.scratch_stale = false; F.out = nullptr;   // (side_recorded stays: the event is still there)
     }
@@ -648,24 +677,29 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
                                (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi);
     }
     if (!split) {
+        // waves composed by content: the windows' frames dealt to the lanes by class (the scan has left every frame's class)
+        if (runs.r[0].fkey != nullptr && b->n_windows && b->n_multi) {
+            if (!mark("clx_k_compose")) return false;
+            hipLaunchKernelGGL(clx_k_compose, dim3((unsigned)b->n_windows, n_runs), dim3(CLX_COMPOSE_THREADS), 0, stream, runs, (const clx_window*)b->d_windows);
+        }
         // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them
         if (runs.r[0].taken != nullptr && b->any_bps_le16) {
             if (!mark("clx_k_lean")) return false;
             hipLaunchKernelGGL(clx_k_lean, dim3(groups, n_runs), dim3(64), 0, stream, runs,
-                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
+                               (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
         }
         // the split tier for audio of more than 16 bits (launched when the batch holds such frames: it also takes <= 16-bit groups of
         // more than 12 taps that share the batch, which otherwise stay with clx_k_lanes_hi)
         if (runs.r[0].taken != nullptr && b->any_bps_gt16) {
             if (!mark("clx_k_lean24")) return false;
             hipLaunchKernelGGL(clx_k_lean24, dim3(groups, n_runs), dim3(64), 0, stream, runs,
-                               (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
+                               (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
         }
         if (!mark("clx_k_lanes")) return false;             // (+ clx_k_lanes_hi, its order > 12 twin)
         hipLaunchKernelGGL(clx_k_lanes, dim3(groups, n_runs), dim3(64), 0, stream, runs,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
         hipLaunchKernelGGL(clx_k_lanes_hi, dim3(groups, n_runs), dim3(64), 0, stream, runs,
-                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_slot_frame, (uint32_t)b->n_slots, b->d_dump);
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
     }
     else {
         if (n_runs != 1) return false;
@@ -693,6 +727,11 @@ clx_run make_run(const clx_batch* b, const clx_batch::Flight& F, const uint8_t* 
     R.taken = (lean && !(b->flags & CLX_LANES_GENERAL)) ? F.d_taken : nullptr;
     R.results = F.d_results; R.gen = F.gen;
     R.crc_part = F.d_crc_part; R.crc_todo = F.d_crc_todo;
+    // the run's slot maps: its own when its waves are composed by content (clx_k_compose rewrites the windows' parts), else the plan's
+    const bool composed = lean && b->n_windows != 0 && F.d_fkey != nullptr;
+    R.slot_frame = composed ? F.d_slot_frame : b->d_slot_frame;
+    R.first_slot = composed ? F.d_first_slot : b->d_first_slot;
+    R.fkey = composed ? F.d_fkey : nullptr;
     R.flags = (b->flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u;
     return R;
 }
@@ -891,6 +930,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         clx_batch::Flight& F0 = b->flight[0];
         F0.d_results = b->d_results; F0.d_sf_start = b->d_sf_start; F0.d_errkey = b->d_errkey; F0.d_endbits = b->d_endbits; F0.d_taken = b->d_taken;
         F0.d_crc_part = b->d_crc_part; F0.d_crc_todo = b->d_crc_todo;
+        F0.d_slot_frame = b->d_slot_frame_run; F0.d_first_slot = b->d_first_slot_run; F0.d_fkey = b->d_fkey;
         if (++F0.gen == 0u) {
             HIP_TRY(ctx, hipMemsetAsync(b->d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), stream));
             HIP_TRY(ctx, hipMemsetAsync(b->d_crc_part, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_crc_part), stream));
@@ -980,8 +1020,17 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         if (plan_lanes_data(b) != CLX_OK) return CLX_API_ERROR;       // (with the batch's first pipelined submission when no run needed it)
         if (!F.d_sf_start) {
             if (slot == 0) { F.d_sf_start = b->d_sf_start; F.d_errkey = b->d_errkey; F.d_endbits = b->d_endbits; F.d_taken = b->d_taken;
-                             F.d_crc_part = b->d_crc_part; F.d_crc_todo = b->d_crc_todo; }
+                             F.d_crc_part = b->d_crc_part; F.d_crc_todo = b->d_crc_todo;
+                             F.d_slot_frame = b->d_slot_frame_run; F.d_first_slot = b->d_first_slot_run; F.d_fkey = b->d_fkey; }
             else {
+                if (b->n_windows) {      // (its own slot maps, starting as the plan's: clx_k_compose rewrites the windows' parts run by run)
+                    HIP_TRY(ctx, hipMalloc((void**)&F.d_slot_frame, ns * sizeof(uint32_t)));
+                    HIP_TRY(ctx, hipMalloc((void**)&F.d_first_slot, nf * sizeof(uint32_t)));
+                    HIP_TRY(ctx, hipMalloc((void**)&F.d_fkey, nf * sizeof(uint32_t)));
+                    HIP_TRY(ctx, hipMemcpy(F.d_slot_frame, b->d_slot_frame, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                    HIP_TRY(ctx, hipMemcpy(F.d_first_slot, b->d_first_slot, nf * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                    HIP_TRY(ctx, hipMemset(F.d_fkey, 0, nf * sizeof(uint32_t)));
+                }
                 HIP_TRY(ctx, hipMalloc((void**)&F.d_crc_part, ns * sizeof(clx_crc_part)));
                 HIP_TRY(ctx, hipMalloc((void**)&F.d_crc_todo, nf * sizeof(uint32_t)));
                 HIP_TRY(ctx, hipMemset(F.d_crc_part, 0, ns * sizeof(clx_crc_part)));
@@ -1239,7 +1288,20 @@ extern "C" int clx_decode_frames_stream(clx_ctx* ctx, const uint8_t* arena, size
     // Few, large chunks: a chunk's decode lasts at least as long as the predictor kernel's serial chain (0.19 ms however few
     // frames it has), so small chunks cost more than their share of overlap brings (10 000 frames, upload only: 16 chunks 2.50 ms,
     // 4 chunks 1.73, 3 chunks 1.44, 2 chunks 1.45).
+    // Round 4: a fourth, smaller chunk at the end (42 / 33 / 19 / 6 %: the call waits for the last chunk's decode, which nothing
+    // overlaps) was measured and is worse -- 1.78 against 1.44 ms: a chunk costs ~0.2 ms whatever its size.  Three chunks stay; the
+    // last one is the smallest (40 / 40 / 20 %).
     const size_t per = ctx->stream_chunk ? ctx->stream_chunk : std::min<size_t>(std::max<size_t>((n + 2) / 3, 256), 8192);
+    std::vector<size_t> cuts;            // chunk c = frames [cuts[c], cuts[c + 1])
+    cuts.push_back(0);
+    if (!ctx->stream_chunk && n >= 4096 && n <= 3 * 8192) {
+        const double share[2] = { 0.40, 0.80 };
+        for (double sh : share) cuts.push_back(std::max<size_t>(cuts.back() + 1, (size_t)(sh * (double)n) & ~(size_t)31));
+        cuts.push_back(n);
+    } else {
+        for (size_t lo = per; lo < n; lo += per) cuts.push_back(lo);
+        cuts.push_back(n);
+    }
     auto harvest = [&](clx_stream_slot& S) -> bool {                                       // results of the slot's finished chunk
         if (S.hi <= S.lo) return true;
         if (!hip_ok(ctx, hipStreamSynchronize(S.st), "sync")) return false;
@@ -1248,9 +1310,8 @@ extern "C" int clx_decode_frames_stream(clx_ctx* ctx, const uint8_t* arena, size
         return true;
     };
     int st = CLX_OK;
-    size_t c = 0;
-    for (size_t lo = 0; lo < n && st == CLX_OK; lo += per, ++c) {
-        const size_t hi = std::min(n, lo + per), nc = hi - lo;
+    for (size_t c = 0; c + 1 < cuts.size() && st == CLX_OK; ++c) {
+        const size_t lo = cuts[c], hi = cuts[c + 1], nc = hi - lo;
         clx_stream_slot& S = ctx->slots[c % 3];
         if (!S.st && !hip_ok(ctx, hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking), "hipStreamCreate")) { st = CLX_API_ERROR; break; }
         if (!harvest(S)) { st = CLX_API_ERROR; break; }                                  // (also: the slot's buffers are free again)
@@ -1287,11 +1348,17 @@ extern "C" int clx_decode_frames_stream(clx_ctx* ctx, const uint8_t* arena, size
             if (!hip_ok(ctx, hipHostMalloc((void**)&S.h_res, (nc + nc / 4) * sizeof(clx_frame_result), hipHostMallocDefault), "hipHostMalloc results")) { st = CLX_API_ERROR; break; }
             S.res_cap = nc + nc / 4;
         }
+        // what no frame covers, and what a failed frame leaves, comes back as zeros: the planar output's failed frames are cleared
+        // behind the decode (clx_k_clear_failed), so the buffer itself only needs clearing when the frames leave gaps in it or the
+        // narrow stage (which skips failed frames) writes the bytes that go back -- and not at all when nothing goes back
+        bool gaps = false;
+        for (size_t i = lo + 1; i < hi && !gaps; ++i)
+            gaps = out_sample_offsets[i] != out_sample_offsets[i - 1] + (uint64_t)frames[i - 1].n_channels * frames[i - 1].block_size;
+        const bool clear_out = out != nullptr && (sample_bytes != 0u || gaps);
         const bool ok =
             hip_ok(ctx, hipMemsetAsync(S.d_arena + (arena_alloc - 48), 0, 48, S.st), "memset") &&
             hip_ok(ctx, hipMemcpyAsync(S.d_arena, arena + a0, span, hipMemcpyHostToDevice, S.st), "H2D arena") &&
-            // what no frame covers, and what a failed frame leaves, comes back as zeros
-            hip_ok(ctx, hipMemsetAsync(sample_bytes ? (void*)S.d_pcm : (void*)S.d_out, 0, out_n * (sample_bytes ? sample_bytes : 4u), S.st), "memset out");
+            (!clear_out || hip_ok(ctx, hipMemsetAsync(sample_bytes ? (void*)S.d_pcm : (void*)S.d_out, 0, out_n * (sample_bytes ? sample_bytes : 4u), S.st), "memset out"));
         if (!ok) { st = CLX_API_ERROR; break; }
         st = clx_batch_run(S.b, S.d_arena, span, S.d_out, S.st);
         if (st != CLX_OK) break;

@@ -60,6 +60,9 @@ struct clx_run {
     uint64_t* end_bits;      // scratch: end bit per frame
     uint32_t* taken;         // per group of 64 slots: == gen when clx_k_lean decoded the group in this run
     clx_frame_result* results;
+    const uint32_t* slot_frame;  // which frame the lane at each (physical) slot decodes -- the plan's map, or this run's own when waves are
+    const uint32_t* first_slot;  // composed by content (clx_k_compose) -- and, per frame, the physical slot of its first subframe
+    uint32_t* fkey;          // scratch, per frame: the content class clx_k_scan found (clx_k_compose's sort key); null: no composition
     clx_crc_part* crc_part;  // scratch, per predictor slot: what the lean kernels' lanes found of their frame's CRC-16 (clx_crct.h)
     uint32_t* crc_todo;      // scratch, per frame: clx_k_finalize -> clx_k_crc16_runs: 1 = the stand-alone kernel has to check this frame
     uint32_t gen;
@@ -68,8 +71,17 @@ struct clx_run {
 #define CLX_RUN_CRC 1u
 struct clx_runs { clx_run r[CLX_MAX_MERGE]; };       // passed to the kernels by value
 
+// clx_k_compose: a window of consecutive stereo frames of one block size whose lanes are dealt by content class (clx_plan.h)
+#define CLX_COMPOSE_WINDOW 16384u
+#define CLX_COMPOSE_KEYS 32u
+#define CLX_COMPOSE_THREADS 512u
+struct clx_window { uint32_t f_lo, f_hi, s_lo, pad; };   // frames [f_lo, f_hi), physical slots from s_lo (= the first frame's canonical slot) on
+// content class of a stereo frame (clx_k_scan): bit 4 a constant / verbatim subframe, bits 3-2 the predictor order class, bits 1-0 the
+// channel assignment.  Sorting by it puts waves of one predictor build side by side.
+#define CLX_FKEY(special, order_class, assignment) (((special) ? 16u : 0u) | ((uint32_t)(order_class) << 2) | ((uint32_t)(assignment) & 3u))
+
 #ifdef __cplusplus
-static_assert(sizeof(clx_run) == 88, "clx_run layout");
+static_assert(sizeof(clx_run) == 112, "clx_run layout");
 static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
 static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
 // K1 writes the 16 bytes in front of `coef` as one store: {out_base | n, lim_log2, flags | order, shift, wasted, decor}

@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* r
 // when its subframes belong to the other kernel.
 template <bool HI>
 __device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_dev_frame* __restrict__ frames,
-                 const uint32_t* __restrict__ slot_frame, uint32_t n_slots, int32_t* __restrict__ dump_all) {
+                 uint32_t n_slots, int32_t* __restrict__ dump_all) {
     __shared__ LanesLds L;
     const clx_run& R = runs.r[blockIdx.y];
     if (R.taken != nullptr && R.taken[blockIdx.x] == R.gen) return;  // clx_k_lean (clx_lean.hip) decoded this group in this run
@@ -1072,13 +1072,14 @@ __device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_
     CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+    // (the run's slot map: the plan's, or what clx_k_compose dealt -- clx_lean.hip; the scan's results are indexed by the plan's slot)
     uint32_t f = 0xffffffffu;
-    if (slot < n_slots) f = slot_frame[slot];
+    if (slot < n_slots) f = R.slot_frame[slot];
     clx_dev_frame fr;
     fr.byte_off = 0; fr.out_off = 0; fr.limit_bits = 0; fr.first_slot = 0; fr.header_bytes = 0; fr.block_size = 0;
     fr.n_channels = 0; fr.channel_assignment = 0; fr.bps = 1; fr.flags = 0;
     if (f != 0xffffffffu) fr = frames[f];
-    const uint32_t ch = (f != 0xffffffffu) ? slot - fr.first_slot : 0u;
+    const uint32_t ch = (f != 0xffffffffu) ? slot - R.first_slot[f] : 0u;
     uint32_t bs = fr.block_size;
 
     LaneReader r;
@@ -1090,7 +1091,7 @@ __device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_
     r.err = 0u;
     bool active = (f != 0xffffffffu);
     if (active && ch != 0u) {
-        const uint32_t sp = sf_start[slot];
+        const uint32_t sp = sf_start[fr.first_slot + ch];
         if (sp == 0xffffffffu) active = false;           // an earlier channel failed (the scan reported it)
         else r.pos = sp;
     }
@@ -1135,14 +1136,14 @@ __device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_
     CLX_TL_END(3, blockIdx.x);
 }
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_lanes(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+void clx_k_lanes(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots,
                  int32_t* __restrict__ dump_all) {
-    clx_lanes_fused<false>(runs, frames, slot_frame, n_slots, dump_all);
+    clx_lanes_fused<false>(runs, frames, n_slots, dump_all);
 }
 extern "C" __global__ __launch_bounds__(64)
-void clx_k_lanes_hi(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
+void clx_k_lanes_hi(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots,
                     int32_t* __restrict__ dump_all) {
-    clx_lanes_fused<true>(runs, frames, slot_frame, n_slots, dump_all);
+    clx_lanes_fused<true>(runs, frames, n_slots, dump_all);
 }
 
 // ------------------------------------------------------------------------------------------------

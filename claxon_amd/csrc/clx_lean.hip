@@ -312,12 +312,15 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
 #pragma unroll
     for (int sx = 32; sx >= 1; sx >>= 1) { const uint32_t a = __shfl_xor(nch_max, sx, 64); nch_max = a > nch_max ? a : nch_max; }
 
+    bool k_special = false;                              // the frame's content class for clx_k_compose (CLX_FKEY): a constant / verbatim
+    uint32_t k_omax = 0;                                 // subframe among its channels, the highest predictor order
     for (uint32_t ch = 0; ch < nch_max; ++ch) {
         const bool on = ch < nch && !r.err;
         // ---- headers (per lane, generic reader)
         uint32_t codes = 0, first = 0, per = 0, parts_left = 0, rice2 = 0, order = 0;
         if (on) {
             const SfHead h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
+            if (!r.err) { k_special = k_special || h.kind < 2u; k_omax = h.order > k_omax ? h.order : k_omax; }
             if (!r.err) {
                 if (h.kind == 0u) (void)clx_lread(r, h.sf_bps);
                 else if (h.kind == 1u) {
@@ -402,6 +405,81 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
             if (r.err) clx_report_error(errkey, f, ch, r.err);
             else sf_start[fr.first_slot + ch + 1u] = r.pos;
         }
+    }
+    // ---- the frame's content class, with the last channel's header (the cursor stands in front of it)
+    if (active && R.fkey != nullptr) {
+        uint32_t key = CLX_COMPOSE_KEYS - 1u;            // (a frame that does not parse: the last class)
+        if (!r.err) {
+            LaneReader q = r;
+            const SfHead h = clx_lparse_sf_header(q, clx_channel_bps(fr, nch));
+            if (!q.err) {
+                k_special = k_special || h.kind < 2u; k_omax = h.order > k_omax ? h.order : k_omax;
+                const uint32_t oc = (k_omax <= 4u && !k_special) ? 0u : k_omax <= 8u ? 1u : k_omax <= 12u ? 2u : 3u;      // (clx_k_lean's builds)
+                key = CLX_FKEY(k_special, oc, fr.channel_assignment);
+            }
+        }
+        R.fkey[f] = key;
+    }
+}
+
+// ---- C: waves composed by content ---------------------------------------------------------------------------------------------
+// clx_k_compose: one workgroup per window (clx_plan_windows: up to 16 384 consecutive stereo frames of one block size), behind the
+// scan.  A stable counting sort of the window's frames by content class (clx_k_scan's key): frame of rank r takes the physical
+// slots s_lo + 2r, s_lo + 2r + 1 -- so a wave of 64 subframes holds one class (one predictor build, plain Rice turns, one stereo
+// form) instead of a sample of all of them.  Only the run's slot maps change (clx_run::slot_frame / first_slot); sf_start, crc_part
+// and the frames' places in `out` are indexed by what the PLAN says, as before.
+extern "C" __global__ __launch_bounds__(CLX_COMPOSE_THREADS)
+void clx_k_compose(const clx_runs runs, const clx_window* __restrict__ windows) {
+    __shared__ uint8_t keys[CLX_COMPOSE_WINDOW];
+    __shared__ uint16_t cnt[CLX_COMPOSE_KEYS][CLX_COMPOSE_THREADS];      // cnt[k][t]: frames of class k among thread t's, then the rank of its next one
+    __shared__ uint16_t wsum[CLX_COMPOSE_THREADS / 64][CLX_COMPOSE_KEYS];       // per wave: its threads' frames of each class
+    const clx_run& R = runs.r[blockIdx.y];
+    const clx_window W = windows[blockIdx.x];
+    uint32_t* const slot_frame = const_cast<uint32_t*>(R.slot_frame);
+    uint32_t* const first_slot = const_cast<uint32_t*>(R.first_slot);
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, n = W.f_hi - W.f_lo;
+    // (the classes, coalesced; eight loads in flight per thread: one after the other they would cost a memory round trip each)
+    for (uint32_t i0 = t; i0 < n; i0 += 8u * CLX_COMPOSE_THREADS) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) { const uint32_t i = i0 + CLX_COMPOSE_THREADS * q; v[q] = i < n ? R.fkey[W.f_lo + i] : 0u; }
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) { const uint32_t i = i0 + CLX_COMPOSE_THREADS * q; if (i < n) keys[i] = (uint8_t)(v[q] & (CLX_COMPOSE_KEYS - 1u)); }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < CLX_COMPOSE_KEYS; ++k) cnt[k][t] = 0;
+    __syncthreads();
+    // thread t owns the frames [lo, hi) of the window: a stable sort keeps them in this order inside every class
+    const uint32_t chunk = (n + CLX_COMPOSE_THREADS - 1u) / CLX_COMPOSE_THREADS, lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    for (uint32_t i = lo; i < hi; ++i) cnt[keys[i]][t] += 1u;           // (its own column: no other thread touches it)
+    // exclusive prefix over (class-major, thread-minor): inside the wave by shuffles, across the waves through LDS
+    uint32_t pre[CLX_COMPOSE_KEYS];
+#pragma unroll
+    for (uint32_t k = 0; k < CLX_COMPOSE_KEYS; ++k) {
+        const uint32_t c = cnt[k][t];
+        uint32_t x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if ((int)lane >= d) x += y; }
+        pre[k] = x - c;
+        if (lane == 63u) wsum[wave][k] = (uint16_t)x;
+    }
+    __syncthreads();
+    uint32_t run = 0;                                     // frames of the classes before k
+#pragma unroll
+    for (uint32_t k = 0; k < CLX_COMPOSE_KEYS; ++k) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < CLX_COMPOSE_THREADS / 64u; ++w) { const uint32_t p = wsum[w][k]; before += w < wave ? p : 0u; total += p; }
+        cnt[k][t] = (uint16_t)(pre[k] + run + before);
+        run += total;
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t k = keys[i];
+        const uint32_t rank = cnt[k][t];
+        cnt[k][t] = (uint16_t)(rank + 1u);
+        const uint32_t s = W.s_lo + 2u * rank, f = W.f_lo + i;
+        first_slot[f] = s;
+        *reinterpret_cast<uint2*>(slot_frame + s) = make_uint2(f, f);       // (s is even: the window starts at its first frame's slot)
     }
 }
 
@@ -935,7 +1013,7 @@ __device__ __forceinline__ bool cln_run24(const clx_buf& buf, LaneState<OMAX>& S
 // The kernels' common body.  SPLIT = false: clx_k_lean (<= 16-bit audio, <= 12 taps); true: clx_k_lean24 (<= 24-bit audio -- a side
 // channel has 25 --, <= 32 taps, the groups clx_k_lean left).
 template <bool SPLIT>
-__device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame,
+__device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, const clx_dev_frame* __restrict__ frames,
                                            uint32_t n_slots, int32_t* __restrict__ dump_all) {
     constexpr int OMAX = SPLIT ? 32 : 12;
     const clx_run& R = runs.r[blockIdx.y];
@@ -950,13 +1028,16 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     const uint32_t gen = R.gen;
     const int lane = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+    // (which frame this lane decodes: the run's slot map -- the plan's, or what clx_k_compose dealt; what the scan and the CRC parts
+    //  are indexed by is the PLAN's slot of the subframe, cslot)
     uint32_t f = 0xffffffffu;
-    if (slot < n_slots) f = slot_frame[slot];
+    if (slot < n_slots) f = R.slot_frame[slot];
     clx_dev_frame fr;
     fr.byte_off = 0; fr.out_off = 0; fr.limit_bits = 0; fr.first_slot = 0; fr.header_bytes = 0; fr.block_size = 0;
     fr.n_channels = 0; fr.channel_assignment = 0; fr.bps = 1; fr.flags = 0;
     if (f != 0xffffffffu) fr = frames[f];
-    const uint32_t ch = (f != 0xffffffffu) ? slot - fr.first_slot : 0u;
+    const uint32_t ch = (f != 0xffffffffu) ? slot - R.first_slot[f] : 0u;
+    const uint32_t cslot = fr.first_slot + ch;
     const uint32_t bs = fr.block_size;
 
     LaneReader r;
@@ -968,7 +1049,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     r.err = 0u;
     bool active = (f != 0xffffffffu);
     if (active && ch != 0u) {
-        const uint32_t sp = sf_start[slot];
+        const uint32_t sp = sf_start[cslot];
         if (sp == 0xffffffffu) active = false;             // an earlier channel failed (the scan reported it): decodes nothing
         else r.pos = sp;
     }
@@ -1016,7 +1097,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         const uint32_t eb = (o + fr.limit_bits) >> 3;      // the frame's end, in bytes from the origin
         uint32_t db = (eb >> 4) << 2;                      // (the last channel: the frame's whole granules; the rest is taken at the end)
         if (!crc_last) {
-            const uint32_t nsp = sf_start[slot + 1u];
+            const uint32_t nsp = sf_start[cslot + 1u];
             if (nsp == 0xffffffffu) crc_mine = false;      // (this subframe does not parse: the frame fails)
             db = (nsp >> 7) << 2;
         }
@@ -1136,21 +1217,19 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
             if (crc_last && te != 0u) { cln_crc_take_masked(CR, clx_buf_load16(buf, r.origin + 4u * db), 0u, te); db += 4u; }
             clx_crc_part part;
             part.gen = gen; part.rx = clx_crct_reduced(CR.c.r) | ((uint32_t)__popc(CR.c.x) << 31); part.da = crc_da; part.db = db;
-            R.crc_part[slot] = part;
+            R.crc_part[cslot] = part;
         }
     }
 }
 
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
-void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
-                int32_t* __restrict__ dump_all) {
+void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;
-    cln_kernel<false>(L, runs, frames, slot_frame, n_slots, dump_all);
+    cln_kernel<false>(L, runs, frames, n_slots, dump_all);
 }
 
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
-void clx_k_lean24(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ slot_frame, uint32_t n_slots,
-                  int32_t* __restrict__ dump_all) {
+void clx_k_lean24(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;
-    cln_kernel<true>(L, runs, frames, slot_frame, n_slots, dump_all);
+    cln_kernel<true>(L, runs, frames, n_slots, dump_all);
 }

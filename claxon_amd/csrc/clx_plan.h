@@ -95,4 +95,29 @@ static inline size_t clx_plan_lanes(const clx_dev_frame* dev, size_t n, uint64_t
     return n_multi;
 }
 
+// Windows of clx_k_compose: maximal runs of consecutive stereo frames of one block size and one width class (<= 16 bits or not),
+// cut every CLX_COMPOSE_WINDOW frames.  mode: 0 by content of the descriptors (a window is composed when it holds >= 256 frames and
+// its channel assignments differ), 1 every such window, -1 none.  `win` must hold n entries; returns their number.
+static inline size_t clx_plan_windows(const clx_dev_frame* dev, size_t n, int mode, clx_window* win) {
+    size_t nw = 0;
+    if (mode < 0) return 0;
+    size_t i = 0;
+    while (i < n) {
+        if (dev[i].n_channels != 2) { ++i; continue; }
+        size_t j = i;
+        bool mixed = false;
+        while (j < n && j - i < CLX_COMPOSE_WINDOW && dev[j].n_channels == 2 && dev[j].block_size == dev[i].block_size &&
+               (dev[j].bps <= 16) == (dev[i].bps <= 16) && dev[j].first_slot == dev[i].first_slot + 2u * (uint32_t)(j - i)) {
+            mixed = mixed || dev[j].channel_assignment != dev[i].channel_assignment;
+            ++j;
+        }
+        if (j - i >= 64 && (dev[i].first_slot & 1u) == 0u && (mode > 0 || (mixed && j - i >= 256))) {       // (an even first slot: pairs stay pairs)
+            win[nw].f_lo = (uint32_t)i; win[nw].f_hi = (uint32_t)j; win[nw].s_lo = dev[i].first_slot; win[nw].pad = 0;
+            ++nw;
+        }
+        i = j;
+    }
+    return nw;
+}
+
 #endif

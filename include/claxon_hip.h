@@ -201,7 +201,16 @@ enum {
      * aligned rows), then clx_k_lean24 (the split tier: <= 24 bits, <= 32 taps) when the batch holds frames of more than 16 bits,
      * and the general kernels on the groups those leave.  This flag leaves the tiers out: every group goes through the general
      * kernels (test and comparison target). */
-    CLX_LANES_GENERAL   = 1u << 10
+    CLX_LANES_GENERAL   = 1u << 10,
+    /* Waves composed by content (fused lane build; round 4).  A wave of 64 subframes runs the predictor build of its HIGHEST order,
+     * the masked form of its turns when ONE lane holds a constant or verbatim subframe, the generic stereo form unless ALL its
+     * pairs are mid/side -- so behind the scan a small kernel (clx_k_compose) re-deals the frames of a window (up to 16 384 stereo
+     * frames of one block size) to the lanes by class: predictor order <= 4 / <= 8 / <= 12 / more, constant or verbatim subframes,
+     * channel assignment.  Which frame a lane decodes changes, nothing else: every frame still goes to its own place in `out`.
+     * Default: on for windows whose descriptors differ in their channel assignment (streams as encoders write them), off where
+     * every descriptor is the same (synthetic batches of one shape).  These flags force it on / off. */
+    CLX_COMPOSE         = 1u << 11,
+    CLX_NO_COMPOSE      = 1u << 12
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32

@@ -16,12 +16,14 @@ def ctx():
 
 
 @pytest.fixture(scope="module", params=[cx.PATH_WAVES | cx.K2_LATENCY, cx.PATH_WAVES | cx.K2_THROUGHPUT, cx.PATH_LANES | cx.LANES_SPLIT,
-                                        cx.PATH_LANES | cx.LANES_FUSED, cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL],
-                ids=["waves", "waves-1w", "lanes", "lanes-fused", "lanes-general"])
+                                        cx.PATH_LANES | cx.LANES_FUSED, cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL,
+                                        cx.PATH_LANES | cx.LANES_FUSED | cx.COMPOSE],
+                ids=["waves", "waves-1w", "lanes", "lanes-fused", "lanes-general", "lanes-composed"])
 def gpu(ctx, request):
     """Both kernel paths, every build of each: wave-per-frame (clx_kernels.hip) with the multi-wave and the one-wave
     predictor kernels, lane-per-subframe (clx_lanes.hip) with the split and the fused decode kernels -- the fused build with the
-    lean 16-bit tier (clx_k_lean, clx_lean.hip) in front of the general kernels, and with the general kernels alone."""
+    lean 16-bit tier (clx_k_lean, clx_lean.hip) in front of the general kernels, with the general kernels alone, and with the waves
+    composed by content (clx_k_compose: every window of stereo frames dealt to the lanes by class)."""
     return GpuBackend(ctx, request.param)
 
 

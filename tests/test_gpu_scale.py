@@ -331,6 +331,45 @@ def test_pipelined_submissions_of_the_lane_kernels(oracle, ctx):
         assert np.array_equal(o.cpu().numpy(), ref)
 
 
+def test_composed_waves_at_scale(oracle, ctx):
+    """12 288 mixed config-5 frames through pipelined submissions with the waves composed by content (the default for a batch whose
+    descriptors differ in their channel assignment: two windows of clx_k_compose): every buffer, status, message and end bit against
+    the oracle; the same in stream order (CLX_NO_COMPOSE); and a profiled run shows clx_k_compose in the chain."""
+    import torch
+    w = synth.config5_unique(12288)
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.array_equal(ref, w.pcm)
+    d_ref = torch.from_numpy(ref).to("cuda:0")
+    for flags in (0, cx.NO_COMPOSE):
+        batch = ctx.plan(descs, w.out_offs, verify_crc=True, path=flags)
+        assert batch.submit_lanes
+        depth = min(batch.submit_depth, 6)
+        outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(depth)]
+        st = torch.cuda.current_stream().cuda_stream
+        for i in range(batch.submit_depth + 3):
+            batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+        batch.flush(st)
+        torch.cuda.synchronize()
+        res = batch.results()
+        assert np.array_equal(res["status"], r["statuses"]) and np.all(res["status"] == cx.OK)
+        assert np.array_equal(res["msg"], r["msgs"]) and np.array_equal(res["end_bit"], r["end_bits"])
+        for k, o in enumerate(outs):
+            assert bool(torch.equal(o, d_ref)), "output buffer %d differs from the oracle (flags %d)" % (k, flags)
+        batch.close()
+        bl = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED | flags)
+        bl.set_profiling(True)
+        outs[0].fill_(0x13131313)
+        bl.run(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+        torch.cuda.synchronize()
+        kt = bl.kernel_times()
+        assert ("clx_k_compose" in kt) == (flags == 0), sorted(kt)
+        assert bool(torch.equal(outs[0], d_ref))
+        bl.close()
+
+
 def test_device_indexer_against_oracle_offsets(oracle, ctx):
     """clx_index_frames_device against the frame starts the ORACLE's reader walks through (oracle.decode_stream), not
     against the product's own host indexer: a 3 MB raw stream of mixed frames, with and without a garbage tail."""

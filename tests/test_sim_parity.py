@@ -14,10 +14,12 @@ import claxon_amd as cx
 
 
 @pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED,
-                                        cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL], ids=["waves", "lanes", "lanes-fused", "lanes-general"])
+                                        cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL, cx.PATH_LANES | cx.LANES_FUSED | cx.COMPOSE],
+                ids=["waves", "lanes", "lanes-fused", "lanes-general", "lanes-composed"])
 def sim(request):
     """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip: split build, fused build with
-    the lean 16-bit tier clx_k_lean in front, fused build with the general kernels alone)."""
+    the lean 16-bit tier clx_k_lean in front, fused build with the general kernels alone, fused build with every window of stereo
+    frames dealt to the lanes by content class -- clx_k_compose, round 4)."""
     import simlib
     simlib.build()
     return SimBackend(request.param)
@@ -289,3 +291,33 @@ def test_sim_groups_given_up_by_the_lean_kernel(oracle):
     given_up, taken = stats[57] // 64, stats[52]
     assert (given_up, taken) == (2, 2), (given_up, taken)                  # four waves: two stay with clx_k_lean, two are given up
     assert (stats[14], stats[15]) == (64, 64), (stats[14], stats[15])      # CRC-16: the lanes' own gathering | the stand-alone kernel's
+
+
+def test_sim_waves_composed_by_content(oracle):
+    """clx_k_compose (round 4): behind the scan the frames of a window are dealt to the lanes by content class -- predictor order
+    class, constant / verbatim subframes, channel assignment -- so a wave holds one class.  Same samples, statuses and end bits as
+    in stream order (the simulator harness also checks that what was dealt is a permutation of the plan's slot pairs inside the
+    windows); far fewer wide turns on the mixed workload (one loud or verbatim lane no longer moves a wave of 63 others); and the
+    default composes a batch whose descriptors differ in their channel assignment, not one of a single shape."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+
+    def counted(w, flags):
+        for i in range(64):
+            stats[i] = 0
+        pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | flags), w, verify_crc=True)
+        return int(stats[48]), int(stats[50]) // 64, int(stats[58]) // 64          # windows composed, lean turns, wide turns
+
+    w5 = synth.config5_unique(256)
+    win0, lean0, wide0 = counted(w5, cx.NO_COMPOSE)
+    win1, lean1, wide1 = counted(w5, cx.COMPOSE)
+    assert win0 == 0 and win1 == 1
+    assert lean0 + wide0 == lean1 + wide1 and wide1 < 0.6 * wide0, (lean0, wide0, lean1, wide1)
+    assert counted(w5, 0)[0] == 1                                  # mixed channel assignments: composed by default
+    assert counted(synth.config3(300), 0)[0] == 0                  # one shape: left in stream order
+    assert counted(synth.config3(70), cx.COMPOSE)[0] == 1          # (forced: still exact)
+    # windows end where the block size, the width class or the channel count changes; mono and multi-channel frames stay where they are
+    wm = synth.concat("mixed shapes", [synth.config5_unique(80), synth.config4(70), synth.small_mixed(40), synth.config3(66)])
+    assert counted(wm, cx.COMPOSE)[0] >= 3

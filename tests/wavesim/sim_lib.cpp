@@ -39,6 +39,14 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         std::vector<uint32_t> crc_todo(n ? n : 1, 0xa5a5a5a5u);
         runs.r[0].crc_part = crc_part.data(); runs.r[0].crc_todo = crc_todo.data();
         runs.r[0].flags = (flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u;
+        // the run's slot maps: the plan's, or its own when waves are composed by content (as the library does: clx_plan_windows)
+        std::vector<uint32_t> first_slot(n ? n : 1, 0u), fkey(n ? n : 1, 0u);
+        for (size_t i = 0; i < n; ++i) first_slot[i] = dev[i].first_slot;
+        std::vector<clx_window> windows(n ? n : 1);
+        const int cmode = (!lean || (flags & CLX_NO_COMPOSE)) ? -1 : (flags & CLX_COMPOSE) ? 1 : 0;
+        const size_t n_windows = clx_plan_windows(dev.data(), n, cmode, windows.data());
+        std::vector<uint32_t> slot_frame_plan = slot_frame, first_slot_plan = first_slot;      // (what must stay untouched)
+        runs.r[0].slot_frame = slot_frame.data(); runs.r[0].first_slot = first_slot.data(); runs.r[0].fkey = n_windows ? fkey.data() : nullptr;
         if (n_multi) {
             if (flags & CLX_LANES_GENERAL) SIM_LAUNCH(clx_k_scan_general, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
             else SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
@@ -46,19 +54,37 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         // CLX_LANES_FUSED: the fused kernels; otherwise the two-wave one
         if (flags & CLX_LANES_FUSED) {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 32 + 16);
+            if (n_windows && n_multi) {
+                SIM_LAUNCH(clx_k_compose, n_windows, CLX_COMPOSE_THREADS, runs, windows.data());
+                sim_stats[48] += n_windows;
+                // what it dealt is a permutation of the plan's pairs inside each window, and nothing outside them moved
+                std::vector<uint8_t> seen(n ? n : 1, 0);
+                for (size_t wi = 0; wi < n_windows; ++wi)
+                    for (uint32_t f = windows[wi].f_lo; f < windows[wi].f_hi; ++f) {
+                        const uint32_t s0 = first_slot[f];
+                        if (s0 < windows[wi].s_lo || s0 + 1u >= windows[wi].s_lo + 2u * (windows[wi].f_hi - windows[wi].f_lo) || ((s0 - windows[wi].s_lo) & 1u) ||
+                            slot_frame[s0] != f || slot_frame[s0 + 1u] != f) return CLX_API_ERROR;
+                        seen[f] = 1;
+                    }
+                for (size_t i = 0; i < n; ++i) if (!seen[i] && first_slot[i] != first_slot_plan[i]) return CLX_API_ERROR;
+                for (uint64_t sl = 0; sl < n_slots; ++sl) {
+                    const uint32_t f = slot_frame[sl];
+                    if (f == 0xffffffffu ? slot_frame_plan[sl] != 0xffffffffu : (sl < first_slot[f] || sl >= first_slot[f] + dev[f].n_channels)) return CLX_API_ERROR;
+                }
+            }
             // the lean kernel first (it marks the groups it decodes with this run's generation number), unless the caller
             // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
-            if (lean) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
+            if (lean) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
             for (uint32_t t : taken) sim_stats[52] += t == runs.r[0].gen;
             if (lean) {     // the split tier on what is left (the library launches it when the batch holds frames of more than 16 bits)
                 uint64_t before = 0, after = 0;
                 for (uint32_t t : taken) before += t == runs.r[0].gen;
-                SIM_LAUNCH(clx_k_lean24, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
+                SIM_LAUNCH(clx_k_lean24, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
                 for (uint32_t t : taken) after += t == runs.r[0].gen;
                 sim_stats[13] += after - before;
             }
-            SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
-            SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, runs, dev.data(), slot_frame.data(), (uint32_t)n_slots, dump.data());
+            SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
+            SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
         } else {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,

@@ -24,6 +24,8 @@
 #define __launch_bounds__(...)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint2 { uint32_t x, y; } __attribute__((aligned(8)));
+static inline uint2 make_uint2(uint32_t a, uint32_t b) { uint2 v; v.x = a; v.y = b; return v; }
 struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { uint4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }
 
