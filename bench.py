@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-crc", action="store_true", help="time the step WITHOUT the CRC-16 check (secondary figure; `value` verifies by default)")
     ap.add_argument("--path", choices=["auto", "waves", "lanes", "lanes-fused", "lanes-general"], default="auto",
                     help="kernel path (default: library's choice); lanes-general = the fused lane build without the 16-bit tier clx_k_lean")
+    ap.add_argument("--order", type=int, default=0, help="config4 only: another predictor order than BASELINE's 32 (12: the split tier's <= 12-tap kernel)")
     ap.add_argument("--compose", choices=["auto", "on", "off"], default="auto",
                     help="waves composed by content (clx_k_compose): the library's choice by the descriptors, or forced on / off")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process group backend for the barrier and the MAX / SUM reductions (nccl = RCCL)")
@@ -387,6 +388,8 @@ def _rank_share(args, synth, shard, sh_world, sh_rank, generate=True):
     else:
         lo, hi = sh_rank * args.frames, (sh_rank + 1) * args.frames
         gen = {"config2": synth.config2, "config3": synth.config3, "config4": synth.config4}[args.workload]
+        if args.workload == "config4" and args.order:
+            gen = lambda n, _o=args.order: synth.config4(n, order=_o)
         w = _seeded(synth, gen, args.frames, lo) if generate else None
         # the ranges are what balanced_ranges gives for the job's index: every frame of these shapes has the same decoded size
         # and (to within a percent) the same compressed size; the measured imbalance is carried in the line
@@ -397,6 +400,8 @@ def _rank_share(args, synth, shard, sh_world, sh_rank, generate=True):
             "config3": "BASELINE configs[2]: %d stereo 16-bit frames/GPU, bs 4096, mid/side, LPC order 8 (coefficient precision 12-14), Rice partition order 4, optimal k",
             "config4": "BASELINE configs[3]: %d stereo 24-bit frames/GPU, bs 4096, LPC order 32, mixed partition orders 0-7, Rice2, wasted bits",
         }[args.workload] % args.frames
+        if args.workload == "config4" and args.order:
+            workload_name = workload_name.replace("LPC order 32", "LPC order %d (NOT the BASELINE shape: --order)" % args.order)
         scaling = "weak"
     return w, ts, shard_info, workload_name, scaling
 

@@ -213,9 +213,10 @@ def config3(n=10000, bs=4096, order=8, precision=None, partition_order=4):
                          pcm, 2, bs, 16, fps)
 
 
-def config4(n=10000, bs=4096):
+def config4(n=10000, bs=4096, order=32):
     """24-bit stereo, LPC order 32 (precision 15), mixed channel assignments, partition order 0-8
-    per subframe, wasted bits in {0,0,4,8}; side channel at 25 bps => i64 accumulator mandatory."""
+    per subframe, wasted bits in {0,0,4,8}; side channel at 25 bps => i64 accumulator mandatory.
+    `order`: the same with another predictor order (12: what 24-bit music usually carries; the split tier's <= 12-tap kernel)."""
     pcm = np.empty((n, 2, bs), dtype=np.int32)
     fps = []
     t = np.arange(bs)
@@ -236,9 +237,9 @@ def config4(n=10000, bs=4096):
         for c in range(2):
             # drawn 0-8 as SURVEY §8(d) says; order 32 needs >= 32 samples in the first partition
             # (subframe.rs:275-277), so 8 (16 samples/partition) is clamped to 7
-            fp.sf[c] = sf(SF_LPC, 32, 15, min(int(g.integers(0, 9)), 7))
+            fp.sf[c] = sf(SF_LPC, order, 15, min(int(g.integers(0, 9)), 7))
         fps.append(fp)
-    return encode_frames("config4: %d stereo frames bs=%d 24-bit LPC-32 P0-8 wasted" % (n, bs), pcm, 2, bs, 24, fps)
+    return encode_frames("config4: %d stereo frames bs=%d 24-bit LPC-%d P0-8 wasted" % (n, bs, order), pcm, 2, bs, 24, fps)
 
 
 def pcm_music_like(index, n, bits=16):
