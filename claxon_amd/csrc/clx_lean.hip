@@ -143,6 +143,14 @@ __device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32
     if (room >= 8) { g.pb = clx_buf_load16(buf, g.origin + 4u * g.fill + 16u); g.np = 2u; }
     if (room >= 12) { g.pc = clx_buf_load16(buf, g.origin + 4u * g.fill + 32u); g.np = 3u; }
 }
+// The ring is pumped (landing + requests) every OTHER turn in CALM waves: at 5 bits per code a lane uses a granule in 1.6 turns,
+// and the wave paid for a landing, a CRC step and three request blocks per turn as soon as ONE lane had something in flight.
+// Calm is decided once, where the subframes' sizes are known (cln_kernel: every lane's subframe holds at most 7 bits per
+// sample; the scan: its frames do): such lanes keep two turns' worth landed beyond their cursors in a ring of 24 dwords.  A burst
+// inside a calm subframe runs the ring dry and is refilled on the spot, as always.  Deciding it turn by turn from the lanes' rates
+// was measured too (tools/r04_call8.sh, r04_call9.sh): the same gain on config 3, but the bookkeeping cost the waves that are never
+// calm (configs 4 and 5) 1.5-5 %.
+__device__ __forceinline__ bool cln_pump_now(bool calm, bool even) { return !calm || even; }
 // slot of stream dword d, for d in [fill - RING, fill)
 __device__ __forceinline__ uint32_t cln_slot(const LRing& g, uint32_t d) {
     const uint32_t t = g.fs + d - g.fill;                                 // fs - (fill - d), negative (wrapped) when it wraps
@@ -307,6 +315,8 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
     LKind KR;                                            // (the careful reader's view: every lane skips Rice codes)
     KR.rice = true; KR.verb = false; KR.bitmask = 0xffffffffu; KR.ricemask = 0xffffffffu; KR.verbmask = 0u; KR.cor = 0u; KR.vsh = 0u; KR.vshm = 0u;
     const uint32_t bs = fr.block_size;
+    // (a calm wave -- no frame above 7 bits per sample over all its channels: the ring is pumped every other turn, cln_pump_now)
+    const bool calm = __all(!active || fr.limit_bits <= 7u * bs * (uint32_t)fr.n_channels);
     uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
     uint32_t nch_max = nch;
 #pragma unroll
@@ -364,14 +374,15 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
             }
             if (r.err) left = 0u;
         }
-        bool ring_ok = false;
+        bool ring_ok = false, even = false;
 #pragma unroll 1
         while (__any(left >= 16u && !r.err)) {
             const bool has = left >= 16u && !r.err;          // this lane has sixteen codes to skip
             const bool live = has && ring_able;
             const LCur keep = cur;                           // (a lane without them rides along where it is: its ring stays consistent)
-            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); ring_ok = true; }
-            else { cln_land(g, row, NC, false); cln_request(buf, g, cur.p); }
+            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); ring_ok = true; even = false; }
+            else if (cln_pump_now(calm, even)) { cln_land(g, row, NC, false); cln_request(buf, g, cur.p); }
+            even = !even;
             int done = 0;
             bool refilled = false;
             if (__all(live || !has)) {
@@ -673,7 +684,9 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             // one Rice code (subframe.rs:337-341): z zeros, a one, k remainder bits = 32 - sh bits
-            // (v_ffbh + v_min; a sentinel bit under the code instead of the clamp measured no faster: tools/gpu_ab.sh)
+            // (v_ffbh + v_min; a sentinel bit under the code instead of the clamp measured no faster: tools/gpu_ab.sh.  Round 4: v_ffbh taken
+            //  as it comes -- 0xffffffff for a zero register -- with one "was any register zero" per turn saves the sixteen v_min, but the
+            //  instruction has to be an asm statement then, which the compiler schedules around blindly: the pipelined step +15 %)
             const uint32_t z = (uint32_t)__clz((int)wa);
             int32_t sh = (int32_t)(c14 - z);
             const uint32_t u = (z << kk) | clx_bfe(wa, (uint32_t)sh, k4);
@@ -703,16 +716,19 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             int32_t acc = 0;
             int32_t pred;
             if (SPLIT) {
-                int32_t ah = 0;
+                // (the oldest pair's term starts each chain: the VOP3P form with a constant 0 addend -- no v_mov per chain)
+                acc = clx_sdot2_first(C[NP - 1], P[NH + i - 1 - 2 * (NP - 1)]);
+                int32_t ah = clx_sdot2_first(C[NP - 1], PH[(SPLIT ? NH + i - 1 - 2 * (NP - 1) : 0)]);
 #pragma unroll
-                for (int q = NP - 1; q >= 0; --q) {
+                for (int q = NP - 2; q >= 0; --q) {
                     acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
                     ah = clx_sdot2(C[q], PH[(SPLIT ? NH + i - 1 - 2 * q : 0)], ah);
                 }
                 pred = (int32_t)(((uint32_t)ah << e1) + (uint32_t)(acc >> shift)) >> e3;
             } else if (!WIDE) {
+                acc = clx_sdot2_first(C[NP - 1], P[NH + i - 1 - 2 * (NP - 1)]);
 #pragma unroll
-                for (int q = NP - 1; q >= 0; --q) acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
+                for (int q = NP - 2; q >= 0; --q) acc = clx_sdot2(C[q], P[NH + i - 1 - 2 * q], acc);
                 pred = acc >> shift;
             } else {
 #pragma unroll
@@ -778,7 +794,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
                                          const uint32_t (&C)[NP], const int32_t (&CW)[2 * NP], uint32_t order, uint32_t shift, int32_t lim, int32_t lim24,
                                          uint32_t per, uint32_t rice2,
                                          uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane,
-                                         LCrc& CR, bool crc) {
+                                         LCrc& CR, bool crc, bool calm) {
 
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;      // (eight neighbouring lanes' 16-byte stage stores then cover all 32 banks)
     bool slow = true;                                    // H holds i32 samples (the prologue leaves them so)
@@ -800,7 +816,10 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             }
         }
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
-        else { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p); }
+        else if (cln_pump_now(calm, (t0 & 16u) == 0u)) {      // (the turns at whose start a pair of tiles leaves: the stores stay right in front of the landing's wait)
+            cln_land(g, row, CR, crc); cln_request(buf, g, cur.p);
+            CLX_STAT(46, 1);
+        }
         const bool was_slow = slow;                      // (no lean turn is tried: the history does not fit the packed form)
         int done = 0;
         bool refilled = false;                           // the ring was refilled on the spot once in this turn (a lane outran it)
@@ -872,7 +891,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
 // LPC / fixed parameters of a lane after the prologue, in the lean kernel's form
 template <int NP>
 __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LRing& g, uint32_t* row, int4* stage, uint32_t n, uint32_t i0, uint32_t nmax,
-                                        const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane, LCrc& CR, bool crc) {
+                                        const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane, LCrc& CR, bool crc, bool calm) {
     uint32_t C[NP], H[2 * NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) C[q] = ((uint32_t)S.c[2 * q] << 16) | ((uint32_t)S.c[2 * q + 1] & 0xffffu);
@@ -892,7 +911,7 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     // the 24-bit evaluation's range (clx_ltransition), under the same cap for subframes without taps
     const int32_t lim24a = S.order == 0u ? (1 << 29) : S.lim;
     const int32_t lim24 = lim24a < cap ? lim24a : cap;
-    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, CW, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
+    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, CW, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
 }
@@ -923,7 +942,7 @@ template <int NP, int OMAX>
 __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, const int32_t (&hist0)[OMAX],
                                            const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, uint32_t per, uint32_t rice2,
                                            uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane,
-                                           LCrc& CR, bool crc) {
+                                           LCrc& CR, bool crc, bool calm) {
     constexpr int NH = 2 * NP - 1;
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
     const uint32_t e1 = shift <= 12u ? 12u - shift : 0u, e2 = shift <= 12u ? shift : 12u, e3 = shift <= 12u ? 0u : shift - 12u;
@@ -947,7 +966,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
         int4* const mine = cln_mine(stage, t0, lane);
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
-        else { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p); }
+        else if (cln_pump_now(calm, (t0 & 16u) == 0u)) { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p); }
         {
             bool refilled = false;
           again:
@@ -992,7 +1011,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
 
 template <int NP, int OMAX>
 __device__ __forceinline__ bool cln_run24(const clx_buf& buf, LaneState<OMAX>& S, LRing& g, uint32_t* row, int4* stage, uint32_t n, uint32_t i0, uint32_t nmax,
-                                          const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane, LCrc& CR, bool crc) {
+                                          const LKind& K, const Finish& F, const LMover& M, LTile& T, int lane, LCrc& CR, bool crc, bool calm) {
     static_assert(2 * NP <= OMAX, "taps");
     uint32_t C[NP];
 #pragma unroll
@@ -1005,7 +1024,7 @@ __device__ __forceinline__ bool cln_run24(const clx_buf& buf, LaneState<OMAX>& S
     const int32_t cap = (1 << 29) >> (int)F.wasted;
     const int32_t lim0 = S.order == 0u ? (1 << 29) : S.lim > (1 << 15) ? (1 << 27) : (int32_t)((uint32_t)(S.lim - 1) << 12);
     const int32_t lim = lim0 < cap ? lim0 : cap;
-    const bool done = cln_body24<NP, OMAX>(buf, S.r, g, row, stage, cur, S.hist, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, F, M, T, lane, CR, crc);
+    const bool done = cln_body24<NP, OMAX>(buf, S.r, g, row, stage, cur, S.hist, C, S.order, S.shift, lim, S.per, S.rice2, n, i0, nmax, K, F, M, T, lane, CR, crc, calm);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
 }
@@ -1087,19 +1106,24 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     //      gives it; the first granule of the frame is the first channel's, taken here with the bytes in front of the frame masked
     const clx_buf buf = clx_make_buf(arena, (uint32_t)arena_alloc_len);
     const bool crc = (R.flags & CLX_RUN_CRC) != 0u;       // wave-uniform
+    // (where the next subframe starts: the end of this lane's share of the frame's CRC, and how many bits its subframe holds)
+    const bool last_ch = active && ch + 1u == (uint32_t)fr.n_channels;
+    const uint32_t next_sp = (active && !last_ch) ? sf_start[cslot + 1u] : 0xffffffffu;
+    // a calm wave: no lane's subframe holds more than 7 bits per sample -- its ring is pumped every other turn (cln_pump_now)
+    const uint32_t sf_bits = !active ? 0u : last_ch ? o + fr.limit_bits - pos0 : next_sp - pos0;       // (a failed or unbounded one: huge)
+    const bool calm = __all(sf_bits <= 7u * bs);
     LCrc CR;
     CR.c.r = 0u; CR.c.x = 0u; CR.next = 0u; CR.db = CLN_CRC_NONE;
     bool crc_mine = false, crc_last = false;
     uint32_t crc_da = 0u;
     if (crc && active && !(fr.flags & 1u)) {               // (a bare subframe has no footer)
         crc_mine = true;
-        crc_last = ch + 1u == (uint32_t)fr.n_channels;
+        crc_last = last_ch;
         const uint32_t eb = (o + fr.limit_bits) >> 3;      // the frame's end, in bytes from the origin
         uint32_t db = (eb >> 4) << 2;                      // (the last channel: the frame's whole granules; the rest is taken at the end)
         if (!crc_last) {
-            const uint32_t nsp = sf_start[cslot + 1u];
-            if (nsp == 0xffffffffu) crc_mine = false;      // (this subframe does not parse: the frame fails)
-            db = (nsp >> 7) << 2;
+            if (next_sp == 0xffffffffu) crc_mine = false;  // (this subframe does not parse: the frame fails)
+            db = (next_sp >> 7) << 2;
         }
         if (db < 4u) { if (crc_last) crc_mine = false; db = 4u; }      // (a frame that ends inside its first granule: the stand-alone kernel's)
         crc_da = ch == 0u ? 0u : (pos0 >> 7) << 2;
@@ -1182,12 +1206,12 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         if constexpr (SPLIT) {
             // the split evaluation needs sum|c| < 2^19 (S.lim >= 4096) -- any <= 32 coefficients of <= 15 bits but the all -2^14 row
             if (__any(lv && S.order != 0u && S.lim < 4096)) done = false;
-            else if (omax <= 12u) done = cln_run24<6, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane, CR, crc);
-            else                  done = cln_run24<16, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane, CR, crc);
+            else if (omax <= 12u) done = cln_run24<6, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane, CR, crc, calm);
+            else                  done = cln_run24<16, OMAX>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, F, M, T, lane, CR, crc, calm);
         } else {
-            if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
-            else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
-            else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc);
+            if (omax <= 4u && mode == 0) done = cln_run<2>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
+            else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
+            else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
         }
         if (!done) {                                       // given up: clx_k_lanes decodes the group
             if (lane == 0) taken[blockIdx.x] = 0u;

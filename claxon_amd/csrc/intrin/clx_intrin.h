@@ -97,6 +97,15 @@ typedef short clx_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t clx_sdot2(uint32_t a, uint32_t b, int32_t acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(clx_short2, a), __builtin_bit_cast(clx_short2, b), acc, false);
 }
+// The first term of a chain, acc = a.lo16 * b.lo16 + a.hi16 * b.hi16: the VOP3P form with the constant 0 as its addend.  The builtin
+// becomes v_dot2c_i32_i16 (VOP2: the accumulator is also the destination), which costs a v_mov to clear the accumulator for
+// every sample -- one instruction in thirty.  (Nothing has to sit between a v_dot2 and a reader of its result on gfx950:
+// tools/ubench/dot2_hazard.hip.)
+__device__ __forceinline__ int32_t clx_sdot2_first(uint32_t a, uint32_t b) {
+    int32_t d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 // Raw buffer over the arena: 32-bit byte offsets per lane against one wave-uniform descriptor, and loads that reach past the
 // end of the allocation return zeros instead of faulting (what a lane with a damaged frame descriptor may ask for).
 typedef uint32_t clx_u32x4 __attribute__((ext_vector_type(4)));

