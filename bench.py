@@ -118,7 +118,7 @@ def main():
     # consecutive steps are submitted with up to batch.submit_depth of them in flight (clx_batch_submit: each step a whole run on
     # an internal stream of the library), so they rotate over that many output buffers -- when there is room for them
     depth = batch.submit_depth
-    pipelined = (not args.no_pipeline) and depth > 1 and depth * 4 * w.total_samples < 64 * (1 << 30)
+    pipelined = (not args.no_pipeline) and depth > 1 and depth * 4 * w.total_samples < 128 * (1 << 30)
     outs = [d_out] + ([torch.zeros(w.total_samples, dtype=torch.int32, device=dev) for _ in range(depth - 1)] if pipelined else [])
     # the steps in flight read DISTINCT copies of the compressed input (same bytes, different addresses), so that no step finds the
     # input of its neighbour in a cache: every step's compressed bytes come from HBM, as roofline.achieved assumes
@@ -181,7 +181,7 @@ def main():
     #      tools/merge_probe.py shows (profiles/r03_config3_merged12_kernel_stats.csv)
     merged = None
     if pipelined and batch.submit_lanes:
-        n_merge = max(1, depth // 2)
+        n_merge = max(1, batch.submit_merge)
         batch.set_profiling(2)
         acc = {}
         reps = 3
@@ -298,7 +298,7 @@ def main():
            "bit_exact": True, "bit_exact_checked": "every output buffer vs the source PCM before the timed steps, and again -- on buffers cleared in between -- after them",
            "crc16_in_step": bool(with_crc), "kernel_path": args.path, "compose": args.compose, "gen_seconds": round(gen_s, 1),
            "steps_in_flight": depth if pipelined else 1, "distinct_input_copies_in_flight": len(arenas),
-           "merged_launches_per_region": _launch_sizes(args.steps, batch.submit_depth) if (pipelined and batch.submit_lanes) else None,
+           "merged_launches_per_region": _launch_sizes(args.steps, batch.submit_merge) if (pipelined and batch.submit_lanes) else None,
            "devices": args.devices or None,
            "value_basis": ("throughput of consecutive steps (one 10 000-frame batch each), up to %d in flight on the library's internal streams; "
                            "config.one_step_at_a_time is a single batch's latency" % depth) if pipelined else "one step at a time",
@@ -362,9 +362,9 @@ def _device_of(devices, local_rank):
     return ds[local_rank % len(ds)]
 
 
-def _launch_sizes(steps, depth):
-    """How the steps of one timed region go out: the library merges consecutive submissions, depth / 2 per grid (two streams)."""
-    m = max(1, depth // 2)
+def _launch_sizes(steps, merge):
+    """How the steps of one timed region go out: the library merges consecutive submissions, `merge` per grid (two streams in turn)."""
+    m = max(1, merge)
     return [m] * (steps // m) + ([steps % m] if steps % m else [])
 
 

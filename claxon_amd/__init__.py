@@ -87,7 +87,7 @@ assert FRAME_HEADER_DTYPE.itemsize == C.sizeof(FrameHeader) == 24
 EXPORTS = [
     "clx_message", "clx_message_status", "clx_version", "clx_parse_frame_header", "clx_crc8", "clx_crc16",
     "clx_create", "clx_destroy", "clx_last_error", "clx_decode_frames", "clx_decode_frames_multi", "clx_decode_frames_stream", "clx_set_stream_chunk", "clx_host_alloc", "clx_host_free", "clx_decode_subframes", "clx_interleave",
-    "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_submit_depth", "clx_batch_submit_lanes", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
+    "clx_batch_create", "clx_batch_run", "clx_batch_submit", "clx_batch_submit_depth", "clx_batch_submit_lanes", "clx_batch_submit_merge", "clx_batch_flush", "clx_batch_interleave", "clx_batch_results", "clx_batch_slots", "clx_batch_set_profiling",
     "clx_batch_kernel_ms", "clx_batch_kernel_name", "clx_batch_destroy", "clx_read_stream_header", "clx_read_stream_header_ext",
     "clx_tags_vendor", "clx_tags_count", "clx_tags_get", "clx_tags_lookup", "clx_tags_free", "clx_reader_tags", "clx_reader_open", "clx_reader_new",
     "clx_reader_streaminfo", "clx_reader_next_block", "clx_reader_close", "clx_index_frames", "clx_index_frames_device",
@@ -162,6 +162,8 @@ def lib():
     L.clx_batch_flush.argtypes = [vp, vp]
     L.clx_batch_submit_depth.argtypes = [vp]
     L.clx_batch_submit_lanes.argtypes = [vp]
+    L.clx_batch_submit_merge.argtypes = [vp]
+    L.clx_batch_submit_merge.restype = C.c_int
     L.clx_batch_results.argtypes = [vp, vp]
     L.clx_batch_interleave.argtypes = [vp, vp, vp, C.c_uint32, vp]
     L.clx_index_frames_device.argtypes = [vp, vp, sz, sz, vp, vp, sz, C.POINTER(sz), C.POINTER(sz), C.c_uint32]
@@ -613,6 +615,11 @@ class Batch:
     def submit_lanes(self):
         """True when this batch's pipelined submissions run the fused lane kernels (clx_batch_submit_lanes)."""
         return bool(lib().clx_batch_submit_lanes(self._h))
+
+    @property
+    def submit_merge(self):
+        """How many consecutive submissions go out as one launch (clx_batch_submit_merge)."""
+        return int(lib().clx_batch_submit_merge(self._h))
 
     def flush(self, stream=0):
         self.ctx._check(lib().clx_batch_flush(self._h, C.c_void_p(stream) if stream else None))

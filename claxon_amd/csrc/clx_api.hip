@@ -988,6 +988,8 @@ extern "C" int clx_batch_submit_depth(const clx_batch* b) {
     return (b->flags & CLX_K2_THROUGHPUT) ? 1 : clx_batch::kDepthWaves;
 }
 
+extern "C" int clx_batch_submit_merge(const clx_batch* b) { return (b && clx_batch_submit_lanes(b)) ? b->merge : 1; }
+
 extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, void* stream_) {
     if (!b || !b->ctx) return CLX_API_ERROR;
     clx_ctx* ctx = b->ctx;

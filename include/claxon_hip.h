@@ -300,6 +300,7 @@ int  clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  * the lane kernels (two merged launches of twelve), 1 where a submission is a plain run. */
 int  clx_batch_submit_depth(const clx_batch* b);
 int  clx_batch_submit_lanes(const clx_batch* b);      /* 1: its pipelined submissions run the fused lane kernels */
+int  clx_batch_submit_merge(const clx_batch* b);      /* how many consecutive submissions go out as one launch (1: none are merged) */
 int  clx_batch_flush(clx_batch* b, void* stream);
 /* Blocks until the last run finished, then copies the per-frame results to host. */
 int  clx_batch_results(clx_batch* b, clx_frame_result* results);
