@@ -769,12 +769,14 @@ def _pmc_traffic(workload, frames):
 
 
 def kernel_source_sha16():
-    """sha256 over the kernel sources (claxon_amd/csrc/*.hip, *.h, intrin/*.h), first 16 hex digits."""
+    """sha256 over the KERNEL sources (claxon_amd/csrc: clx_kernels / clx_lanes / clx_lean .hip, clx_device.h, clx_crct.h, intrin/*.h --
+    not the host layer clx_api.hip / clx_plan.h / host/), first 16 hex digits."""
     import glob
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "claxon_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) + glob.glob(os.path.join(base, "intrin", "*.h"))):
+    names = ["clx_kernels.hip", "clx_lanes.hip", "clx_lean.hip", "clx_device.h", "clx_crct.h"]
+    for f in [os.path.join(base, n) for n in names] + sorted(glob.glob(os.path.join(base, "intrin", "*.h"))):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
