@@ -370,6 +370,40 @@ def test_composed_waves_at_scale(oracle, ctx):
         bl.close()
 
 
+def test_config5_rank_share_against_the_oracle(oracle, ctx):
+    """The node-scale workload's per-GPU share at its full size (BASELINE configs[4]: rank 3 of 8 of the 1 M-frame job, 125 003 frames
+    of 16 384 unique ones tiled with their own frame numbers and CRCs; what `bench.py --workload config5 --shard-of 8 --shard-rank 3`
+    times): pipelined submissions, waves composed by content, CRC-16 verified -- every status, message, end bit and sample against
+    the ORACLE's decode of the very same 1.2 GB of frames (not the generator's PCM)."""
+    import torch
+    from claxon_amd import shard
+    ts = synth.config5_tiled(1_000_000, 16384)
+    lo, hi = shard.balanced_ranges(ts.weights(), 8)[3]
+    w = ts.slice(lo, hi)
+    assert w.n >= 125000
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
+    ref = np.zeros(w.total_samples, dtype=np.int32)
+    r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.all(r["statuses"] == cx.OK)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    d_ref = torch.from_numpy(ref).to("cuda:0")
+    del ref
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True)
+    assert batch.submit_lanes
+    outs = [torch.full((w.total_samples,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(3)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(batch.submit_depth + 3):
+        batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % 3].data_ptr(), st)
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    assert np.array_equal(res["status"], r["statuses"]) and np.array_equal(res["msg"], r["msgs"])
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o, d_ref)), "output buffer %d differs from the oracle" % k
+    batch.close()
+
+
 def test_device_indexer_against_oracle_offsets(oracle, ctx):
     """clx_index_frames_device against the frame starts the ORACLE's reader walks through (oracle.decode_stream), not
     against the product's own host indexer: a 3 MB raw stream of mixed frames, with and without a garbage tail."""

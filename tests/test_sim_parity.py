@@ -14,12 +14,13 @@ import claxon_amd as cx
 
 
 @pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED,
-                                        cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL, cx.PATH_LANES | cx.LANES_FUSED | cx.COMPOSE],
-                ids=["waves", "lanes", "lanes-fused", "lanes-general", "lanes-composed"])
+                                        cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL],
+                ids=["waves", "lanes", "lanes-fused", "lanes-general"])
 def sim(request):
     """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip: split build, fused build with
-    the lean 16-bit tier clx_k_lean in front, fused build with the general kernels alone, fused build with every window of stereo
-    frames dealt to the lanes by content class -- clx_k_compose, round 4)."""
+    the lean 16-bit tier clx_k_lean in front, fused build with the general kernels alone).  (Waves composed by content --
+    clx_k_compose, round 4 -- need windows of at least 64 stereo frames: test_sim_waves_composed_by_content below and the
+    `lanes-composed` selection of the GPU suite, whose workloads are that large.)"""
     import simlib
     simlib.build()
     return SimBackend(request.param)
