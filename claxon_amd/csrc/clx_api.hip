@@ -497,6 +497,8 @@ int plan_lanes_data(clx_batch* b) {
             !hip_ok(ctx, hipMemcpy(b->d_first_slot_run, first_slot.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D first_slot (run)") ||
             !hip_ok(ctx, hipMemset(b->d_fkey, 0, nf * sizeof(uint32_t)), "memset fkey")) return CLX_API_ERROR;
     }
+    // (the fills above go through the null stream, which the batch's non-blocking streams do not wait for)
+    if (!hip_ok(ctx, hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return CLX_API_ERROR;
     b->lanes_planned = true;
     return CLX_OK;
 }
@@ -1044,6 +1046,7 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
                 HIP_TRY(ctx, hipMemset(F.d_sf_start, 0xff, ns * sizeof(uint32_t)));
                 HIP_TRY(ctx, hipMemset(F.d_errkey, 0xff, nf * sizeof(uint32_t)));
                 HIP_TRY(ctx, hipMemset(F.d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipStreamSynchronize(nullptr));       // (the fills went through the null stream; the launches' streams do not wait for it)
             }
         }
         // what cannot share a launch with the pending submissions goes after them: another caller stream (the launch waits for
