@@ -135,11 +135,17 @@ __device__ __forceinline__ void cln_land(LRing& g, uint32_t* row, LCrc& C, bool 
     if (mode == 1) C.next = g.fill;
     g.np = 0;
 }
-__device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32_t p) {
+// `more` (wave-uniform): a second and a third granule may be asked for.  Calm waves (cln_pump_now) say so at every fourth pump
+// only: their lanes use 1.3 granules per pump, out of step with each other, so the second landing block and its CRC step ran at
+// every pump for the quarter of the lanes that had two in flight -- with the second granules asked for TOGETHER it runs at a quarter
+// of the pumps for most of them.  In between a lane falls at most 1.5 granules behind (6 bits per sample: the calm limit), which a
+// ring of 24 dwords holds beside the two turns' worth it must have landed.
+__device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32_t p, bool more) {
     const uint32_t d = (p - 1u) >> 5;                                   // the oldest dword a window may still read
     const int32_t room = (int32_t)(CLN_RING + d - g.fill);                // slots that hold dwords before d
     g.np = 0;
     if (room >= 4) { g.pa = clx_buf_load16(buf, g.origin + 4u * g.fill); g.np = 1u; }
+    if (!more) return;
     if (room >= 8) { g.pb = clx_buf_load16(buf, g.origin + 4u * g.fill + 16u); g.np = 2u; }
     if (room >= 12) { g.pc = clx_buf_load16(buf, g.origin + 4u * g.fill + 32u); g.np = 3u; }
 }
@@ -316,7 +322,7 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
     KR.rice = true; KR.verb = false; KR.bitmask = 0xffffffffu; KR.ricemask = 0xffffffffu; KR.verbmask = 0u; KR.cor = 0u; KR.vsh = 0u; KR.vshm = 0u;
     const uint32_t bs = fr.block_size;
     // (a calm wave -- no frame above 7 bits per sample over all its channels: the ring is pumped every other turn, cln_pump_now)
-    const bool calm = __all(!active || fr.limit_bits <= 7u * bs * (uint32_t)fr.n_channels);
+    const bool calm = __all(!active || fr.limit_bits <= 6u * bs * (uint32_t)fr.n_channels);
     uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
     uint32_t nch_max = nch;
 #pragma unroll
@@ -375,13 +381,14 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
             if (r.err) left = 0u;
         }
         bool ring_ok = false, even = false;
+        uint32_t pumps = 0;
 #pragma unroll 1
         while (__any(left >= 16u && !r.err)) {
             const bool has = left >= 16u && !r.err;          // this lane has sixteen codes to skip
             const bool live = has && ring_able;
             const LCur keep = cur;                           // (a lane without them rides along where it is: its ring stays consistent)
             if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); ring_ok = true; even = false; }
-            else if (cln_pump_now(calm, even)) { cln_land(g, row, NC, false); cln_request(buf, g, cur.p); }
+            else if (cln_pump_now(calm, even)) { cln_land(g, row, NC, false); cln_request(buf, g, cur.p, !calm || (pumps & 3u) == 0u); ++pumps; }
             even = !even;
             int done = 0;
             bool refilled = false;
@@ -817,7 +824,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
         }
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
         else if (cln_pump_now(calm, (t0 & 16u) == 0u)) {      // (the turns at whose start a pair of tiles leaves: the stores stay right in front of the landing's wait)
-            cln_land(g, row, CR, crc); cln_request(buf, g, cur.p);
+            cln_land(g, row, CR, crc); cln_request(buf, g, cur.p, !calm || (t0 & 96u) == 0u);      // (calm: every fourth pump -- the pumps are at the even turns)
             CLX_STAT(46, 1);
         }
         const bool was_slow = slow;                      // (no lean turn is tried: the history does not fit the packed form)
@@ -966,7 +973,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
         int4* const mine = cln_mine(stage, t0, lane);
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
-        else if (cln_pump_now(calm, (t0 & 16u) == 0u)) { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p); }
+        else if (cln_pump_now(calm, (t0 & 16u) == 0u)) { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p, !calm || (t0 & 96u) == 0u); }
         {
             bool refilled = false;
           again:
@@ -1111,7 +1118,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     const uint32_t next_sp = (active && !last_ch) ? sf_start[cslot + 1u] : 0xffffffffu;
     // a calm wave: no lane's subframe holds more than 7 bits per sample -- its ring is pumped every other turn (cln_pump_now)
     const uint32_t sf_bits = !active ? 0u : last_ch ? o + fr.limit_bits - pos0 : next_sp - pos0;       // (a failed or unbounded one: huge)
-    const bool calm = __all(sf_bits <= 7u * bs);
+    const bool calm = __all(sf_bits <= 6u * bs);
     LCrc CR;
     CR.c.r = 0u; CR.c.x = 0u; CR.next = 0u; CR.db = CLN_CRC_NONE;
     bool crc_mine = false, crc_last = false;
