@@ -5,7 +5,7 @@ set -u
 cd "$(dirname "$0")/.."
 O=gpurun_out/final_r04; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -2 $O/pytest.log
+[ -n "${SKIP_TESTS:-}" ] || { timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -2 $O/pytest.log; }
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 line() { python - "$1" "$2" <<'PY'
 import json,sys
