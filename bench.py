@@ -15,6 +15,11 @@ Workloads (`--workload`):
           fixed).  `--shard-of N --shard-rank r` runs rank r's share of an N-way split on one GPU without a process group.
 Frames are independent: ranks share nothing and there is no collective on the data path (barrier + MAX/SUM reductions only).
 
+The timed region -- exactly `--steps` steps between barrier + synchronize on both sides, MAX over the ranks -- is repeated `--repeats`
+times (default 5): `value` / `ms_per_step` are the MEDIAN region, `ms_per_step_min` / `_max` and `value_min` / `_max` travel beside
+them.  `--devices 0,0` maps local ranks to devices (two ranks on one GPU: the rehearsal of the N-rank line on the hardware that
+exists); `--compose on|off` forces the waves' composition by content; `cpu_baseline` is in the line at every N (rank 0).
+
 One JSON line on rank 0; DESIGN.md section 5 says how `roofline` and `cpu_baseline` are derived.
 """
 import argparse
@@ -484,6 +489,8 @@ def _launcher_selftest(args):
                           "scaling": scaling, "config": {"workload": workload_name, "samples_per_step": samples_all, "shard": shard_info,
                                                          "per_rank": [{"rank": i, "ms_per_step": r[0], "range": [int(r[2]), int(r[3])]} for i, r in enumerate(per_rank)],
                                                          "process_group": {"backend": "gloo", "world_size": world},
+                                                         "devices": args.devices or None,
+                                                         "device_of_rank": [_device_of(args.devices, r) for r in range(world)],
                                                          "launcher": os.environ.get("CLX_BENCH_LAUNCHER", "external (WORLD_SIZE in the environment)" if world > 1 else "single process")}}))
     if world > 1:
         dist.barrier()

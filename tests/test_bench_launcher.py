@@ -71,3 +71,22 @@ def test_external_launcher_environment_is_respected():
     (a0, a1), (b0, b1) = [p["range"] for p in j["config"]["per_rank"]]
     assert a0 == 0 and a1 == b0 and b1 == 3000                                      # strong scaling: the 3000 frames are cut in two
     assert j["config"]["shard"]["imbalance"] < 0.02                                  # ... by algorithmic bytes
+
+
+def test_devices_option_maps_ranks_to_devices():
+    """`--gpus 2 --devices 0,0` (round 4: two ranks on ONE GPU, the rehearsal of the N-rank line where no second GPU exists): the option
+    travels to the self-spawned ranks and maps local rank r to devices[r]; without it rank r runs on device r."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--devices", "0,0", "--launcher-selftest", "--steps", "4", "--frames", "300"],
+                       env=_clean_env(), capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    cfg = _line(r.stdout)["config"]
+    assert cfg["devices"] == "0,0" and cfg["device_of_rank"] == [0, 0]
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest", "--steps", "4", "--frames", "300"],
+                       env=_clean_env(), capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    cfg = _line(r.stdout)["config"]
+    assert cfg["devices"] is None and cfg["device_of_rank"] == [0, 1]
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench._device_of("3,1,2", r) for r in range(4)] == [3, 1, 2, 3] and bench._device_of("", 5) == 5
+    assert bench._launch_sizes(20, 12) == [12, 8] and bench._launch_sizes(24, 12) == [12, 12] and bench._launch_sizes(5, 1) == [1] * 5
