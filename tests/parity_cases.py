@@ -553,21 +553,22 @@ def check_crc_in_batch(oracle, backend, w, seed=77, frac=0.4, loose_every=0):
     rng = np.random.default_rng(seed)
     arena = w.arena.copy()
     hit = np.zeros(w.n, dtype=bool)
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
     for i in range(w.n):
         if rng.uniform() >= frac:
             continue
         hit[i] = True
         lo, hi = int(w.offs[i]), int(w.offs[i] + w.lens[i])
+        body = lo + int(descs["header_bytes"][i])                         # (the headers stay intact: the host has parsed them)
         kind = int(rng.integers(0, 4))
         for _ in range(int(rng.integers(1, 4))):
             if kind == 0:
                 pos = int(rng.integers(8 * (hi - 2), 8 * hi))             # the footer itself
             elif kind == 1:
-                pos = int(rng.integers(8 * (hi - 40), 8 * hi))            # near the end: the last subframe's tail
+                pos = int(rng.integers(8 * max(body, hi - 40), 8 * hi))   # near the end: the last subframe's tail
             else:
-                pos = int(rng.integers(8 * (lo + 8), 8 * hi))             # anywhere behind the header
+                pos = int(rng.integers(8 * body, 8 * hi))                 # anywhere behind the header
             arena[pos >> 3] ^= (0x80 >> (pos & 7))
-    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)       # (the headers are intact)
     lens = w.lens.copy()
     if loose_every:
         for i in range(0, w.n - 1, loose_every):
@@ -606,3 +607,39 @@ def giveup_workload(n=128, seed=4242):
             fp.sf[c] = S.sf(S.SF_LPC, 8, 12, po)
         fps.append(fp)
     return S.encode_frames("give-up families", pcm, 2, bs, 16, fps)
+
+
+def crc_share_workload(seed=9090):
+    """Frames whose CRC-16 the decode lanes gather in shares of every shape (clx_crct.h): 1, 2, 3, 6 and 8 channels (a frame's shares
+    chain over up to eight lanes, and its lanes straddle waves), short blocks (32 .. 160 samples: subframes that begin and end inside one
+    16-byte granule, frames that start at every offset inside their first granule), constant and verbatim subframes among the predicted
+    ones, 16- and 24-bit audio.  Every family is a run of frames of one shape that fills whole waves of 64 subframes, so that the lean
+    kernels take them (three-channel frames then sit across wave boundaries)."""
+    S = synth
+    ws = []
+    for k, (channels, bs, bps, count) in enumerate([(1, 64, 16, 64), (2, 32, 16, 64), (3, 96, 16, 64), (6, 64, 16, 32), (8, 160, 16, 16),
+                                                    (2, 64, 24, 64), (8, 64, 24, 16), (2, 4096, 16, 32)]):
+        pcm = np.empty((count, channels, bs), dtype=np.int32)
+        fps = []
+        lim = 1 << (bps - 1)
+        t = np.arange(bs)
+        for i in range(count):
+            g = np.random.default_rng(seed + 1000 * k + i)
+            for c in range(channels):
+                x = 0.3 * lim * np.sin(2 * np.pi * g.uniform(50, 3000) * t / 44100.0 + g.uniform(0, 6.28)) + g.normal(0, lim * g.choice([1e-4, 1e-3, 1e-2]), bs)
+                pcm[i, c] = np.clip(np.rint(x), -lim, lim - 1).astype(np.int32)
+            ca = int(g.integers(0, 4)) if channels == 2 else 0
+            fp = S.FrameParams(ca, 0, 7000 + i)
+            for c in range(channels):
+                u = g.uniform()
+                if ca == 0 and u < 0.08:
+                    pcm[i, c] = int(g.integers(-100, 100)); fp.sf[c] = S.sf(S.SF_CONSTANT, 0, 0, 0)
+                elif ca == 0 and u < 0.16:
+                    fp.sf[c] = S.sf(S.SF_VERBATIM, 0, 0, 0)
+                elif u < 0.4:
+                    fp.sf[c] = S.sf(S.SF_FIXED, int(g.integers(0, 5)), 0, int(g.integers(0, 2)))
+                else:
+                    fp.sf[c] = S.sf(S.SF_LPC, int(g.integers(1, 13)), int(g.integers(8, 15)), int(g.integers(0, 2)))
+            fps.append(fp)
+        ws.append(S.encode_frames("crc shares %d ch bs %d %d bit" % (channels, bs, bps), pcm, channels, bs, bps, fps))
+    return synth.concat("crc shares", ws)

@@ -69,6 +69,9 @@ def test_gpu_crc16_in_batch(oracle, gpu):
     pc.check_crc_in_batch(oracle, gpu, synth.config5_unique(400), seed=3)
     pc.check_crc_in_batch(oracle, gpu, synth.config4(120), seed=5)
     pc.check_crc_in_batch(oracle, gpu, synth.config3(300), seed=9, frac=0.1, loose_every=3)
+    ws = pc.crc_share_workload()          # 1 .. 8 channels, short blocks, frames at every offset inside their first granule
+    pc.check_workload(oracle, gpu, ws)
+    pc.check_crc_in_batch(oracle, gpu, ws, seed=3, frac=0.3)
 
 
 def test_gpu_truncations(oracle, gpu):

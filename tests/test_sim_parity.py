@@ -276,6 +276,13 @@ def test_sim_crc16_gathered_by_the_decode_lanes(oracle):
     n, done, todo = counted(lambda: pc.check_crc_in_batch(oracle, sim, synth.config3(70), seed=9, frac=0.1, loose_every=3))
     assert todo >= 23, (done, todo)
     pc.check_crc_in_batch(oracle, sim, pc.lean_workload(), seed=11, loose_every=5)
+    # shares of every shape: 1 .. 8 channels (a frame's shares chain over up to eight lanes, across wave boundaries), blocks of 32 .. 160
+    # samples (subframes inside one granule, frames at every offset inside their first granule), 16- and 24-bit: all but a frame or two settled by the lanes
+    ws = pc.crc_share_workload()
+    _, done, todo = counted(lambda: pc.check_workload(oracle, sim, ws, verify_crc=True))
+    assert done >= ws.n - 4 and done + todo == ws.n, (done, todo, ws.n)
+    n, done, todo = counted(lambda: pc.check_crc_in_batch(oracle, sim, ws, seed=3, frac=0.3))
+    assert n >= 60 and done >= 150, (n, done, todo)
 
 
 def test_sim_groups_given_up_by_the_lean_kernel(oracle):
