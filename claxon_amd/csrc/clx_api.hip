@@ -628,6 +628,9 @@ extern "C" int clx_batch_set_profiling(clx_batch* b, int enable) {
 namespace {
 // K3: four frames per workgroup at a time; beyond 8 workgroups per CU the waves loop
 unsigned crc_grid(size_t n) { return (unsigned)std::min<size_t>((n + 3) / 4, 2048); }
+// the same behind the lane kernels, per run of a merged launch: 256 workgroups (1 024 waves) per run fill the machine when every frame
+// is theirs, and are few enough to find room at once when none is (the lean kernels' lanes gather the CRC of what they decode)
+unsigned crc_grid_runs(size_t n) { return (unsigned)std::min<size_t>((n + 3) / 4, 256); }
 // clamp every frame's readable span against the arena and upload the plan (once per arena size)
 int upload_plan(clx_batch* b, size_t arena_len, hipStream_t stream) {
     clx_ctx* ctx = b->ctx;
@@ -716,7 +719,7 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
                        (const clx_dev_frame*)b->d_frames, (uint32_t)b->n);
     if (b->flags & CLX_VERIFY_CRC16) {
         if (!mark("clx_k_crc16")) return false;
-        hipLaunchKernelGGL(clx_k_crc16_runs, dim3(crc_grid(b->n), n_runs), dim3(256), 0, stream, runs,
+        hipLaunchKernelGGL(clx_k_crc16_runs, dim3(n_runs > 1 ? crc_grid_runs(b->n) : crc_grid(b->n), n_runs), dim3(256), 0, stream, runs,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n);
     }
     return true;

@@ -1416,14 +1416,26 @@ __constant__ K3Rom clx_k3_rom = clx_make_k3_rom();
 __device__ __forceinline__ void clx_crc16_frames(const uint8_t* __restrict__ arena, const clx_dev_frame* __restrict__ frames, uint32_t n_frames,
                                                  clx_frame_result* __restrict__ results, const uint32_t* __restrict__ todo) {
     __shared__ K3Rom T;
+    __shared__ uint32_t any_todo;
+    const int lane = (int)threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6, n_waves = gridDim.x * 4u;
+    if (todo != nullptr) {
+        // (the usual case on the lane path: the decode lanes have settled every frame -- a workgroup that finds nothing to do leaves
+        //  before it copies the tables; in a full machine these workgroups wait for room behind the other stream's decode kernel)
+        if (threadIdx.x == 0) any_todo = 0u;
+        __syncthreads();
+        bool mine = false;
+        for (uint32_t f = blockIdx.x * 4u + wave + n_waves * (uint32_t)lane; f < n_frames; f += n_waves * 64u) mine = mine || todo[f] != 0u;
+        if (mine) any_todo = 1u;
+        __syncthreads();
+        if (any_todo == 0u) return;
+    }
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&clx_k3_rom);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&T);
         for (uint32_t i = threadIdx.x; i < sizeof(K3Rom) / 4u; i += 256u) dst[i] = src[i];
     }
     __syncthreads();
-    const int lane = (int)threadIdx.x & 63;
-    const uint32_t wave = threadIdx.x >> 6, n_waves = gridDim.x * 4u;
     for (uint32_t f = blockIdx.x * 4u + wave; f < n_frames; f += n_waves) {
         if (todo != nullptr && todo[f] == 0u) continue;                      // wave-uniform
         const clx_dev_frame fr = frames[f];
