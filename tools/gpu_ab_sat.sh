@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library builds in the saturated regime: ONE merged launch of M runs at a time (tools/merge_probe.py) under a kernel trace;
-# prints each kernel's median duration.  usage: tools/gpu_ab_sat.sh "A B" rounds M   (builds as for tools/gpu_ab.sh; resolves ~1 %)
+# prints each kernel's median duration.  (CLX_TUNE_MERGE / CLX_TUNE_STREAMS are read by builds made with -DCLX_TUNING only.)  usage: tools/gpu_ab_sat.sh "A B" rounds M   (builds as for tools/gpu_ab.sh; resolves ~1 %)
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 VARS=${1:-"A B"}; ROUNDS=${2:-2}; M=${3:-9}

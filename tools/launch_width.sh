@@ -1,4 +1,5 @@
 #!/bin/bash
+# (CLX_TUNE_MERGE / CLX_TUNE_STREAMS are read by builds made with CLX_EXTRA_FLAGS="-DCLX_TUNING" only: point CLAXON_HIP_LIB at one)
 # lean / scan durations of ONE merged launch of M runs at a time (no other launch beside it), M = 1..12
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)

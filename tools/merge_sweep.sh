@@ -1,6 +1,7 @@
 #!/bin/bash
 # bench.py under CLX_TUNE_MERGE / CLX_TUNE_STREAMS: runs per merged launch of the fused lane kernels x internal streams (run through
-# gpurun; the numbers are collected in profiles/r03_merge_sweep.txt).
+# gpurun; the numbers are collected in profiles/r03_merge_sweep.txt).  The product build reads no environment variable: point
+# CLAXON_HIP_LIB at a build made with CLX_EXTRA_FLAGS="-DCLX_TUNING" (tools/r04_call12.sh shows how).
 # usage: tools/merge_sweep.sh ["M S" ...] [-- bench.py arguments]      default: a few shapes, the bench workload, 20 and 96 steps
 set -u
 cd "$(dirname "$0")/.."

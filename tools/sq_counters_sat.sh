@@ -1,4 +1,5 @@
 #!/bin/bash
+# (CLX_TUNE_MERGE / CLX_TUNE_STREAMS are read by builds made with CLX_EXTRA_FLAGS="-DCLX_TUNING" only: point CLAXON_HIP_LIB at one)
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
