@@ -777,16 +777,21 @@ def _pmc_traffic(workload, frames):
 
 def kernel_source_sha16():
     """sha256 over the KERNEL sources (claxon_amd/csrc: clx_kernels / clx_lanes / clx_lean .hip, clx_device.h, clx_crct.h, intrin/*.h --
-    not the host layer clx_api.hip / clx_plan.h / host/), first 16 hex digits."""
+    not the host layer clx_api.hip / clx_plan.h / host/) with comments and white space taken out, first 16 hex digits."""
     import glob
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "claxon_amd", "csrc")
     names = ["clx_kernels.hip", "clx_lanes.hip", "clx_lean.hip", "clx_device.h", "clx_crct.h"]
+    import re
     for f in [os.path.join(base, n) for n in names] + sorted(glob.glob(os.path.join(base, "intrin", "*.h"))):
         h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
+        with open(f, "r", errors="replace") as fh:
+            text = fh.read()
+        # (what the compiler sees: comments out, white space collapsed -- a reworded comment does not make a counter profile stale)
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

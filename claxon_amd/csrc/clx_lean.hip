@@ -151,7 +151,7 @@ __device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32
 }
 // The ring is pumped (landing + requests) every OTHER turn in CALM waves: at 5 bits per code a lane uses a granule in 1.6 turns,
 // and the wave paid for a landing, a CRC step and three request blocks per turn as soon as ONE lane had something in flight.
-// Calm is decided once, where the subframes' sizes are known (cln_kernel: every lane's subframe holds at most 7 bits per
+// Calm is decided once, where the subframes' sizes are known (cln_kernel: every lane's subframe holds at most 6 bits per
 // sample; the scan: its frames do): such lanes keep two turns' worth landed beyond their cursors in a ring of 24 dwords.  A burst
 // inside a calm subframe runs the ring dry and is refilled on the spot, as always.  Deciding it turn by turn from the lanes' rates
 // was measured too (tools/r04_call8.sh, r04_call9.sh): the same gain on config 3, but the bookkeeping cost the waves that are never
@@ -321,7 +321,7 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
     LKind KR;                                            // (the careful reader's view: every lane skips Rice codes)
     KR.rice = true; KR.verb = false; KR.bitmask = 0xffffffffu; KR.ricemask = 0xffffffffu; KR.verbmask = 0u; KR.cor = 0u; KR.vsh = 0u; KR.vshm = 0u;
     const uint32_t bs = fr.block_size;
-    // (a calm wave -- no frame above 7 bits per sample over all its channels: the ring is pumped every other turn, cln_pump_now)
+    // (a calm wave -- no frame above 6 bits per sample over all its channels: the ring is pumped every other turn, cln_pump_now)
     const bool calm = __all(!active || fr.limit_bits <= 6u * bs * (uint32_t)fr.n_channels);
     uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
     uint32_t nch_max = nch;
@@ -1116,7 +1116,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     // (where the next subframe starts: the end of this lane's share of the frame's CRC, and how many bits its subframe holds)
     const bool last_ch = active && ch + 1u == (uint32_t)fr.n_channels;
     const uint32_t next_sp = (active && !last_ch) ? sf_start[cslot + 1u] : 0xffffffffu;
-    // a calm wave: no lane's subframe holds more than 7 bits per sample -- its ring is pumped every other turn (cln_pump_now)
+    // a calm wave: no lane's subframe holds more than 6 bits per sample -- its ring is pumped every other turn (cln_pump_now)
     const uint32_t sf_bits = !active ? 0u : last_ch ? o + fr.limit_bits - pos0 : next_sp - pos0;       // (a failed or unbounded one: huge)
     const bool calm = __all(sf_bits <= 6u * bs);
     LCrc CR;
