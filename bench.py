@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--devices", default="",
                     help="comma-separated device index per local rank (default: rank r on device r); `--gpus 2 --devices 0,0 --backend gloo` "
                          "rehearses the N-rank path -- spawn, process group, barrier, reductions, one line -- on ONE GPU")
+    ap.add_argument("--process-group", action="store_true",
+                    help="create the process group even when WORLD_SIZE is 1: the barrier and the MAX / SUM / all_gather reductions then go "
+                         "through the backend (RCCL on device tensors with --backend nccl) on the one GPU that is there")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no decode: only the launcher, the rank plan and the cross-rank reductions (CPU, gloo); prints a line with value null")
     args = ap.parse_args()
@@ -85,7 +88,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dev_index = _device_of(args.devices, local_rank)
-    if world > 1:
+    use_pg = world > 1 or args.process_group       # collectives go through the process group (always with several ranks)
+    if use_pg:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -99,7 +103,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     # (gloo reduces host tensors; RCCL device tensors)
-    red_dev = dev if (world == 1 or args.backend == "nccl") else None
+    red_dev = dev if (not use_pg or args.backend == "nccl") else None
 
     # ---- this rank's share of the job's frame index
     t_gen = time.time()
@@ -130,12 +134,16 @@ def main():
     arenas = [d_arena] + ([d_arena.clone() for _ in range(depth - 1)] if pipelined and depth * w.arena.size < 8 * (1 << 30) else [])
     stream = torch.cuda.current_stream(dev).cuda_stream
 
+    barrier_s = []                                  # what the closing barrier of each timed region took on this rank (outside the clock)
+
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
     def timed(b, steps, pipe):
-        """`steps` passes of batch b, bracketed by barrier + synchronize on both sides; seconds (this rank)."""
+        """`steps` passes of batch b, bracketed by barrier + synchronize on both sides; seconds (this rank).  The clock stops when
+        this rank's work is done (after synchronize) and BEFORE the closing barrier: the job's time is the MAX over the ranks of
+        these local times, so a collective inside a 3-ms region would only add its own latency to every rank's figure."""
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         if pipe:
@@ -145,8 +153,11 @@ def main():
         else:
             for _ in range(steps):
                 b.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream)
-        torch.cuda.synchronize(); barrier()
-        return time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        barrier_s.append(time.perf_counter() - t1)
+        return t1 - t0
 
     for i in range(max(args.warmup, len(outs) if pipelined else 0)):
         if pipelined:
@@ -217,12 +228,12 @@ def main():
     for _ in range(max(1, args.repeats)):
         el_local = timed(batch, args.steps, pipelined)
         # whole-job figures: MAX elapsed over ranks, SUM of samples per step
-        el, samples_all, _ = shard.reduce_job(dist if world > 1 else None, el_local, w.total_samples, 0, device=red_dev)
+        el, samples_all, _ = shard.reduce_job(dist if use_pg else None, el_local, w.total_samples, 0, device=red_dev)
         regions.append(el); regions_local.append(el_local)
     res = batch.results()
     if not outputs_exact(outs[:min(len(outs), args.steps)]):
         raise SystemExit("bench: a timed step did not reproduce the source PCM; refusing to report a number")
-    _, _, n_bad = shard.reduce_job(dist if world > 1 else None, 0.0, 0, int((res["status"] != 0).sum()), device=red_dev)      # SUM of failed frames (must be 0)
+    _, _, n_bad = shard.reduce_job(dist if use_pg else None, 0.0, 0, int((res["status"] != 0).sum()), device=red_dev)      # SUM of failed frames (must be 0)
     if n_bad:
         raise SystemExit("bench: %d frames failed to decode in the timed region" % n_bad)
     elapsed = float(np.median(regions))
@@ -230,7 +241,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = samples_all / (ms_per_step * 1e-3) / 1e6
     # every rank's own step time and share (all_gather of three numbers): how even the ranks were
-    per_rank = _gather_floats(dist if world > 1 else None, [1e3 * elapsed_local / args.steps, float(w.algorithmic_bytes), float(w.n)], world, device=red_dev)
+    per_rank = _gather_floats(dist if use_pg else None, [1e3 * elapsed_local / args.steps, float(w.algorithmic_bytes), float(w.n)], world, device=red_dev)
     if world > 1:      # algorithmic bytes: max over ranks / mean
         algs = [r[1] for r in per_rank]
         shard_info["imbalance"] = round(max(algs) / (sum(algs) / len(algs)) - 1.0, 5)
@@ -298,7 +309,9 @@ def main():
            "compressed_bytes_this_rank": w.compressed_bytes, "bits_per_sample": round(8.0 * w.compressed_bytes / w.total_samples, 3),
            "parallelism": "one frame index sharded over %d GPU(s), no collective on the data path" % world, "shard": shard_info,
            "per_rank": [{"rank": i, "ms_per_step": round(r[0], 4), "frames": int(r[2])} for i, r in enumerate(per_rank)],
-           "process_group": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None, "world_size": world},
+           "process_group": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if use_pg else None, "world_size": world,
+                             "barrier_us": round(1e6 * float(np.median(barrier_s)), 1) if (use_pg and barrier_s) else None,
+                             "barrier_note": "the closing barrier of a timed region, outside the clock (rank 0's median)"},
            "launcher": os.environ.get("CLX_BENCH_LAUNCHER", "external (WORLD_SIZE in the environment)" if world > 1 else "single process"),
            "bit_exact": True, "bit_exact_checked": "every output buffer vs the source PCM before the timed steps, and again -- on buffers cleared in between -- after them",
            "crc16_in_step": bool(with_crc), "kernel_path": args.path, "compose": args.compose, "gen_seconds": round(gen_s, 1),
@@ -322,7 +335,7 @@ def main():
     if pipelined and not args.no_extras:
         # ---- the same steps one at a time (clx_batch_run: nothing of step i+1 starts before step i has finished)
         el_1 = timed(batch, args.steps, False)
-        el_1, samples_1, _ = shard.reduce_job(dist if world > 1 else None, el_1, w.total_samples, 0, device=red_dev)
+        el_1, samples_1, _ = shard.reduce_job(dist if use_pg else None, el_1, w.total_samples, 0, device=red_dev)
         ms_1 = 1e3 * el_1 / args.steps
         cfg["one_step_at_a_time"] = {"value": round(samples_1 / (ms_1 * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_1, 4),
                                      "frac": round(alg_bytes / (ms_1 * 1e-3) / 1e9 / PEAK_GBS, 4),
@@ -338,7 +351,7 @@ def main():
         torch.cuda.synchronize()
         rc = bc.results()
         el_c = timed(bc, args.steps, pipelined)
-        el_c, samples_c, bad_c = shard.reduce_job(dist if world > 1 else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=red_dev)
+        el_c, samples_c, bad_c = shard.reduce_job(dist if use_pg else None, el_c, w.total_samples, int((rc["status"] != 0).sum()), device=red_dev)
         bc.close()
         if bad_c == 0:
             ms_c = 1e3 * el_c / args.steps
@@ -502,7 +515,7 @@ def _gather_floats(dist, vals, world, device=None):
     """Every rank's list of floats, on every rank: [[rank 0's], [rank 1's], ...] (all_gather of one small tensor)."""
     import torch
     t = torch.tensor(vals, dtype=torch.float64, device=device)
-    if dist is None or world == 1:
+    if dist is None:
         return [t.tolist()]
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)

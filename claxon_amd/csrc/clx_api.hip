@@ -324,6 +324,7 @@ struct clx_batch {
     int merge = kMerge, n_streams = kStreams;          // (builds with -DCLX_TUNING let CLX_TUNE_MERGE / CLX_TUNE_STREAMS override them)
     struct Pending { const uint8_t* arena; size_t arena_len; int32_t* out; int flight; };
     std::vector<Pending> pend;
+    bool launch_failed = false;                        // a merged launch was dropped; reported once more by the next flush / results
     hipStream_t pend_stream = nullptr;                 // the caller's stream the pending submissions came in on
     hipStream_t mstream[kMaxStreams] = {};
     // An event behind each of a stream's last kEvRing launches: a later launch on ANOTHER stream that re-uses an output buffer or a
@@ -388,7 +389,7 @@ extern "C" void clx_destroy(clx_ctx* ctx) {
 
 extern "C" const char* clx_last_error(const clx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
-namespace { int launch_pending(clx_batch* b); }
+namespace { int launch_pending(clx_batch* b, bool inputs_ready = false); }
 extern "C" void clx_batch_destroy(clx_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);      // (by value: a batch destroyed after its context must not look into it)
@@ -398,7 +399,10 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
         clx_ctx scratch_ctx;                   // (the batch's own context may be gone: errors of this launch have nowhere to go)
         scratch_ctx.device = b->device;
         b->ctx = &scratch_ctx;
-        (void)launch_pending(b);
+        // (and with it the stream the submissions came in on, when that was the context's own: the device is drained instead of
+        //  an event recorded there -- whatever was queued in front of the submissions has then run)
+        (void)hipDeviceSynchronize();
+        (void)launch_pending(b, true);
         b->ctx = nullptr;
     }
     if (b->d_frames) (void)hipFree(b->d_frames);
@@ -690,7 +694,14 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
         // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them
         if (runs.r[0].taken != nullptr && b->any_bps_le16) {
             if (!mark("clx_k_lean")) return false;
-            hipLaunchKernelGGL(clx_k_lean, dim3(groups, n_runs), dim3(64), 0, stream, runs,
+            // CLX_LEAN_LDS_PAD (measurement builds only): extra dynamic LDS per wave, i.e. fewer decode waves per CU -- the knob behind
+            // profiles/r05_occupancy_sweep.txt
+#ifdef CLX_TUNING
+            static const unsigned lean_pad = [] { const char* e = std::getenv("CLX_LEAN_LDS_PAD"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
+#else
+            const unsigned lean_pad = 0u;
+#endif
+            hipLaunchKernelGGL(clx_k_lean, dim3(groups, n_runs), dim3(64), lean_pad, stream, runs,
                                (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
         }
         // the split tier for audio of more than 16 bits (launched when the batch holds such frames: it also takes <= 16-bit groups of
@@ -809,19 +820,37 @@ bool launch_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int3
     return true;
 }
 // Launch the pending submissions of the fused lane path as ONE grid (grid.y = the runs) on one of the two internal streams.
-int launch_pending(clx_batch* b) {
+// A launch that cannot be made drops ITS submissions (they had been accepted with CLX_OK): the call that triggered it fails, the
+// flights' scratch is marked for clearing, and the batch remembers the failure (launch_failed) until clx_batch_flush /
+// clx_batch_results / clx_batch_interleave has reported it once -- a caller that only looks at the flush learns of it there.  Nothing is
+// recorded about the launch (who wrote which output buffer last, which launch used which flight) before it and its event are out.
+// inputs_ready: the device has been synchronised since the submissions came in -- nothing is recorded on the stream they came in on
+// (clx_batch_destroy: that stream may have been the context's own, and the context may be gone).
+int launch_pending(clx_batch* b, bool inputs_ready) {
     clx_ctx* ctx = b->ctx;
     if (b->pend.empty()) return CLX_OK;
     const int k = (int)(b->n_merged % (uint64_t)b->n_streams);
+    bool went_out = false;                     // some kernel of this launch may have been queued
+    auto fail = [&](const char* what, hipError_t e) -> int {
+        if (went_out) for (const auto& P : b->pend) b->flight[P.flight].scratch_stale = true;       // (may never reach clx_k_finalize)
+        b->pend.clear();
+        b->launch_failed = true;
+        ctx->last_error = std::string("a merged launch of the lane kernels failed (") + what + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string()) +
+                          "); its submissions were dropped";
+        return CLX_API_ERROR;
+    };
+#define LP_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(#expr, e_); } while (0)
     if (!b->mstream[k]) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&b->mstream[k], hipStreamNonBlocking));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&b->m_in[k], hipEventDisableTiming));
-        for (auto& e : b->m_done[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        LP_TRY(hipStreamCreateWithFlags(&b->mstream[k], hipStreamNonBlocking));
+        LP_TRY(hipEventCreateWithFlags(&b->m_in[k], hipEventDisableTiming));
+        for (auto& e : b->m_done[k]) LP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     hipStream_t ms = b->mstream[k];
     // behind everything queued so far on the stream the submissions came in on (their inputs)
-    HIP_TRY(ctx, hipEventRecord(b->m_in[k], b->pend_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ms, b->m_in[k], 0));
+    if (!inputs_ready) {
+        LP_TRY(hipEventRecord(b->m_in[k], b->pend_stream));
+        LP_TRY(hipStreamWaitEvent(ms, b->m_in[k], 0));
+    }
     // (this stream's earlier launches are ahead of this one in the stream) a launch on ANOTHER stream must be waited for when it was
     // the last one to write one of this launch's output buffers -- however many launches ago -- or to use a scratch set this launch
     // uses (only after partial launches: flights are handed out in rotation, `merge` at a time, and merge * n_streams of them make
@@ -835,39 +864,38 @@ int launch_pending(clx_batch* b) {
             if (it != b->out_writer.end() && it->second.stream != k) need[it->second.stream] = std::max(need[it->second.stream], it->second.count);
         }
         for (int j = 0; j < clx_batch::kMaxStreams; ++j) {
-            if (!need[j]) continue;
+            if (!need[j] || !b->m_count[j]) continue;        // (references are made of launches that went out: need <= m_count)
             // (an event that has been recorded again since stands for a later launch of the same stream: still correct)
-            const uint64_t c = b->m_count[j] - need[j] < (uint64_t)clx_batch::kEvRing ? need[j] : b->m_count[j];
-            HIP_TRY(ctx, hipStreamWaitEvent(ms, b->m_done[j][(c - 1) % clx_batch::kEvRing], 0));
+            const uint64_t c = (need[j] <= b->m_count[j] && b->m_count[j] - need[j] < (uint64_t)clx_batch::kEvRing) ? need[j] : b->m_count[j];
+            LP_TRY(hipStreamWaitEvent(ms, b->m_done[j][(c - 1) % clx_batch::kEvRing], 0));
         }
     }
     // (the staging upload of the plan went out on whichever caller stream made that submission)
-    if (b->up_in_flight) HIP_TRY(ctx, hipStreamWaitEvent(ms, b->ev_up, 0));
+    if (b->up_in_flight) LP_TRY(hipStreamWaitEvent(ms, b->ev_up, 0));
     if (b->out_writer.size() > 4096u) {        // (a caller that never re-uses a buffer: forget the old ones behind a full ordering point)
         for (int a = 0; a < clx_batch::kMaxStreams; ++a)
             for (int j = 0; j < clx_batch::kMaxStreams; ++j)
                 if (a != j && b->mstream[a] && b->m_count[j])
-                    HIP_TRY(ctx, hipStreamWaitEvent(b->mstream[a], b->m_done[j][(b->m_count[j] - 1) % clx_batch::kEvRing], 0));
+                    LP_TRY(hipStreamWaitEvent(b->mstream[a], b->m_done[j][(b->m_count[j] - 1) % clx_batch::kEvRing], 0));
         b->out_writer.clear();
     }
     clx_runs runs;
     std::memset(&runs, 0, sizeof runs);
     unsigned n_runs = 0;
+    went_out = true;                           // (from here on the flights' scratch may have been touched)
     for (const auto& P : b->pend) {
         clx_batch::Flight& F = b->flight[P.flight];
         if (++F.gen == 0u) {       // (the generation number wrapped: nothing stale may look current)
-            HIP_TRY(ctx, hipMemsetAsync(F.d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), ms));
-            HIP_TRY(ctx, hipMemsetAsync(F.d_crc_part, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_crc_part), ms));
+            LP_TRY(hipMemsetAsync(F.d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), ms));
+            LP_TRY(hipMemsetAsync(F.d_crc_part, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_crc_part), ms));
             F.gen = 1u;
         }
         if (F.scratch_stale) {     // (clx_k_finalize leaves the scratch cleared behind every run that gets that far)
-            HIP_TRY(ctx, hipMemsetAsync(F.d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), ms));
-            HIP_TRY(ctx, hipMemsetAsync(F.d_errkey, 0xff, std::max<size_t>(b->n, 1) * sizeof(uint32_t), ms));
+            LP_TRY(hipMemsetAsync(F.d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), ms));
+            LP_TRY(hipMemsetAsync(F.d_errkey, 0xff, std::max<size_t>(b->n, 1) * sizeof(uint32_t), ms));
             F.scratch_stale = false;
         }
         runs.r[n_runs++] = make_run(b, F, P.arena, P.arena_len, P.out, true);
-        b->out_writer[P.out] = clx_batch::LaunchRef{ k, b->m_count[k] + 1 };
-        b->flight_launch[P.flight] = clx_batch::LaunchRef{ k, b->m_count[k] + 1 };
     }
     int nk = 0;
     auto mark = [&](const char* name) -> bool {          // (clx_batch_set_profiling(b, 2): an event in front of each kernel, one behind the last)
@@ -875,17 +903,16 @@ int launch_pending(clx_batch* b) {
         if (name) b->kname[nk] = name;
         return hip_ok(ctx, hipEventRecord(b->ev[nk++], ms), "hipEventRecord");
     };
-    const bool launched = launch_lanes(b, runs, n_runs, false, ms, mark) && hipGetLastError() == hipSuccess;
-    if (!launched) {
-        // what went out of it has used the flights' scratch and may never reach clx_k_finalize: cleared again before the next use
-        for (const auto& P : b->pend) b->flight[P.flight].scratch_stale = true;
-        b->pend.clear();
-        ctx->last_error = "a merged launch of the lane kernels failed";
-        return CLX_API_ERROR;
-    }
-    if (b->profile_merged) { if (!mark(nullptr)) return CLX_API_ERROR; b->n_kernels = nk - 1; b->ev_valid = true; b->ev_runs = (int)n_runs; }
+    if (!(launch_lanes(b, runs, n_runs, false, ms, mark) && hipGetLastError() == hipSuccess)) return fail("kernel launch", hipSuccess);
+    if (b->profile_merged) { if (!mark(nullptr)) return fail("hipEventRecord", hipSuccess); b->n_kernels = nk - 1; b->ev_valid = true; b->ev_runs = (int)n_runs; }
+    LP_TRY(hipEventRecord(b->m_done[k][b->m_count[k] % clx_batch::kEvRing], ms));
+#undef LP_TRY
+    // the launch and its event are out: now it is the last writer of its output buffers and the last user of its flights
     ++b->m_count[k];
-    HIP_TRY(ctx, hipEventRecord(b->m_done[k][(b->m_count[k] - 1) % clx_batch::kEvRing], ms));
+    for (const auto& P : b->pend) {
+        b->out_writer[P.out] = clx_batch::LaunchRef{ k, b->m_count[k] };
+        b->flight_launch[P.flight] = clx_batch::LaunchRef{ k, b->m_count[k] };
+    }
     b->m_unwaited[k] = true;
     b->pend.clear();
     ++b->n_merged;
@@ -893,7 +920,12 @@ int launch_pending(clx_batch* b) {
 }
 // make `stream` wait for every pipelined submission that nobody has waited for yet (what is pending is launched first)
 int wait_flights(clx_batch* b, hipStream_t stream) {
-    if (launch_pending(b) != CLX_OK) return CLX_API_ERROR;
+    if (launch_pending(b) != CLX_OK) { b->launch_failed = false; return CLX_API_ERROR; }       // (reported right here)
+    if (b->launch_failed) {        // an earlier launch was dropped and only a submit call has said so: the flush says it too, once
+        b->launch_failed = false;
+        b->ctx->last_error = "an earlier merged launch of this batch failed; its submissions were dropped";
+        return CLX_API_ERROR;
+    }
     for (int k = 0; k < clx_batch::kMaxStreams; ++k)
         if (b->m_unwaited[k]) { HIP_TRY(b->ctx, hipStreamWaitEvent(stream, b->m_done[k][(b->m_count[k] - 1) % clx_batch::kEvRing], 0)); b->m_unwaited[k] = false; }
     for (auto& F : b->flight)
@@ -1030,26 +1062,41 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
                              F.d_crc_part = b->d_crc_part; F.d_crc_todo = b->d_crc_todo;
                              F.d_slot_frame = b->d_slot_frame_run; F.d_first_slot = b->d_first_slot_run; F.d_fkey = b->d_fkey; }
             else {
-                if (b->n_windows) {      // (its own slot maps, starting as the plan's: clx_k_compose rewrites the windows' parts run by run)
-                    HIP_TRY(ctx, hipMalloc((void**)&F.d_slot_frame, ns * sizeof(uint32_t)));
-                    HIP_TRY(ctx, hipMalloc((void**)&F.d_first_slot, nf * sizeof(uint32_t)));
-                    HIP_TRY(ctx, hipMalloc((void**)&F.d_fkey, nf * sizeof(uint32_t)));
-                    HIP_TRY(ctx, hipMemcpy(F.d_slot_frame, b->d_slot_frame, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-                    HIP_TRY(ctx, hipMemcpy(F.d_first_slot, b->d_first_slot, nf * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-                    HIP_TRY(ctx, hipMemset(F.d_fkey, 0, nf * sizeof(uint32_t)));
+                // everything into locals first: the flight gets its scratch only when ALL of it exists and is filled (d_sf_start is the
+                // "allocated" sentinel) -- a failure half way frees what there is and leaves the flight as it was
+                uint32_t *sl = nullptr, *fs = nullptr, *fk = nullptr, *todo = nullptr, *sfs = nullptr, *ek = nullptr, *tk = nullptr;
+                clx_crc_part* part = nullptr; uint64_t* eb = nullptr;
+                const auto all = [&]() -> bool {
+                    if (b->n_windows) {      // (its own slot maps, starting as the plan's: clx_k_compose rewrites the windows' parts run by run)
+                        if (!hip_ok(ctx, hipMalloc((void**)&sl, ns * sizeof(uint32_t)), "hipMalloc slot map") ||
+                            !hip_ok(ctx, hipMalloc((void**)&fs, nf * sizeof(uint32_t)), "hipMalloc first slots") ||
+                            !hip_ok(ctx, hipMalloc((void**)&fk, nf * sizeof(uint32_t)), "hipMalloc content classes") ||
+                            !hip_ok(ctx, hipMemcpy(sl, b->d_slot_frame, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice), "hipMemcpy slot map") ||
+                            !hip_ok(ctx, hipMemcpy(fs, b->d_first_slot, nf * sizeof(uint32_t), hipMemcpyDeviceToDevice), "hipMemcpy first slots") ||
+                            !hip_ok(ctx, hipMemset(fk, 0, nf * sizeof(uint32_t)), "hipMemset content classes")) return false;
+                    }
+                    return hip_ok(ctx, hipMalloc((void**)&part, ns * sizeof(clx_crc_part)), "hipMalloc crc parts") &&
+                           hip_ok(ctx, hipMalloc((void**)&todo, nf * sizeof(uint32_t)), "hipMalloc crc todo") &&
+                           hip_ok(ctx, hipMemset(part, 0, ns * sizeof(clx_crc_part)), "hipMemset crc parts") &&
+                           hip_ok(ctx, hipMalloc((void**)&sfs, ns * sizeof(uint32_t)), "hipMalloc sf_start") &&
+                           hip_ok(ctx, hipMalloc((void**)&ek, nf * sizeof(uint32_t)), "hipMalloc errkey") &&
+                           hip_ok(ctx, hipMalloc((void**)&eb, nf * sizeof(uint64_t)), "hipMalloc end bits") &&
+                           hip_ok(ctx, hipMalloc((void**)&tk, ((ns + 63) / 64) * sizeof(uint32_t)), "hipMalloc taken") &&
+                           // (scratch starts cleared; clx_k_finalize leaves it cleared behind every run)
+                           hip_ok(ctx, hipMemset(sfs, 0xff, ns * sizeof(uint32_t)), "hipMemset sf_start") &&
+                           hip_ok(ctx, hipMemset(ek, 0xff, nf * sizeof(uint32_t)), "hipMemset errkey") &&
+                           hip_ok(ctx, hipMemset(tk, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "hipMemset taken") &&
+                           hip_ok(ctx, hipStreamSynchronize(nullptr), "hipStreamSynchronize");       // (the fills went through the null stream; the launches' streams do not wait for it)
+                };
+                if (!all()) {
+                    const std::string why = ctx->last_error;
+                    for (void* q : { (void*)sl, (void*)fs, (void*)fk, (void*)part, (void*)todo, (void*)sfs, (void*)ek, (void*)eb, (void*)tk }) if (q) (void)hipFree(q);
+                    ctx->last_error = why;
+                    return CLX_API_ERROR;
                 }
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_crc_part, ns * sizeof(clx_crc_part)));
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_crc_todo, nf * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMemset(F.d_crc_part, 0, ns * sizeof(clx_crc_part)));
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_sf_start, ns * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_errkey, nf * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_endbits, nf * sizeof(uint64_t)));
-                HIP_TRY(ctx, hipMalloc((void**)&F.d_taken, ((ns + 63) / 64) * sizeof(uint32_t)));
-                // (scratch starts cleared; clx_k_finalize leaves it cleared behind every run)
-                HIP_TRY(ctx, hipMemset(F.d_sf_start, 0xff, ns * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMemset(F.d_errkey, 0xff, nf * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMemset(F.d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipStreamSynchronize(nullptr));       // (the fills went through the null stream; the launches' streams do not wait for it)
+                F.d_slot_frame = sl; F.d_first_slot = fs; F.d_fkey = fk; F.d_crc_part = part; F.d_crc_todo = todo;
+                F.d_errkey = ek; F.d_endbits = eb; F.d_taken = tk;
+                F.d_sf_start = sfs;                      // (last: the sentinel)
             }
         }
         // what cannot share a launch with the pending submissions goes after them: another caller stream (the launch waits for

@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #ifndef CLX_HD
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define CLX_HD __host__ __device__ __forceinline__
 #else
 #define CLX_HD static inline

@@ -531,8 +531,16 @@ __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover&
         for (int j = 0; j < 4; ++j) { w[j] = src[32 * (4 * half + j)]; a[j] = rp[8 * (4 * half + j)]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j] = M.all_real ? a[j] + toff : (a[j] & 1ull) ? (a[j] & ~1ull) + doff : a[j] + toff;
+#ifndef CLN_NO_STORES
         clx_store4x16(reinterpret_cast<int32_t*>(a[0]), reinterpret_cast<int32_t*>(a[1]), reinterpret_cast<int32_t*>(a[2]), reinterpret_cast<int32_t*>(a[3]),
                       w[0], w[1], w[2], w[3]);
+#else       // (measurement: what the write path costs -- everything but the store instructions; wrong output)
+        {
+            const clx_i32x4 x0 = { w[0].x, w[0].y, w[0].z, w[0].w }, x1 = { w[1].x, w[1].y, w[1].z, w[1].w }, x2 = { w[2].x, w[2].y, w[2].z, w[2].w }, x3 = { w[3].x, w[3].y, w[3].z, w[3].w };
+            asm volatile("s_nop 1" :: "v"(reinterpret_cast<int32_t*>(a[0])), "v"(reinterpret_cast<int32_t*>(a[1])), "v"(reinterpret_cast<int32_t*>(a[2])), "v"(reinterpret_cast<int32_t*>(a[3])),
+                         "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "memory");
+        }
+#endif
     }
     clx_wave_sync();
 }
@@ -809,7 +817,9 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
     uint32_t nslow = 0;
     for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
         const bool live = n != 0u && !r.err;
+#ifndef CLN_LAND_FIRST
         cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
+#endif
         int4* const mine = cln_mine(stage, t0, lane);
         if (slow) {
             // back to the lean turns as soon as every live lane's history fits the packed form
@@ -827,6 +837,9 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             cln_land(g, row, CR, crc); cln_request(buf, g, cur.p, !calm || (t0 & 96u) == 0u);      // (calm: every fourth pump -- the pumps are at the even turns)
             CLX_STAT(46, 1);
         }
+#ifdef CLN_LAND_FIRST
+        cln_flush(T, stage, M, lane);                    // (measurement: the ring lands in FRONT of the tile stores)
+#endif
         const bool was_slow = slow;                      // (no lean turn is tried: the history does not fit the packed form)
         int done = 0;
         bool refilled = false;                           // the ring was refilled on the spot once in this turn (a lane outran it)
@@ -1253,7 +1266,10 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     }
 }
 
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
+#ifndef CLN_WAVES
+#define CLN_WAVES 3
+#endif
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CLN_WAVES)))
 void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;
     cln_kernel<false>(L, runs, frames, n_slots, dump_all);

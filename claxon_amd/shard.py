@@ -39,7 +39,7 @@ def reduce_job(dist, elapsed_s, samples, n_bad, device=None):
     import torch
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     c = torch.tensor([int(samples), int(n_bad)], dtype=torch.int64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():      # (a group of one rank too: `bench.py --process-group` rehearses the collectives)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), int(c[0].item()), int(c[1].item())

@@ -290,7 +290,14 @@ int  clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_len,
  * One batch, one caller stream at a time: a batch's submissions and runs come in on ONE `stream` until a clx_batch_flush /
  * clx_batch_results on that stream (submissions that arrive on another stream are not merged with pending ones, but what is
  * already in flight is ordered against the stream it came in on only; distinct batches and contexts are independent).
- * Accepted submissions are never dropped: re-planning or destroying a batch launches what is still pending first. */
+ * Output buffers are told apart by their BASE address: two submissions with the same `d_out` are ordered (the later one goes out
+ * behind the earlier one), two whose buffers overlap but start at different addresses are NOT -- hand over buffers that are either
+ * identical or disjoint.
+ * Pending submissions are not forgotten: re-planning or destroying a batch launches what is still pending first.  A merged launch
+ * that cannot be made (a HIP error) drops ITS submissions: the call that triggered the launch returns CLX_API_ERROR, and so does,
+ * once, the next clx_batch_flush / clx_batch_results / clx_batch_interleave of the batch (clx_last_error says which).  A batch
+ * that still holds pending submissions should be flushed or destroyed BEFORE its context: clx_batch_destroy then drains the device
+ * instead of ordering the launch behind the (possibly gone) stream the submissions came in on. */
 #ifndef CLX_SUBMIT_DEPTH
 #define CLX_SUBMIT_DEPTH 24     /* the most submissions any batch keeps in flight */
 #endif

@@ -80,3 +80,32 @@ def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_onl
                                  res.ctypes.data, flags, sfd.ctypes.data, C.byref(nslots))
     assert st == 0
     return out, res, sfd[:nslots.value]
+
+
+def decode_runs(arenas, arena_len, descs, out_offs, verify_crc=False, fill=0, path=0, first_gen=7):
+    """Consecutive runs of ONE planned batch on ONE set of scratch under simulation (sim_decode_frames_runs: the multi-run state of
+    clx_batch_submit -- generation-tagged marks and CRC parts, slot maps re-dealt run by run, scratch left cleared by
+    clx_k_finalize).  Run r decodes arenas[r]; returns [(out, results), ...]."""
+    descs = np.ascontiguousarray(descs, dtype=cx.FRAME_DESC_DTYPE)
+    out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+    n = descs.size
+    total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+    keep, ptrs = [], []
+    for a in arenas:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        buf = np.zeros(a.size + 64, dtype=np.uint8)
+        base = (-buf.ctypes.data) % 16
+        al = buf[base:base + a.size]
+        al[:] = a
+        keep.append((buf, al)); ptrs.append(al.ctypes.data)
+    outs = [np.full(total, fill, dtype=np.int32) for _ in arenas]
+    ress = [np.zeros(n, dtype=cx.FRAME_RESULT_DTYPE) for _ in arenas]
+    k = len(arenas)
+    VP = C.c_void_p * k
+    flags = (cx.VERIFY_CRC16 if verify_crc else 0) | path
+    L = lib()
+    L.sim_decode_frames_runs.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    st = L.sim_decode_frames_runs(VP(*ptrs), arena_len, k, descs.ctypes.data, n, VP(*[o.ctypes.data for o in outs]), out_offs.ctypes.data,
+                                  VP(*[r.ctypes.data for r in ress]), flags, first_gen & 0xffffffff)
+    assert st == 0
+    return list(zip(outs, ress))

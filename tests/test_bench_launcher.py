@@ -90,3 +90,21 @@ def test_devices_option_maps_ranks_to_devices():
     import bench
     assert [bench._device_of("3,1,2", r) for r in range(4)] == [3, 1, 2, 3] and bench._device_of("", 5) == 5
     assert bench._launch_sizes(20, 12) == [12, 8] and bench._launch_sizes(24, 12) == [12, 12] and bench._launch_sizes(5, 1) == [1] * 5
+
+
+def test_a_process_group_of_one_rank_reduces_like_none():
+    """`bench.py --process-group` (round 5): the MAX / SUM / all_gather reductions through a process group of ONE rank give what
+    the single-process path computes without a group (gloo here; on the GPU box the same flag runs them through RCCL)."""
+    import torch.distributed as dist
+    from test_shard_gloo import _free_port
+    sys.path.insert(0, ROOT)
+    import bench
+    from claxon_amd import shard
+    plain = shard.reduce_job(None, 0.25, 1234, 0)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert shard.reduce_job(dist, 0.25, 1234, 0) == plain == (0.25, 1234, 0)
+        assert bench._gather_floats(dist, [1.5, 2.0], 1) == bench._gather_floats(None, [1.5, 2.0], 1) == [[1.5, 2.0]]
+    finally:
+        dist.destroy_process_group()

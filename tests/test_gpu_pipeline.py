@@ -143,3 +143,25 @@ def test_small_batch_choices(setup):
     res = b.results()
     check(w, out, res, ref, r, True)
     b.close()
+
+
+@pytest.mark.gpu
+def test_bench_line_with_the_collectives_through_rccl_on_one_rank():
+    """`bench.py --process-group --backend nccl` with one rank: init_process_group("nccl", device_id=...), the barrier around the
+    timed regions and the MAX / SUM / all_gather reductions on device tensors run through RCCL on the GPU that is there -- the
+    N-rank line's collectives on hardware (round 5; no second GPU on this box).  The closing barrier is outside the clock."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--process-group", "--backend", "nccl", "--frames", "1024", "--steps", "8",
+                        "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    pg = j["config"]["process_group"]
+    assert pg["backend"].startswith("nccl") and pg["world_size"] == 1 and pg["barrier_us"] is not None and pg["barrier_us"] >= 0
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["bit_exact"] is True

@@ -329,3 +329,46 @@ def test_sim_waves_composed_by_content(oracle):
     # windows end where the block size, the width class or the channel count changes; mono and multi-channel frames stay where they are
     wm = synth.concat("mixed shapes", [synth.config5_unique(80), synth.config4(70), synth.small_mixed(40), synth.config3(66)])
     assert counted(wm, cx.COMPOSE)[0] >= 3
+
+
+@pytest.mark.parametrize("compose", [cx.NO_COMPOSE, cx.COMPOSE], ids=["stream-order", "composed"])
+@pytest.mark.parametrize("first_gen", [7, 0xffffffff], ids=["gen7", "gen-wrap"])
+def test_sim_consecutive_runs_on_one_scratch(oracle, compose, first_gen):
+    """The multi-run state of clx_batch_submit (round 4) under the simulator: consecutive runs of ONE planned batch
+    on ONE set of scratch -- sf_start / errkey as clx_k_finalize leaves them, group marks and CRC parts tagged with the run's
+    generation number (a stale part or mark of an EARLIER run must not be honoured, also across a wrap of the number), the run's
+    slot maps re-dealt by clx_k_compose from whatever the run before left.  Run r decodes the same frames with DIFFERENT damage
+    (which frames fail, which groups are given up and which CRC parts exist changes from run to run): every run matches the
+    oracle's decode of its own arena."""
+    import simlib
+    simlib.build()
+    w = synth.concat("runs", [synth.config5_unique(96), pc.giveup_workload(64), synth.config3(40)])
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
+    rng = np.random.default_rng(23)
+
+    def damaged(frac):
+        a = w.arena.copy()
+        for i in range(w.n):
+            if rng.uniform() >= frac:
+                continue
+            lo, hi = int(w.offs[i]) + int(descs["header_bytes"][i]), int(w.offs[i] + w.lens[i])
+            for _ in range(int(rng.integers(1, 3))):
+                pos = int(rng.integers(8 * lo, 8 * hi))
+                a[pos >> 3] ^= (0x80 >> (pos & 7))
+        return a
+
+    arenas = [w.arena.copy(), damaged(0.5), damaged(0.3), w.arena.copy(), damaged(0.7)]
+    runs = simlib.decode_runs(arenas, w.arena_len, descs, w.out_offs, verify_crc=True, fill=0x31313131,
+                              path=cx.PATH_LANES | cx.LANES_FUSED | compose, first_gen=first_gen)
+    n_bad = []
+    for a, (out, res) in zip(arenas, runs):
+        ref = np.full(out.size, 0x31313131, dtype=np.int32)
+        r = oracle.decode_batch(a[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, check_crc=True)
+        assert np.array_equal(res["status"], r["statuses"]) and np.array_equal(res["msg"], r["msgs"])
+        ok = np.nonzero(res["status"] == cx.OK)[0]
+        assert np.array_equal(res["end_bit"][ok], r["end_bits"][ok])
+        for i in ok:
+            lo, hi = int(w.out_offs[i]), int(w.out_offs[i]) + int(w.channels[i]) * int(w.block_sizes[i])
+            assert np.array_equal(out[lo:hi], ref[lo:hi]), int(i)
+        n_bad.append(int(np.sum(res["status"] != cx.OK)))
+    assert n_bad[0] == 0 and n_bad[3] == 0 and min(n_bad[1], n_bad[2], n_bad[4]) >= 10, n_bad

@@ -1,5 +1,7 @@
 // TEST INFRASTRUCTURE: runs the production kernel source under the wave simulator.
 #include <vector>
+#include <algorithm>
+#include <cstring>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -10,42 +12,55 @@ extern "C" { uint64_t sim_stats[64]; }
 #include "clx_lean.hip"
 #include "clx_plan.h"
 
-extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
-                                 int32_t* out, const uint64_t* out_offs, clx_frame_result* results, uint32_t flags,
-                                 clx_sf_desc* sfd_out /* optional, n_slots entries */, uint64_t* n_slots_out) {
-    std::vector<clx_dev_frame> dev(n ? n : 1);
+// The lane path of one planned batch: the plan and ONE set of scratch (what a flight of the library holds), used by consecutive
+// runs -- sf_start / errkey as clx_k_finalize leaves them, the groups' marks and the CRC parts tagged with generation numbers, the
+// run's own slot maps that clx_k_compose re-deals run by run.
+struct SimLanes {
+    std::vector<clx_dev_frame> dev;
     uint64_t n_slots = 0;
-    if (clx_plan_frames(frames, n, out_offs, dev.data(), &n_slots) >= 0) return CLX_API_ERROR;
-    clx_plan_limits(frames, n, arena_len, dev.data());
-    std::vector<clx_sf_desc> sfd(n_slots ? n_slots : 1);
-    memset(sfd.data(), 0, sfd.size() * sizeof(clx_sf_desc));
-    const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
-    if (flags & CLX_PATH_LANES) {
-        std::vector<uint32_t> slot_frame(n_slots ? n_slots : 1), multi(n ? n : 1), sf_start(n_slots ? n_slots : 1, 0xffffffffu),
-            errkey(n ? n : 1, 0xffffffffu);
-        std::vector<uint64_t> endbits(n ? n : 1, 0);
-        const size_t n_multi = clx_plan_lanes(dev.data(), n, n_slots, slot_frame.data(), multi.data());
-        if (n_slots_out) *n_slots_out = n_slots;
-        // one run (the library merges several submissions of a batch into one launch: blockIdx.y; here always run 0)
-        std::vector<uint32_t> taken((n_slots + 63) / 64 + 1, 0u);
-        const bool lean = (flags & CLX_LANES_FUSED) && !(flags & CLX_LANES_GENERAL);
+    size_t n = 0, n_multi = 0, n_windows = 0;
+    uint32_t flags = 0, gen = 6u;
+    std::vector<uint32_t> slot_frame, multi, sf_start, errkey, taken, crc_todo, first_slot, fkey, slot_frame_plan, first_slot_plan;
+    std::vector<uint64_t> endbits;
+    std::vector<clx_crc_part> crc_part;
+    std::vector<clx_window> windows;
+    bool lean = false;
+    bool plan(const clx_frame_desc* frames, size_t n_, const uint64_t* out_offs, size_t arena_len, uint32_t flags_) {
+        n = n_; flags = flags_;
+        dev.assign(n ? n : 1, clx_dev_frame{});
+        if (clx_plan_frames(frames, n, out_offs, dev.data(), &n_slots) >= 0) return false;
+        clx_plan_limits(frames, n, arena_len, dev.data());
+        slot_frame.assign(n_slots ? n_slots : 1, 0u); multi.assign(n ? n : 1, 0u);
+        sf_start.assign(n_slots ? n_slots : 1, 0xffffffffu); errkey.assign(n ? n : 1, 0xffffffffu); endbits.assign(n ? n : 1, 0);
+        n_multi = clx_plan_lanes(dev.data(), n, n_slots, slot_frame.data(), multi.data());
+        taken.assign((n_slots + 63) / 64 + 1, 0u);
+        lean = (flags & CLX_LANES_FUSED) && !(flags & CLX_LANES_GENERAL);
+        crc_part.assign(n_slots ? n_slots : 1, clx_crc_part{});
+        crc_todo.assign(n ? n : 1, 0xa5a5a5a5u);
+        first_slot.assign(n ? n : 1, 0u); fkey.assign(n ? n : 1, 0u);
+        for (size_t i = 0; i < n; ++i) first_slot[i] = dev[i].first_slot;
+        windows.assign(n ? n : 1, clx_window{});
+        const int cmode = (!lean || (flags & CLX_NO_COMPOSE)) ? -1 : (flags & CLX_COMPOSE) ? 1 : 0;
+        n_windows = clx_plan_windows(dev.data(), n, cmode, windows.data());
+        slot_frame_plan = slot_frame; first_slot_plan = first_slot;      // (what must stay untouched)
+        return true;
+    }
+    // one run, as launch_pending / launch_lanes make it (clx_api.hip): a new generation number, the wrap handled as the library does
+    int run(const uint8_t* arena, size_t arena_len, int32_t* out, clx_frame_result* results) {
+        const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
+        if (++gen == 0u) {       // (the generation number wrapped: nothing stale may look current)
+            std::fill(taken.begin(), taken.end(), 0u);
+            memset(crc_part.data(), 0, crc_part.size() * sizeof(clx_crc_part));
+            gen = 1u;
+        }
         clx_runs runs;
         memset(&runs, 0, sizeof runs);
         runs.r[0].arena = arena; runs.r[0].alloc_len = alloc_len + 16; runs.r[0].out = out; runs.r[0].sf_start = sf_start.data();
         runs.r[0].errkey = errkey.data(); runs.r[0].end_bits = endbits.data(); runs.r[0].taken = lean ? taken.data() : nullptr;
-        runs.r[0].results = results; runs.r[0].gen = 7u;
-        std::vector<clx_crc_part> crc_part(n_slots ? n_slots : 1);
-        memset(crc_part.data(), 0, crc_part.size() * sizeof(clx_crc_part));
-        std::vector<uint32_t> crc_todo(n ? n : 1, 0xa5a5a5a5u);
+        runs.r[0].results = results; runs.r[0].gen = gen;
         runs.r[0].crc_part = crc_part.data(); runs.r[0].crc_todo = crc_todo.data();
         runs.r[0].flags = (flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u;
         // the run's slot maps: the plan's, or its own when waves are composed by content (as the library does: clx_plan_windows)
-        std::vector<uint32_t> first_slot(n ? n : 1, 0u), fkey(n ? n : 1, 0u);
-        for (size_t i = 0; i < n; ++i) first_slot[i] = dev[i].first_slot;
-        std::vector<clx_window> windows(n ? n : 1);
-        const int cmode = (!lean || (flags & CLX_NO_COMPOSE)) ? -1 : (flags & CLX_COMPOSE) ? 1 : 0;
-        const size_t n_windows = clx_plan_windows(dev.data(), n, cmode, windows.data());
-        std::vector<uint32_t> slot_frame_plan = slot_frame, first_slot_plan = first_slot;      // (what must stay untouched)
         runs.r[0].slot_frame = slot_frame.data(); runs.r[0].first_slot = first_slot.data(); runs.r[0].fkey = n_windows ? fkey.data() : nullptr;
         if (n_multi) {
             if (flags & CLX_LANES_GENERAL) SIM_LAUNCH(clx_k_scan_general, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
@@ -93,6 +108,7 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, runs, dev.data(), (uint32_t)n);
         // (the scratch is left ready for a next run)
         for (size_t i = 0; i < n; ++i) if (errkey[i] != 0xffffffffu) return CLX_API_ERROR;
+        if ((flags & CLX_LANES_FUSED)) for (uint64_t sl = 0; sl < n_slots; ++sl) if (sf_start[sl] != 0xffffffffu) return CLX_API_ERROR;
         if (flags & CLX_VERIFY_CRC16) {
             // (how many frames the lean kernels' lanes settled themselves, how many the stand-alone kernel has to check)
             for (size_t i = 0; i < n; ++i) { if (crc_todo[i] > 1u) return CLX_API_ERROR; sim_stats[14 + crc_todo[i]] += 1;
@@ -101,6 +117,41 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         }
         return CLX_OK;
     }
+};
+
+// Consecutive runs of ONE planned batch on ONE set of scratch (the multi-run state of clx_batch_submit: generation-tagged marks and
+// CRC parts, slot maps re-dealt run by run, scratch left cleared by clx_k_finalize): run r decodes arenas[r] (all of arena_len
+// bytes, the same frame layout -- what differs is damage) into outs[r] / results[r].  first_gen: the generation number of run 0
+// (0xffffffff makes run 1 wrap).
+extern "C" int sim_decode_frames_runs(const uint8_t* const* arenas, size_t arena_len, size_t n_runs, const clx_frame_desc* frames, size_t n,
+                                      int32_t* const* outs, const uint64_t* out_offs, clx_frame_result* const* results, uint32_t flags, uint32_t first_gen) {
+    if (!(flags & CLX_PATH_LANES)) return CLX_API_ERROR;
+    SimLanes L;
+    if (!L.plan(frames, n, out_offs, arena_len, flags)) return CLX_API_ERROR;
+    L.gen = first_gen - 1u;
+    for (size_t r = 0; r < n_runs; ++r) {
+        const int st = L.run(arenas[r], arena_len, outs[r], results[r]);
+        if (st != CLX_OK) return st;
+    }
+    return CLX_OK;
+}
+
+extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
+                                 int32_t* out, const uint64_t* out_offs, clx_frame_result* results, uint32_t flags,
+                                 clx_sf_desc* sfd_out /* optional, n_slots entries */, uint64_t* n_slots_out) {
+    if (flags & CLX_PATH_LANES) {
+        SimLanes L;
+        if (!L.plan(frames, n, out_offs, arena_len, flags)) return CLX_API_ERROR;
+        if (n_slots_out) *n_slots_out = L.n_slots;
+        return L.run(arena, arena_len, out, results);
+    }
+    std::vector<clx_dev_frame> dev(n ? n : 1);
+    uint64_t n_slots = 0;
+    if (clx_plan_frames(frames, n, out_offs, dev.data(), &n_slots) >= 0) return CLX_API_ERROR;
+    clx_plan_limits(frames, n, arena_len, dev.data());
+    std::vector<clx_sf_desc> sfd(n_slots ? n_slots : 1);
+    memset(sfd.data(), 0, sfd.size() * sizeof(clx_sf_desc));
+    const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
     SIM_LAUNCH(clx_k_residual, n, 64, arena, alloc_len, dev.data(), (uint32_t)n, out, sfd.data(), results);
     if (n_slots_out) *n_slots_out = n_slots;
     if (sfd_out) memcpy(sfd_out, sfd.data(), n_slots * sizeof(clx_sf_desc));
