@@ -508,7 +508,7 @@ int plan_lanes_data(clx_batch* b) {
 }
 // (Re)plan `b` for a list of frames: host-side planning, kernel selection, device buffers (reused when they are large enough).
 int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags);
-int launch_pending(clx_batch* b);
+int launch_pending(clx_batch* b, bool inputs_ready);
 int batch_plan(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint64_t* out_sample_offsets, uint32_t flags) {
     const int st = batch_plan_(b, frames, n, out_sample_offsets, flags);
     if (st != CLX_OK) { b->n = 0; b->n_slots = 0; b->n_multi = 0; b->planned_arena_len = (size_t)-1; }      // a failed plan leaves an empty batch, not a half-updated one
