@@ -275,20 +275,27 @@ def main():
     if merged:
         roofline["merged_launch"] = merged
     if prof and prof.get("insts"):
-        # What actually bounds these kernels: the SIMDs' instruction issue.  A SIMD of gfx950 takes one vector
-        # instruction per ~4.2 cycles whatever it is (2.3 for the simplest: mov / add / logic / shift), a scalar one between vector
-        # ones ~2.2, an LDS one ~8 (profiles/r03_ubench_valu_cost.txt, r02_ubench_valu_peak.txt); the counts are wave-instructions
-        # per launch from the same committed --pmc profile as `traffic`.
+        # How busy the vector pipes are (round 5's measurement, profiles/r05_ubench_coissue.txt): a SIMD of gfx950
+        # takes one vector instruction per ~4.35 cycles in code like this whatever the instruction is (the 2.3-cycle rate of
+        # mov / add / shift only shows when nothing else is mixed in), and scalar, LDS and branch instructions of OTHER waves issue
+        # beside it (+0.5 .. 2 cycles per scalar instruction, ~0 per LDS instruction) -- they are NOT added on top, as rounds 3-4's
+        # flat sum (4.2 / 2.2 / 8.0 cycles) did.  So the bound is the vector instructions alone; what is left of the step is the
+        # pipes waiting: for a wave that is ready (two or three waves per SIMD), for LDS / memory round trips, for the fill and
+        # drain of the rotation.  Counts: wave-instructions per launch from the same committed --pmc profile as `traffic`.
         ins = prof["insts"].values()
         valu, salu, lds = (sum(k[c] for k in ins) for c in ("valu", "salu", "lds"))
         smp = float(prof.get("samples_per_launch") or w.total_samples)
-        cyc = (4.2 * valu + 2.2 * salu + 8.0 * lds) / 1024.0                 # per SIMD (256 CUs x 4)
-        bound_ms = cyc / 2.2e6                                               # at the ~2.2 GHz the kernels run at (GRBM_GUI_ACTIVE)
+        VALU_CYCLES, CLOCK_MHZ = 4.35, 2280.0                                # (measured: 16 slow-class VALU at 8 waves per SIMD; shader clock)
+        cyc = VALU_CYCLES * valu / 1024.0                                    # per SIMD (256 CUs x 4)
+        busy_ms = cyc / (CLOCK_MHZ * 1e3)
         scale = w.total_samples / smp
-        roofline["issue"] = {"bound": "valu issue", "valu_per_sample": round(64.0 * valu / smp, 1), "salu_per_sample": round(64.0 * salu / smp, 1),
-                             "lds_per_sample": round(64.0 * lds / smp, 2), "simd_cycles_per_launch": int(cyc * scale),
-                             "bound_ms": round(bound_ms * scale, 4), "frac": round(bound_ms * scale / t_path_ms, 4),
-                             "note": "instruction counts: committed rocprofv3 --pmc profile (traffic_source); frac = issue-bound time / time of the step"}
+        roofline["issue"] = {"bound": "vector pipe (VALU issue)", "valu_per_sample": round(64.0 * valu / smp, 1), "salu_per_sample": round(64.0 * salu / smp, 1),
+                             "lds_per_sample": round(64.0 * lds / smp, 2), "valu_cycles_each": VALU_CYCLES, "clock_mhz": CLOCK_MHZ,
+                             "simd_cycles_per_launch": int(cyc * scale),
+                             "valu_busy_ms": round(busy_ms * scale, 4), "valu_busy_frac": round(busy_ms * scale / t_path_ms, 4),
+                             "waiting_frac": round(1.0 - busy_ms * scale / t_path_ms, 4),
+                             "note": "instruction counts: committed rocprofv3 --pmc profile (traffic_source); valu_busy_frac = the vector pipes' "
+                                     "busy time / time of the step; scalar and LDS instructions co-issue (profiles/r05_ubench_coissue.txt) and are not added"}
 
     extras = rank == 0 and not args.no_extras
     if extras:
@@ -780,7 +787,7 @@ def _pmc_traffic(workload, frames):
             # the counters belong to the kernel sources they were taken with: an entry from other sources is refused, not quoted
             have = kernel_source_sha16()
             if e.get("kernel_src_sha16") != have:
-                return None, "STALE: %s was taken with kernel sources %s, these are %s (tools/profile_r04.sh + tools/update_traffic.py renew it)" % (
+                return None, "STALE: %s was taken with kernel sources %s, these are %s (tools/profile_round.sh + tools/update_traffic.py renew it)" % (
                     e.get("source"), e.get("kernel_src_sha16"), have), None
             return e.get("path_bytes"), e.get("source"), e
     except Exception:

@@ -273,6 +273,9 @@ struct clx_batch {
     uint32_t* d_multi = nullptr;
     size_t n_multi = 0;
     bool any_bps_le16 = false, any_bps_gt16 = false;     // which of clx_k_lean / clx_k_lean24 can find work at all
+    unsigned general_grid = 0;       // workgroups per run of the general lane kernels behind the tiers (clx_plan_general_grid)
+    uint32_t* d_most_left = nullptr; // the longest list of groups the tiers left in any run so far (clx_k_left), and where the host
+    uint32_t* h_most_left = nullptr; // finds a copy of it (pinned; read without waiting: it sizes later launches)
     uint32_t* d_sf_start = nullptr;
     uint32_t* d_errkey = nullptr;
     uint64_t* d_endbits = nullptr;
@@ -415,6 +418,8 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->d_errkey) (void)hipFree(b->d_errkey);
     if (b->d_endbits) (void)hipFree(b->d_endbits);
     if (b->d_taken) (void)hipFree(b->d_taken);
+    if (b->d_most_left) (void)hipFree(b->d_most_left);
+    if (b->h_most_left) (void)hipHostFree(b->h_most_left);
     if (b->d_crc_part) (void)hipFree(b->d_crc_part);
     if (b->d_crc_todo) (void)hipFree(b->d_crc_todo);
     if (b->d_first_slot) (void)hipFree(b->d_first_slot);
@@ -461,6 +466,9 @@ template <typename T> bool grow(clx_ctx* ctx, T** p, size_t* cap, size_t need, c
     *cap = want;
     return true;
 }
+// the marks of the groups of 64 slots (clx_k_lean's "taken in run gen"), and behind them the list clx_k_left makes of the groups the
+// tiers left: a count and up to one entry per group
+size_t taken_bytes(uint64_t n_slots) { return (size_t)(2u * ((n_slots + 63) / 64) + 2u) * sizeof(uint32_t); }
 // The lane kernels' plan data for the batch as planned: slot -> frame map, the multi-channel frames, the scratch of flight 0.
 int plan_lanes_data(clx_batch* b) {
     clx_ctx* ctx = b->ctx;
@@ -475,15 +483,20 @@ int plan_lanes_data(clx_batch* b) {
     b->n_windows = clx_plan_windows(b->h_frames.data(), n, cmode, windows.data());
     b->any_bps_le16 = b->any_bps_gt16 = false;
     for (size_t i = 0; i < n; ++i) { if (b->h_frames[i].bps <= 16u) b->any_bps_le16 = true; else b->any_bps_gt16 = true; }
+    b->general_grid = clx_plan_general_grid(b->h_frames.data(), slot_frame.data(), b->n_slots);
+    if (!b->d_most_left && !hip_ok(ctx, hipMalloc((void**)&b->d_most_left, sizeof(uint32_t)), "hipMalloc most_left")) return CLX_API_ERROR;
+    if (!b->h_most_left && !hip_ok(ctx, hipHostMalloc((void**)&b->h_most_left, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc most_left")) return CLX_API_ERROR;
+    *b->h_most_left = 0u;
+    if (!hip_ok(ctx, hipMemset(b->d_most_left, 0, sizeof(uint32_t)), "memset most_left")) return CLX_API_ERROR;
     if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
         !grow(ctx, &b->d_multi, &b->cap[5], nf * sizeof(uint32_t), "hipMalloc multi") ||
         !grow(ctx, &b->d_sf_start, &b->cap[6], ns * sizeof(uint32_t), "hipMalloc sf_start") ||
         !grow(ctx, &b->d_errkey, &b->cap[7], nf * sizeof(uint32_t), "hipMalloc errkey") ||
         !grow(ctx, &b->d_endbits, &b->cap[8], nf * sizeof(uint64_t), "hipMalloc endbits") ||
-        !grow(ctx, &b->d_taken, &b->cap[9], ((ns + 63) / 64) * sizeof(uint32_t), "hipMalloc taken") ||
+        !grow(ctx, &b->d_taken, &b->cap[9], taken_bytes(ns), "hipMalloc taken") ||
         !grow(ctx, &b->d_crc_part, &b->cap[10], ns * sizeof(clx_crc_part), "hipMalloc crc_part") ||
         !grow(ctx, &b->d_crc_todo, &b->cap[11], nf * sizeof(uint32_t), "hipMalloc crc_todo") ||
-        !hip_ok(ctx, hipMemset(b->d_taken, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "memset taken") ||
+        !hip_ok(ctx, hipMemset(b->d_taken, 0, taken_bytes(ns)), "memset taken") ||
         !hip_ok(ctx, hipMemset(b->d_crc_part, 0, ns * sizeof(clx_crc_part)), "memset crc_part") ||
         !hip_ok(ctx, hipMemset(b->d_sf_start, 0xff, ns * sizeof(uint32_t)), "memset sf_start") ||
         !hip_ok(ctx, hipMemset(b->d_errkey, 0xff, nf * sizeof(uint32_t)), "memset errkey") ||
@@ -711,11 +724,26 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
             hipLaunchKernelGGL(clx_k_lean24, dim3(groups, n_runs), dim3(64), 0, stream, runs,
                                (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
         }
+        // the general kernels: every group when no tier ran in front; else the groups the tiers left, listed by clx_k_left, through a
+        // grid sized for what the descriptors say will be left (clx_plan_general_grid: usually a fraction of the groups, and nothing to do)
+        // (one run by itself keeps the full grid: the workgroups that find nothing wait for nobody there, and a batch that is run
+        //  once has no earlier run to learn from; merged launches size the grid by the plan and by the longest list seen so far)
+        unsigned ggrid = groups;
+        const bool listed = runs.r[0].taken != nullptr;
+        if (listed) {
+            if (!mark("clx_k_left")) return false;
+            hipLaunchKernelGGL(clx_k_left, dim3((groups + 255) / 256, n_runs), dim3(256), 0, stream, runs, (uint32_t)groups, b->d_most_left);
+            if (n_runs > 1 && b->general_grid) {
+                const unsigned seen = b->h_most_left ? *(volatile uint32_t*)b->h_most_left : 0u;
+                ggrid = std::min(groups, std::max(b->general_grid, 2u * seen + 16u));
+            }
+        }
         if (!mark("clx_k_lanes")) return false;             // (+ clx_k_lanes_hi, its order > 12 twin)
-        hipLaunchKernelGGL(clx_k_lanes, dim3(groups, n_runs), dim3(64), 0, stream, runs,
+        hipLaunchKernelGGL(clx_k_lanes, dim3(ggrid, n_runs), dim3(64), 0, stream, runs,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
-        hipLaunchKernelGGL(clx_k_lanes_hi, dim3(groups, n_runs), dim3(64), 0, stream, runs,
+        hipLaunchKernelGGL(clx_k_lanes_hi, dim3(ggrid, n_runs), dim3(64), 0, stream, runs,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
+        if (listed && b->h_most_left) (void)hipMemcpyAsync(b->h_most_left, b->d_most_left, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     }
     else {
         if (n_runs != 1) return false;
@@ -727,7 +755,7 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
     }
     if (!mark("clx_k_finalize")) return false;
     hipLaunchKernelGGL(clx_k_finalize, dim3((unsigned)((b->n + 255) / 256), n_runs), dim3(256), 0, stream, runs,
-                       (const clx_dev_frame*)b->d_frames, (uint32_t)b->n);
+                       (const clx_dev_frame*)b->d_frames, (uint32_t)b->n, (uint32_t)b->n_slots);
     if (b->flags & CLX_VERIFY_CRC16) {
         if (!mark("clx_k_crc16")) return false;
         hipLaunchKernelGGL(clx_k_crc16_runs, dim3(n_runs > 1 ? crc_grid_runs(b->n) : crc_grid(b->n), n_runs), dim3(256), 0, stream, runs,
@@ -854,7 +882,8 @@ int launch_pending(clx_batch* b, bool inputs_ready) {
     // (this stream's earlier launches are ahead of this one in the stream) a launch on ANOTHER stream must be waited for when it was
     // the last one to write one of this launch's output buffers -- however many launches ago -- or to use a scratch set this launch
     // uses (only after partial launches: flights are handed out in rotation, `merge` at a time, and merge * n_streams of them make
-    // a full round)
+    // a full round).  (Round 5 tried the scan AHEAD of its launch, on a stream of its own with a third set of flights:
+    // profiles/r05_scan_ahead_dropped.txt -- worse.)
     {
         uint64_t need[clx_batch::kMaxStreams] = {};      // per stream: the latest of its launches this one depends on
         for (const auto& P : b->pend) {
@@ -893,6 +922,7 @@ int launch_pending(clx_batch* b, bool inputs_ready) {
         if (F.scratch_stale) {     // (clx_k_finalize leaves the scratch cleared behind every run that gets that far)
             LP_TRY(hipMemsetAsync(F.d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), ms));
             LP_TRY(hipMemsetAsync(F.d_errkey, 0xff, std::max<size_t>(b->n, 1) * sizeof(uint32_t), ms));
+            LP_TRY(hipMemsetAsync(F.d_taken + (b->n_slots + 63) / 64, 0, sizeof(uint32_t), ms));       // (the list of groups left: its count)
             F.scratch_stale = false;
         }
         runs.r[n_runs++] = make_run(b, F, P.arena, P.arena_len, P.out, true);
@@ -976,6 +1006,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         if (F0.scratch_stale) {
             HIP_TRY(ctx, hipMemsetAsync(b->d_sf_start, 0xff, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(uint32_t), stream));
             HIP_TRY(ctx, hipMemsetAsync(b->d_errkey, 0xff, std::max<size_t>(b->n, 1) * sizeof(uint32_t), stream));
+            HIP_TRY(ctx, hipMemsetAsync(b->d_taken + (b->n_slots + 63) / 64, 0, sizeof(uint32_t), stream));
             F0.scratch_stale = false;
         }
         clx_runs runs;
@@ -1081,11 +1112,11 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
                            hip_ok(ctx, hipMalloc((void**)&sfs, ns * sizeof(uint32_t)), "hipMalloc sf_start") &&
                            hip_ok(ctx, hipMalloc((void**)&ek, nf * sizeof(uint32_t)), "hipMalloc errkey") &&
                            hip_ok(ctx, hipMalloc((void**)&eb, nf * sizeof(uint64_t)), "hipMalloc end bits") &&
-                           hip_ok(ctx, hipMalloc((void**)&tk, ((ns + 63) / 64) * sizeof(uint32_t)), "hipMalloc taken") &&
+                           hip_ok(ctx, hipMalloc((void**)&tk, taken_bytes(ns)), "hipMalloc taken") &&
                            // (scratch starts cleared; clx_k_finalize leaves it cleared behind every run)
                            hip_ok(ctx, hipMemset(sfs, 0xff, ns * sizeof(uint32_t)), "hipMemset sf_start") &&
                            hip_ok(ctx, hipMemset(ek, 0xff, nf * sizeof(uint32_t)), "hipMemset errkey") &&
-                           hip_ok(ctx, hipMemset(tk, 0, ((ns + 63) / 64) * sizeof(uint32_t)), "hipMemset taken") &&
+                           hip_ok(ctx, hipMemset(tk, 0, taken_bytes(ns)), "hipMemset taken") &&
                            hip_ok(ctx, hipStreamSynchronize(nullptr), "hipStreamSynchronize");       // (the fills went through the null stream; the launches' streams do not wait for it)
                 };
                 if (!all()) {
@@ -2281,6 +2312,13 @@ extern "C" void clx_reader_close(clx_reader* r) { delete r; }
 
 #ifdef CLX_TIMELINE
 // debug aid, see clx_device.h / tools/timeline.py: kernel 0 = residual, 1 = predict, 2 = scan, 3 = lanes
+extern "C" int clx_debug_timeline_reset(void) {
+    const uint32_t z[4] = { 0u, 0u, 0u, 0u };
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(clx_timeline_n), z, sizeof z, 0, hipMemcpyHostToDevice);
+}
+extern "C" int clx_debug_timeline_count(int kernel, uint32_t* n) {
+    return (int)hipMemcpyFromSymbol(n, HIP_SYMBOL(clx_timeline_n), sizeof(uint32_t), (size_t)kernel * sizeof(uint32_t), hipMemcpyDeviceToHost);
+}
 extern "C" int clx_debug_timeline(int kernel, void* host, size_t n_waves) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clx_timeline_buf), n_waves * 14 * sizeof(uint64_t),
                                     (size_t)kernel * CLX_TL_WAVES * 14 * sizeof(uint64_t), hipMemcpyDeviceToHost);

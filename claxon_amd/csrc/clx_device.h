@@ -105,6 +105,20 @@ __device__ uint64_t clx_timeline_buf[4][CLX_TL_WAVES][14];
             tl[0] = tl_r0; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[2] = tl_c0; tl[3] = __builtin_amdgcn_s_memtime(); \
             tl[4] = ((uint64_t)xcc << 32) | hwid; tl[5] = tl_wait; for (int tl_i = 0; tl_i < 8; ++tl_i) tl[6 + tl_i] = tl_ph[tl_i]; \
         } } while (0)
+/* the same with the wave's record taken off a counter (waves of several launches side by side: clx_debug_timeline_reset zeroes it); `tag` goes to field 5 */
+__device__ uint32_t clx_timeline_n[4];
+#define CLX_TL_END_SEQ(kid, tag) do { \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if ((threadIdx.x & 63u) == 0) { \
+            const uint32_t tl_w = atomicAdd(&clx_timeline_n[kid], 1u); \
+            if (tl_w < CLX_TL_WAVES) { \
+                uint32_t hwid, xcc; \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+                uint64_t* tl = clx_timeline_buf[kid][tl_w]; \
+                tl[0] = tl_r0; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[2] = tl_c0; tl[3] = __builtin_amdgcn_s_memtime(); \
+                tl[4] = ((uint64_t)xcc << 32) | hwid; tl[5] = (uint64_t)(tag); \
+            } } } while (0)
 #define CLX_TL_PARAM , uint64_t& tl_wait
 #define CLX_TL_ARG , tl_wait
 #define CLX_TL_PH_PARAM , uint64_t (&tl_ph)[8], uint64_t& tl_mark
@@ -121,6 +135,7 @@ __device__ uint64_t clx_timeline_buf[4][CLX_TL_WAVES][14];
 #define CLX_TL_WAIT(stmt) do { stmt; } while (0)
 #define CLX_TL_BEGIN() do {} while (0)
 #define CLX_TL_END(kid, wave) do {} while (0)
+#define CLX_TL_END_SEQ(kid, tag) do {} while (0)
 #endif
 
 #endif

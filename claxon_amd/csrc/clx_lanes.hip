@@ -1057,12 +1057,10 @@ __device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* r
 // Two kernels: waves whose highest predictor order is <= 12, and the rest (the 32-tap predictor state would otherwise
 // cost every wave its occupancy: 256 VGPRs = one wave per SIMD).  Both are launched over all slots; a wave leaves at once
 // when its subframes belong to the other kernel.
+// One group of 64 slots (`grp`) of run R.
 template <bool HI>
-__device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_dev_frame* __restrict__ frames,
-                 uint32_t n_slots, int32_t* __restrict__ dump_all) {
-    __shared__ LanesLds L;
-    const clx_run& R = runs.r[blockIdx.y];
-    if (R.taken != nullptr && R.taken[blockIdx.x] == R.gen) return;  // clx_k_lean (clx_lean.hip) decoded this group in this run
+__device__ __forceinline__ void clx_lanes_group(LanesLds& L, const clx_run& R, const clx_dev_frame* __restrict__ frames,
+                 uint32_t n_slots, int32_t* __restrict__ dump_all, const uint32_t grp) {
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
     const uint32_t* const sf_start = R.sf_start;
@@ -1071,7 +1069,7 @@ __device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_
     uint64_t* const end_bits = R.end_bits;
     CLX_TL_BEGIN();
     const int lane = (int)threadIdx.x;
-    const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+    const uint32_t slot = grp * 64u + (uint32_t)lane;
     // (the run's slot map: the plan's, or what clx_k_compose dealt -- clx_lean.hip; the scan's results are indexed by the plan's slot)
     uint32_t f = 0xffffffffu;
     if (slot < n_slots) f = R.slot_frame[slot];
@@ -1133,7 +1131,41 @@ __device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_
         if (err) clx_report_error(errkey, f, ch, err);
         else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(end_pos - o);
     }
-    CLX_TL_END(3, blockIdx.x);
+    CLX_TL_END(3, grp);
+}
+// Behind the lean tiers (R.taken != null) the general kernels do not look at every group: clx_k_left has listed the groups the tiers
+// left -- usually none -- and a grid that may be much smaller than the number of groups loops over that list.  (Round 4's form,
+// one workgroup of 14 KiB LDS per group that only read its group's mark, waited for room behind the other stream's decode kernel:
+// 3 756 workgroups per merged launch, median 0.46 ms, and the stream's next scan queued behind them.)
+// The list: R.taken[n_groups] = how many, R.taken[n_groups + 1 ..] = which, in no particular order.
+template <bool HI>
+__device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_dev_frame* __restrict__ frames,
+                 uint32_t n_slots, int32_t* __restrict__ dump_all) {
+    __shared__ LanesLds L;
+    const clx_run& R = runs.r[blockIdx.y];
+    if (R.taken == nullptr) { clx_lanes_group<HI>(L, R, frames, n_slots, dump_all, blockIdx.x); return; }
+    const uint32_t* const left = R.taken + (n_slots + 63u) / 64u;
+    const uint32_t n_left = left[0];
+#pragma unroll 1
+    for (uint32_t i = blockIdx.x; i < n_left; i += gridDim.x) {
+        clx_lanes_group<HI>(L, R, frames, n_slots, dump_all, left[1u + i]);
+        clx_wave_sync();                                     // (the next group's ring and stage start from scratch: one wave, program order)
+    }
+}
+// (most_left: the longest list any run of the batch has had -- the host reads it back, without waiting for it, to size the
+//  general kernels' grid of LATER launches: what is left for reasons only the stream knows -- 16-bit audio of more than 12 taps in a
+//  batch without the split tier, waves that give up -- is left again in the next run of the same batch)
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_left(const clx_runs runs, uint32_t n_groups, uint32_t* __restrict__ most_left) {
+    const clx_run& R = runs.r[blockIdx.y];
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_groups || R.taken == nullptr) return;
+    if (R.taken[g] != R.gen) {
+        uint32_t* const left = R.taken + n_groups;
+        const uint32_t i = atomicAdd(&left[0], 1u);
+        left[1u + i] = g;
+        if (most_left != nullptr) atomicMax(most_left, i + 1u);
+    }
 }
 extern "C" __global__ __launch_bounds__(64)
 void clx_k_lanes(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots,
@@ -1493,10 +1525,11 @@ void clx_k_lanes2(const uint8_t* __restrict__ arena, uint64_t arena_alloc_len,
 // F: error keys -> clx_frame_result
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(256)
-void clx_k_finalize(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_frames) {
+void clx_k_finalize(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_frames, uint32_t n_slots) {
     const clx_run& R = runs.r[blockIdx.y];
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
     if (f >= n_frames) return;
+    if (f == 0u && R.taken != nullptr) R.taken[(n_slots + 63u) / 64u] = 0u;     // (the list of groups the tiers left: empty for the next run)
     const uint32_t key = R.errkey[f];
     const clx_dev_frame fr = frames[f];
     clx_frame_result r;

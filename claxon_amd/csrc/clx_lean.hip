@@ -33,10 +33,12 @@
 // The ring is slot-major -- ring[slot][lane] -- so that a lane's dwords all sit in the lane's own LDS bank (bank = lane mod 32):
 // the lanes of a wave read at unrelated slots (their streams advance at their own pace), and in a lane-major layout those reads
 // collide three to four deep (measured: 56 % of the LDS's active cycles were bank conflicts).
+// 7 168 + 8 192 = 15 360 bytes per wave: TEN waves per CU.  (LDS is handed out in granules: with the wave's 64 row addresses beside them --
+// 15 872 bytes, rounds 3 and 4 -- the per-wave timeline shows nine, not the ten that 160 KiB / 15.5 KiB promises: profiles/r05_timeline_lean.txt.
+// The rows' places travel in registers now, LMover.)
 struct LeanLds {
     uint32_t ring[CLN_ROW][64];
     int4 stage[2][64][4];               // two turns' 64 x 16 output samples: int4 [tile][row ^ tile][piece ^ swizzle] (cln_mine)
-    uint64_t rowp[64];                  // where the wave's rows are (bit 0: a dump slot -- the turn's sample index is not added)
 };
 #define CLN_AT(col, slot) ((col)[(slot) * 64u])        // dword `slot` of the lane whose column `col` is
 
@@ -227,8 +229,10 @@ __device__ __forceinline__ int32_t cln_careful_code(LaneReader& r, LCur& c, uint
 // v_min3, one addition and one and a half v_alignbit), one vote per turn, the careful reader for everything rare.
 // One turn of sixteen code lengths.  Returns 1 (cursor advanced for the live lanes), 0 (a rare case: the careful steps'), -2
 // (nothing but the ring having run dry).
-template <bool EDGE>
-__device__ __forceinline__ int cln_scan_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t per, uint32_t rice2, uint32_t limit, bool live) {
+// ALL: every lane of the wave is live (the caller's vote): the masks that let lanes ride along are compiled out.
+template <bool EDGE, bool ALL>
+__device__ __forceinline__ int cln_scan_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t per, uint32_t rice2, uint32_t limit, bool live_) {
+    const bool live = ALL || live_;
     LCur c = cur;
     if (!live) c.pcnt = 0x7fffff00u;                  // (lanes that skip nothing never meet a partition edge)
     uint32_t c1 = 31u - c.k;
@@ -286,10 +290,91 @@ __device__ __forceinline__ int cln_scan_turn(const uint32_t* row, const LRing& g
     return -2;
 }
 
+// The same sixteen code lengths out of four 32-BIT windows (round 5).  The scan needs no remainder -- only where each code's
+// terminating one sits -- so one window register serves four codes as long as their four TERMINATORS lie in its first 31 bits, whatever
+// lies behind the last of them: per code v_ffbh, one addition (z + k + 1) and one v_lshl_or (the window moved on, a sentinel one
+// OR-ed in at bit 0 so that the register is never zero: v_ffbh needs no clamp), against v_ffbh, v_min, a subtraction and one and a half
+// funnel shifts over four registers above; per window two ring dwords instead of five.  The sentinel marks the end of what the
+// register knows: a terminator found AT or behind bit 31 is not believed -- the sum of the lengths then says so (bits in front of the
+// fourth terminator > 30) and the turn is left to the 128-bit form.  Worth trying while the codes are short (k <= CLN_SHORT_K: the caller's vote).
+// Returns 1 / 0 / -2 like cln_scan_turn, and -1: a window was too short, nothing else was wrong.
+#ifndef CLN_SHORT_K
+#define CLN_SHORT_K 5u
+#endif
+template <bool EDGE, bool ALL>
+__device__ __forceinline__ int cln_scan_turn_short(const uint32_t* row, const LRing& g, LCur& cur, uint32_t per, uint32_t rice2, uint32_t limit, bool live_) {
+    const bool live = ALL || live_;
+    LCur c = cur;
+    if (!live) c.pcnt = 0x7fffff00u;                  // (lanes that skip nothing never meet a partition edge)
+    uint32_t k1 = c.k + 1u;
+    bool bad = false;
+    uint32_t far = 0;                                 // the most bits in front of a window's fourth terminator
+    uint32_t pw = c.p;
+    const uint32_t pb = 4u + rice2, esc = rice2 ? 31u : 15u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (EDGE) {                                   // a partition that starts exactly here: its parameter comes first
+            const bool at = c.pcnt == 0u;
+            if (clx_any(at)) {
+                const uint32_t pv = cln_peek32(row, g, c.p);
+                if (at) {
+                    c.k = pv >> (32u - pb);
+                    bad = bad || c.k == esc || c.parts == 0u || c.next == 0u;
+                    c.p += pb; c.parts -= 1u; c.pcnt = c.next; c.next = per;
+                    k1 = c.k + 1u;
+                }
+            }
+            bad = bad || c.pcnt < 4u;                 // (a partition edge inside the four codes: the careful steps')
+        }
+        c.pcnt -= 4u;
+        pw = c.p;
+        const uint32_t s = cln_slot(g, (c.p - 1u) >> 5);
+        uint32_t w = clx_alignbit(CLN_AT(row, s), CLN_AT(row, s + 1u), 0u - c.p) | 1u;
+        const uint32_t l1 = (uint32_t)__builtin_clz(w) + k1; w = (w << (l1 & 31u)) | 1u;       // (w is never zero: the sentinel)
+        const uint32_t l2 = (uint32_t)__builtin_clz(w) + k1; w = (w << (l2 & 31u)) | 1u;
+        const uint32_t l3 = (uint32_t)__builtin_clz(w) + k1; w = (w << (l3 & 31u)) | 1u;
+        const uint32_t e4 = l1 + l2 + l3 + (uint32_t)__builtin_clz(w);                          // bits in front of the fourth terminator
+        far = e4 > far ? e4 : far;
+        c.p += e4 + k1;
+    }
+    const bool fits = far <= 30u;
+    const bool covered = ((pw - 1u) >> 5) + 2u <= g.fill && c.p <= limit;
+    const bool ok = !live || (!bad && fits && covered);
+    if (__all(ok)) {
+        const uint32_t p_in = cur.p;
+        cur = c;
+        if (!live) cur.p = p_in;
+        return 1;
+    }
+    if (__any(live && !bad && !fits)) return -1;      // (what was parsed behind a window that was too short means nothing)
+    if (__any(live && (bad || c.p > limit))) return 0;
+    return -2;
+}
+
+// one turn of the scan, in the form the wave's codes allow: four codes out of a 32-bit window while every live lane's parameter
+// is small (cln_scan_turn_short), else -- or when a window was too short for its four -- out of 128 bits
+template <bool ALL>
+__device__ __forceinline__ int cln_scan_turns(const uint32_t* row, const LRing& g, LCur& cur, uint32_t per, uint32_t rice2, uint32_t limit, bool live) {
+    const bool edge = clx_any((ALL || live) && cur.pcnt < 16u);
+    int done = -1;
+    if (__all((!ALL && !live) || cur.k <= CLN_SHORT_K)) {
+        if (edge) done = cln_scan_turn_short<true, ALL>(row, g, cur, per, rice2, limit, live);
+        else      done = cln_scan_turn_short<false, ALL>(row, g, cur, per, rice2, limit, live);
+        CLX_STAT(27, done > 0); CLX_STAT(28, done == -1);
+    }
+    if (done == -1) {
+        if (edge) done = cln_scan_turn<true, ALL>(row, g, cur, per, rice2, limit, live);
+        else      done = cln_scan_turn<false, ALL>(row, g, cur, per, rice2, limit, live);
+        CLX_STAT(29, done > 0);
+    }
+    return done;
+}
+
 extern "C" __global__ __launch_bounds__(64)
 void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ multi, uint32_t n_multi) {
     __shared__ struct { uint32_t ring[CLN_ROW][64]; } L;        // (the ring only: 7 KiB per wave -- they fit beside the decode waves)
     const clx_run& R = runs.r[blockIdx.y];
+    CLX_TL_BEGIN();
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
     uint32_t* const sf_start = R.sf_start;
@@ -380,26 +465,29 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
             }
             if (r.err) left = 0u;
         }
-        bool ring_ok = false, even = false;
+        bool ring_ok = false, even = false, fresh = false;
         uint32_t pumps = 0;
 #pragma unroll 1
         while (__any(left >= 16u && !r.err)) {
             const bool has = left >= 16u && !r.err;          // this lane has sixteen codes to skip
             const bool live = has && ring_able;
-            const LCur keep = cur;                           // (a lane without them rides along where it is: its ring stays consistent)
-            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); ring_ok = true; even = false; }
-            else if (cln_pump_now(calm, even)) { cln_land(g, row, NC, false); cln_request(buf, g, cur.p, !calm || (pumps & 3u) == 0u); ++pumps; }
+            if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); ring_ok = true; even = false; fresh = true; }
+            else {
+                fresh = false;
+                if (cln_pump_now(calm, even)) { cln_land(g, row, NC, false); cln_request(buf, g, cur.p, !calm || (pumps & 3u) == 0u); ++pumps; }
+            }
             even = !even;
             int done = 0;
-            bool refilled = false;
-            if (__all(live || !has)) {
-              again:
-                if (clx_any(live && cur.pcnt < 16u)) done = cln_scan_turn<true>(row, g, cur, per, rice2, r.limit, live);
-                else                                 done = cln_scan_turn<false>(row, g, cur, per, rice2, r.limit, live);
-                if (done == -2 && !refilled) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, NC, false); refilled = true; goto again; }
+            if (__all(live)) done = cln_scan_turns<true>(row, g, cur, per, rice2, r.limit, true);        // (the usual case: no lane rides along)
+            else if (__all(live || !has)) {
+                const LCur keep = cur;                       // (a lane without sixteen codes rides along where it is: its ring stays consistent)
+                done = cln_scan_turns<false>(row, g, cur, per, rice2, r.limit, live);
+                if (!has) cur = keep;                        // (its tail is still to come: nothing of the ride may stick)
             }
-            if (!has) cur = keep;                            // (its tail is still to come: nothing of the ride may stick)
             if (done > 0) { if (has) left -= 16u; continue; }
+            // nothing but the ring having run dry: it is filled again at the top and the turn taken once more
+            if (done == -2 && !fresh) { ring_ok = false; continue; }
+            CLX_STAT(30, 1);
             // sixteen careful steps (rolled) for the lanes that have them
 #pragma unroll 1
             for (int ii = 0; ii < 16; ++ii) {
@@ -438,6 +526,7 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
         }
         R.fkey[f] = key;
     }
+    CLX_TL_END_SEQ(2, ((uint64_t)R.gen << 32) | (blockIdx.y << 20) | blockIdx.x);
 }
 
 // ---- C: waves composed by content ---------------------------------------------------------------------------------------------
@@ -512,34 +601,36 @@ __device__ __forceinline__ int4* cln_mine(int4* stage0, uint32_t t0, int lane) {
     const uint32_t t = (t0 >> 4) & 1u;
     return stage0 + t * 256u + (((uint32_t)lane ^ t) * 4u);
 }
+// Where the wave's rows are: a wave-uniform base (the lowest row's address) and, per lane, its own row's distance from it in bytes
+// (0xffffffff: the lane has no row).  A mover fetches the distance of the row it writes from the lane that owns it (ds_bpermute: no
+// LDS storage), and the store takes base + distance as scalar base + 32-bit vector offset.  (A wave whose rows span 4 GiB or more
+// is not taken: cln_kernel.)
 struct LMover {
-    const uint64_t* rowp;      // LeanLds::rowp
+    uint64_t base;             // wave-uniform
+    uint32_t rowoff;           // this lane's row (bytes from `base`), or CLN_NO_ROW
     bool all_real;             // wave-uniform: every row of the wave exists
 };
+#define CLN_NO_ROW 0xffffffffu
 // the pair of tiles that starts at sample index t0 (a multiple of 32)
 __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
     clx_wave_sync();
     const uint32_t h = (uint32_t)lane >> 3, q = (uint32_t)lane & 7u, t = q >> 2;
     const int4* const src = stage0 + t * 256u + ((h ^ t) * 4u) + ((q & 3u) ^ ((h >> 1) & 3u));      // + 32 int4 per instruction (8 rows)
-    const uint64_t* const rp = M.rowp + h;
-    const uint64_t toff = 4ull * t0 + 16ull * q, doff = 16ull * q;
+    const uint32_t toff = 4u * t0 + 16u * q;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         int4 w[4];
-        uint64_t a[4];
+        uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { w[j] = src[32 * (4 * half + j)]; a[j] = rp[8 * (4 * half + j)]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = M.all_real ? a[j] + toff : (a[j] & 1ull) ? (a[j] & ~1ull) + doff : a[j] + toff;
+        for (int j = 0; j < 4; ++j) { w[j] = src[32 * (4 * half + j)]; o[j] = (uint32_t)__shfl((int)M.rowoff, (int)h + 8 * (4 * half + j), 64); }
 #ifndef CLN_NO_STORES
-        clx_store4x16(reinterpret_cast<int32_t*>(a[0]), reinterpret_cast<int32_t*>(a[1]), reinterpret_cast<int32_t*>(a[2]), reinterpret_cast<int32_t*>(a[3]),
-                      w[0], w[1], w[2], w[3]);
-#else       // (measurement: what the write path costs -- everything but the store instructions; wrong output)
-        {
-            const clx_i32x4 x0 = { w[0].x, w[0].y, w[0].z, w[0].w }, x1 = { w[1].x, w[1].y, w[1].z, w[1].w }, x2 = { w[2].x, w[2].y, w[2].z, w[2].w }, x3 = { w[3].x, w[3].y, w[3].z, w[3].w };
-            asm volatile("s_nop 1" :: "v"(reinterpret_cast<int32_t*>(a[0])), "v"(reinterpret_cast<int32_t*>(a[1])), "v"(reinterpret_cast<int32_t*>(a[2])), "v"(reinterpret_cast<int32_t*>(a[3])),
-                         "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "memory");
+        if (M.all_real) clx_store4x16_s(M.base, o[0] + toff, o[1] + toff, o[2] + toff, o[3] + toff, w[0], w[1], w[2], w[3]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (o[j] != CLN_NO_ROW) clx_store1x16_s(M.base, o[j] + toff, w[j]);      // (rows that do not exist are not written)
         }
+#else       // (measurement: what the write path costs -- everything but the store instructions; wrong output)
+        asm volatile("s_nop 1" :: "v"(o[0] + toff), "v"(o[1] + toff), "v"(o[2] + toff), "v"(o[3] + toff), "v"(w[0].x), "v"(w[1].x), "v"(w[2].x), "v"(w[3].x) : "memory");
 #endif
     }
     clx_wave_sync();
@@ -548,17 +639,13 @@ __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover&
 __device__ __forceinline__ void cln_store_single(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
     clx_wave_sync();
     const uint32_t h = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
-    int4 w[4];
-    uint64_t a[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t r = 16u * (uint32_t)k + h;
-        w[k] = stage0[r * 4u + (q ^ ((r >> 1) & 3u))];
-        const uint64_t rp = M.rowp[r];
-        a[k] = (rp & 1ull) ? (rp & ~1ull) + 16ull * q : rp + 4ull * t0 + 16ull * q;
+        const int4 w = stage0[r * 4u + (q ^ ((r >> 1) & 3u))];
+        const uint32_t o = (uint32_t)__shfl((int)M.rowoff, (int)r, 64);
+        if (o != CLN_NO_ROW) clx_store1x16_s(M.base, o + 4u * t0 + 16u * q, w);
     }
-    clx_store4x16(reinterpret_cast<int32_t*>(a[0]), reinterpret_cast<int32_t*>(a[1]), reinterpret_cast<int32_t*>(a[2]), reinterpret_cast<int32_t*>(a[3]),
-                  w[0], w[1], w[2], w[3]);
     clx_wave_sync();
 }
 // A finished pair leaves at the START of the turn after it (and what is left when the kernel ends): the stores then sit right in
@@ -1057,6 +1144,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     constexpr int OMAX = SPLIT ? 32 : 12;
     const clx_run& R = runs.r[blockIdx.y];
     if (SPLIT && R.taken[blockIdx.x] == R.gen) return;       // clx_k_lean has decoded this group
+    CLX_TL_BEGIN();                                          // (-DCLX_TIMELINE builds only: tools/timeline_lean.py)
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
     const uint32_t* const sf_start = R.sf_start;
@@ -1096,6 +1184,14 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     // ---- does this wave qualify?  Every live lane: <= 16-bit audio, a FIXED / LPC subframe of at most 12 taps whose header
     //      parses, the wave's common block size (a multiple of 16, beyond the prologue), a 16-byte aligned row.
     int32_t* const rowp = out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
+    // (where the wave's rows are: the lowest one's address, wave-uniform, and every lane's distance from it -- LMover)
+    uint64_t row_lo = active ? (uint64_t)(uintptr_t)rowp : ~0ull;
+#pragma unroll
+    for (int sx = 32; sx >= 1; sx >>= 1) {
+        const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(row_lo >> 32), sx, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)row_lo, sx, 64);
+        row_lo = other < row_lo ? other : row_lo;
+    }
+    const uint64_t row_far = active ? (uint64_t)(uintptr_t)rowp - row_lo + 4ull * bs : 0ull;      // (its last byte's distance, + 1)
     bool good = !active;
     SfHead h = { 1u, 0u, 0u, 1u };
     uint32_t bs0 = 0;
@@ -1105,7 +1201,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         bs0 = (uint32_t)__shfl((int)bs, (int)__ffsll((long long)am) - 1, 64);
     }
     if (active) {
-        good = fr.bps <= (SPLIT ? 24u : 16u) && bs == bs0 && (bs & 15u) == 0u && bs >= (SPLIT ? 64u : 32u) && (((uintptr_t)rowp) & 15u) == 0u &&
+        good = fr.bps <= (SPLIT ? 24u : 16u) && bs == bs0 && (bs & 15u) == 0u && bs >= (SPLIT ? 64u : 32u) && (((uintptr_t)rowp) & 15u) == 0u && row_far < 0xffffffffull &&
                r.pos <= r.limit && (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
         if (good) {
             h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
@@ -1166,12 +1262,10 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
 
     // ---- where the wave's rows are (cln_store_pair), dump slots for rows that do not exist
     LMover M;
-    {
-        L.rowp[lane] = active ? (uint64_t)(uintptr_t)rowp : ((uint64_t)(uintptr_t)(dump_all + (size_t)slot * 32u) | 1ull);
-        M.rowp = L.rowp;
-        M.all_real = __all(active);
-        clx_wave_sync();
-    }
+    M.base = ((uint64_t)clx_uniform((uint32_t)(row_lo >> 32)) << 32) | clx_uniform((uint32_t)row_lo);
+    M.rowoff = active ? (uint32_t)((uint64_t)(uintptr_t)rowp - row_lo) : CLN_NO_ROW;
+    M.all_real = __all(active);
+    (void)dump_all;                                         // (rows that do not exist are not written: no dump slots here)
     const Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
 
     // ---- careful prologue (as clx_lanes_body's): warm-up samples, the transition, the first residuals -- one sample per turn of
@@ -1264,6 +1358,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
             R.crc_part[cslot] = part;
         }
     }
+    CLX_TL_END_SEQ(3, ((uint64_t)R.gen << 32) | (blockIdx.y << 20) | blockIdx.x);
 }
 
 #ifndef CLN_WAVES

@@ -95,6 +95,33 @@ static inline size_t clx_plan_lanes(const clx_dev_frame* dev, size_t n, uint64_t
     return n_multi;
 }
 
+// How many workgroups per run the general lane kernels get BEHIND the lean tiers, where they loop over the list of groups the tiers
+// left (clx_k_left).  What the descriptors say about a group of 64 slots is what the tiers ask first -- at most 24 bits, one block
+// size that is a multiple of 16 and at least 32 (64 beyond 16 bits), rows that start on 16 bytes (taking the output's base as
+// aligned) -- and a group that fails there is left for certain; what only the stream says (an order beyond the tier's, a header
+// that does not parse, a wave that gives its group up) is rare: an eighth of the groups is held ready for it.  (Waves composed by
+// content hold frames of one block size and width class: the count is the same in stream order.)
+static inline unsigned clx_plan_general_grid(const clx_dev_frame* dev, const uint32_t* slot_frame, uint64_t n_slots) {
+    const uint64_t groups = (n_slots + 63) / 64;
+    uint64_t sure = 0;
+    for (uint64_t g = 0; g < groups; ++g) {
+        bool left = false;
+        uint32_t bs0 = 0;
+        for (uint64_t s = 64 * g; s < 64 * g + 64 && s < n_slots && !left; ++s) {
+            const uint32_t f = slot_frame[s];
+            if (f == 0xffffffffu) continue;
+            const clx_dev_frame& d = dev[f];
+            const uint32_t bs = d.block_size;
+            if (!bs0) bs0 = bs;
+            const uint64_t row = d.out_off + (uint64_t)(s - d.first_slot) * bs;
+            left = d.bps > 24u || bs != bs0 || (bs & 15u) != 0u || bs < (d.bps > 16u ? 64u : 32u) || (row & 3ull) != 0ull;
+        }
+        sure += left ? 1u : 0u;
+    }
+    const uint64_t want = 2 * sure + groups / 8 + 16;
+    return (unsigned)(want < groups ? want : groups);
+}
+
 // Windows of clx_k_compose: maximal runs of consecutive stereo frames of one block size and one width class (<= 16 bits or not),
 // cut every CLX_COMPOSE_WINDOW frames.  mode: 0 by content of the descriptors (a window is composed when it holds >= 256 frames and
 // its channel assignments differ), 1 every such window, -1 none.  `win` must hold n entries; returns their number.

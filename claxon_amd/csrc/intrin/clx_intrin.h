@@ -164,6 +164,17 @@ __device__ __forceinline__ void clx_store4x16(int32_t* p0, int32_t* p1, int32_t*
                  "global_store_dwordx4 %3, %7, off\n\ts_nop 1"
                  :: "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
+// the same with a wave-uniform base and 32-bit byte offsets (global_store ... saddr: address = scalar base + zero-extended vector offset)
+__device__ __forceinline__ void clx_store4x16_s(uint64_t base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
+    const clx_i32x4 a = { w0.x, w0.y, w0.z, w0.w }, b = { w1.x, w1.y, w1.z, w1.w }, c = { w2.x, w2.y, w2.z, w2.w }, d = { w3.x, w3.y, w3.z, w3.w };
+    asm volatile("global_store_dwordx4 %0, %4, %8\n\tglobal_store_dwordx4 %1, %5, %8\n\tglobal_store_dwordx4 %2, %6, %8\n\t"
+                 "global_store_dwordx4 %3, %7, %8\n\ts_nop 1"
+                 :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(a), "v"(b), "v"(c), "v"(d), "s"(base) : "memory");
+}
+__device__ __forceinline__ void clx_store1x16_s(uint64_t base, uint32_t o, const int4& w) {
+    const clx_i32x4 a = { w.x, w.y, w.z, w.w };
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(o), "v"(a), "s"(base) : "memory");
+}
 // Mid/side reconstruction of four samples for lane pairs (even lane = mid -> left, odd lane = side -> right), the short form:
 //   left = mid + ((side + 1) >> 1),   right = mid - (side >> 1) = mid + ((-side + 1) >> 1)
 // which equals frame.rs:382-384's ((2 mid | side & 1) +- side) / 2 while nothing wraps (|mid|, |side| < 2^29: the caller's range

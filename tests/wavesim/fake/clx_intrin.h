@@ -55,6 +55,10 @@ static inline uint4 clx_buf_load16(const clx_buf& b, uint32_t byte_off) {     //
 static inline void clx_store4x16(int32_t* p0, int32_t* p1, int32_t* p2, int32_t* p3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
     *reinterpret_cast<int4*>(p0) = w0; *reinterpret_cast<int4*>(p1) = w1; *reinterpret_cast<int4*>(p2) = w2; *reinterpret_cast<int4*>(p3) = w3;
 }
+static inline void clx_store1x16_s(uint64_t base, uint32_t o, const int4& w) { *reinterpret_cast<int4*>((uintptr_t)(base + o)) = w; }
+static inline void clx_store4x16_s(uint64_t base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
+    clx_store1x16_s(base, o0, w0); clx_store1x16_s(base, o1, w1); clx_store1x16_s(base, o2, w2); clx_store1x16_s(base, o3, w3);
+}
 static inline int32_t clx_ms_short_(int line, int32_t y, uint32_t sgn, uint32_t c) {
     const uint32_t side = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xF5, 0xF, 0xF, false);
     const uint32_t mid = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xA0, 0xF, 0xF, false);

@@ -33,7 +33,7 @@ struct SimLanes {
         slot_frame.assign(n_slots ? n_slots : 1, 0u); multi.assign(n ? n : 1, 0u);
         sf_start.assign(n_slots ? n_slots : 1, 0xffffffffu); errkey.assign(n ? n : 1, 0xffffffffu); endbits.assign(n ? n : 1, 0);
         n_multi = clx_plan_lanes(dev.data(), n, n_slots, slot_frame.data(), multi.data());
-        taken.assign((n_slots + 63) / 64 + 1, 0u);
+        taken.assign(2 * ((n_slots + 63) / 64) + 2, 0u);    // (the groups' marks, then the list clx_k_left makes: a count and the groups)
         lean = (flags & CLX_LANES_FUSED) && !(flags & CLX_LANES_GENERAL);
         crc_part.assign(n_slots ? n_slots : 1, clx_crc_part{});
         crc_todo.assign(n ? n : 1, 0xa5a5a5a5u);
@@ -49,7 +49,7 @@ struct SimLanes {
     int run(const uint8_t* arena, size_t arena_len, int32_t* out, clx_frame_result* results) {
         const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
         if (++gen == 0u) {       // (the generation number wrapped: nothing stale may look current)
-            std::fill(taken.begin(), taken.end(), 0u);
+            std::fill(taken.begin(), taken.begin() + (n_slots + 63) / 64, 0u);      // (the marks; the list behind them is empty between runs)
             memset(crc_part.data(), 0, crc_part.size() * sizeof(clx_crc_part));
             gen = 1u;
         }
@@ -90,22 +90,33 @@ struct SimLanes {
             // the lean kernel first (it marks the groups it decodes with this run's generation number), unless the caller
             // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
             if (lean) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
-            for (uint32_t t : taken) sim_stats[52] += t == runs.r[0].gen;
+            for (size_t gi = 0; gi < (n_slots + 63) / 64; ++gi) sim_stats[52] += taken[gi] == runs.r[0].gen;
             if (lean) {     // the split tier on what is left (the library launches it when the batch holds frames of more than 16 bits)
                 uint64_t before = 0, after = 0;
-                for (uint32_t t : taken) before += t == runs.r[0].gen;
+                for (size_t gi = 0; gi < (n_slots + 63) / 64; ++gi) before += taken[gi] == runs.r[0].gen;
                 SIM_LAUNCH(clx_k_lean24, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
-                for (uint32_t t : taken) after += t == runs.r[0].gen;
+                for (size_t gi = 0; gi < (n_slots + 63) / 64; ++gi) after += taken[gi] == runs.r[0].gen;
                 sim_stats[13] += after - before;
             }
-            SIM_LAUNCH(clx_k_lanes, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
-            SIM_LAUNCH(clx_k_lanes_hi, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
+            // behind the tiers the general kernels loop over the list of groups that were left, with a grid smaller than the list
+            // is long whenever it can be (a third of what is left: every workgroup takes several groups)
+            size_t ggrid = (n_slots + 63) / 64;
+            if (lean) {
+                SIM_LAUNCH(clx_k_left, (ggrid + 255) / 256, 256, runs, (uint32_t)ggrid, (uint32_t*)nullptr);
+                const uint32_t n_left = taken[ggrid];
+                sim_stats[49] += n_left;
+                if (n_left > ggrid) return CLX_API_ERROR;
+                ggrid = n_left >= 3 ? n_left / 3 : 1;
+            }
+            SIM_LAUNCH(clx_k_lanes, ggrid, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
+            SIM_LAUNCH(clx_k_lanes_hi, ggrid, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
         } else {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,
                        errkey.data(), endbits.data(), dump.data());
         }
-        SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, runs, dev.data(), (uint32_t)n);
+        SIM_LAUNCH(clx_k_finalize, (n + 255) / 256, 256, runs, dev.data(), (uint32_t)n, (uint32_t)n_slots);
+        if (lean && taken[(n_slots + 63) / 64] != 0u) return CLX_API_ERROR;      // (the list is left empty for the next run)
         // (the scratch is left ready for a next run)
         for (size_t i = 0; i < n; ++i) if (errkey[i] != 0xffffffffu) return CLX_API_ERROR;
         if ((flags & CLX_LANES_FUSED)) for (uint64_t sl = 0; sl < n_slots; ++sl) if (sf_start[sl] != 0xffffffffu) return CLX_API_ERROR;

@@ -230,6 +230,7 @@ static int update_dpp_(int line, int old, int src, int dpp_ctrl, int row_mask, i
 
 static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned old = *p; if (v < old) *p = v; return old; }   // lanes run one at a time
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned old = *p; *p = old + v; return old; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = *p; if (v > old) *p = v; return old; }
 static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
 struct int4 { int x, y, z, w; } __attribute__((aligned(16)));
 static inline int4 make_int4(int a, int b, int c, int d) { int4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }

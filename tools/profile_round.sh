@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-4 rocprofv3 evidence (round 3's script with this round's output names; the wait / bank-conflict counter pass is left out) (run through gpurun).  For the bench workload (config 3, the kernels of the TIMED steps: fused lane
+# A round's rocprofv3 evidence (run through gpurun; ROUND=r05 by default: the outputs' prefix).  For the bench workload (config 3, the kernels of the TIMED steps: fused lane
 # kernels with the lean 16-bit tier): kernel trace + stats of steps one at a time, of ONE merged launch of twelve steps, and of the
 # pipelined steps (the timed mode); HBM counters and SQ instruction / wait counters in separate --pmc passes.  For configs 2 / 4 / 5:
-# kernel stats and HBM counters of steps one at a time.  Outputs under gpurun_out/prof_r04_<name>/; summaries go to profiles/.
-# usage: tools/profile_r04.sh [names...]     names: config3 config2 config4 config5 (default: all)
+# kernel stats and HBM counters of steps one at a time.  Outputs under gpurun_out/prof_${ROUND}_<name>/; summaries go to profiles/.
+# usage: [ROUND=r05] tools/profile_round.sh [names...]     names: config3 config2 config4 config5 (default: all)
 set -u
+ROUND=${ROUND:-r05}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 NAMES=${*:-config3 config2 config4 config5}
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +15,7 @@ for NAME in $NAMES; do
     config4) ARGS="--workload config4 --frames 10000 --path lanes-fused";;
     *)       ARGS="--workload $NAME --frames 10000 --path lanes-fused";;
   esac
-  OUT=$REPO/gpurun_out/prof_r04_$NAME
+  OUT=$REPO/gpurun_out/prof_${ROUND}_$NAME
   mkdir -p "$OUT"
   BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-pipeline $ARGS"
   echo "== $NAME: kernel trace (one step at a time)"; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1

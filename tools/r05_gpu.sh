@@ -14,7 +14,7 @@ lib() { echo $REPO/claxon_amd/libclaxon_hip_$1.so; }
 stage=$1; shift
 case $stage in
 coissue)
-  $REPO/tools/ubench/coissue | tee $O/coissue.txt ;;
+  timeout 90 $REPO/tools/ubench/coissue | tee $O/coissue.txt ;;
 sat)
   VARS=$1; M=${2:-8}; ROUNDS=${3:-2}
   cd /tmp && export TMPDIR=/tmp

@@ -11,7 +11,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
-#define PAT(body) asm volatile(body : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+s"(sa), "+s"(sb), "+v"(lx), "+s"(sx), "+v"(sp) : "v"(b), "s"(sc), "v"(la), "s"(full))
+#define PAT(body) asm volatile(body : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+s"(sa), "+s"(sb), "+v"(lx), "+s"(sx), "+v"(sp) : "v"(b), "s"(sc), "v"(la), "s"(full) : "scc", "vcc", "memory")
 // operands: 0-3 vector chains, 4 sa, 5 sb, 6 lx, 7 sx, 8 sp, 9 b, 10 sc, 11 la, 12 full
 #define LW "s_waitcnt lgkmcnt(0)\n\t"
 #define S4 "v_perm_b32 %0, %0, %9, %9\n\tv_perm_b32 %1, %1, %9, %9\n\tv_perm_b32 %2, %2, %9, %9\n\tv_perm_b32 %3, %3, %9, %9\n\t"
@@ -77,6 +77,7 @@ template <int T> void run(uint64_t* d, int W, int iters) {
     uint64_t h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
     const double mhz = (double)h[0] / (double)h[1] * 100.0;          // s_memrealtime ticks at 100 MHz
     results[T][W] = ms * 1e-3 * mhz * 1e6 / ((double)W * iters);      // SIMD cycles per iteration per wave
+    if (T == 0) printf("shader clock during '16 S' at W=%d: %.0f MHz\n", W, mhz);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 template <int T> void all(uint64_t* d) {
@@ -84,12 +85,12 @@ template <int T> void all(uint64_t* d) {
     for (int w : Ws) run<T>(d, w, 4000);
     printf("%-46s", names[T]);
     for (int w : Ws) printf("  W=%d %7.2f", w, results[T][w]);
-    printf("\n");
+    printf("\n"); fflush(stdout);
     if constexpr (T + 1 < T_COUNT) all<T + 1>(d);
 }
 int main() {
     uint64_t* d; if (hipMalloc(&d, 64) != hipSuccess) return 1;
-    printf("SIMD cycles per iteration per wave (W waves per SIMD); one iteration = the pattern named\n");
+    printf("SIMD cycles per iteration per wave (W waves per SIMD); one iteration = the pattern named\n"); fflush(stdout);
     all<0>(d);
     return 0;
 }
