@@ -364,6 +364,32 @@ def main():
             ms_c = 1e3 * el_c / args.steps
             cfg["without_crc16"] = {"value": round(samples_c / (ms_c * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
                                     "note": "the same steps with the CRC-16 footer check left out (BENCH_r01 / r02's `value`); `value` verifies"}
+    if extras and world == 1 and pipelined and not w.bare_subframes and w.pcm is not None and int(np.max(w.bps)) <= 16:
+        # ---- narrow output straight from the decode (CLX_OUT_PCM16: interleaved 16-bit PCM written by the lean kernel from the tiles it
+        #      stages anyway -- half the bytes through the write path).  A secondary figure, never `value`: Claxon's Block is planar i32
+        #      (frame.rs:402-411); this is what examples/decode.rs:48-62 and lib.rs:473-520 do with it right afterwards.
+        bp = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=(path & (cx.COMPOSE | cx.NO_COMPOSE)) | cx.OUT_PCM16)
+        pouts = [torch.zeros(w.total_samples + 8, dtype=torch.int16, device=dev) for _ in range(bp.submit_depth)]
+        for i in range(len(pouts)):
+            bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i].data_ptr(), stream)
+        bp.flush(stream); torch.cuda.synchronize()
+        want16 = torch.from_numpy(w.pcm.reshape(-1, 2, w.pcm.size // (2 * w.n)).transpose(0, 2, 1).reshape(-1).astype(np.int16)).to(dev) \
+            if bool(np.all(w.channels == 2)) and bool(np.all(w.block_sizes == w.block_sizes[0])) else None
+        exact16 = (want16 is not None) and all(bool(torch.equal(o[:w.total_samples], want16)) for o in pouts) and bool(np.all(bp.results()["status"] == 0))
+        regs = []
+        for _ in range(max(1, args.repeats)):
+            barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(args.steps):
+                bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i % len(pouts)].data_ptr(), stream)
+            bp.flush(stream); torch.cuda.synchronize(); regs.append(time.perf_counter() - t0)
+        bp.close(); del pouts
+        ms_p = 1e3 * float(np.median(regs)) / args.steps
+        alg16 = w.compressed_bytes + 2 * w.total_samples
+        cfg["pcm16_from_the_decode"] = {"value": round(w.total_samples / (ms_p * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_p, 4),
+                                        "bit_exact": exact16, "algorithmic_bytes": alg16, "achieved_GBps": round(alg16 / (ms_p * 1e-3) / 1e9, 1),
+                                        "frac": round(alg16 / (ms_p * 1e-3) / 1e9 / PEAK_GBS, 4),
+                                        "note": "CLX_OUT_PCM16: interleaved little-endian 16-bit PCM written by the decode kernel itself (2 bytes per sample "
+                                                "out instead of 4); secondary -- `value` is planar i32, Claxon's Block"}
     if extras and world == 1 and args.workload == "config3" and w.pcm is not None and path_tag:
         cfg["wave_kernels_pipelined"] = _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
     if extras and world == 1 and not w.bare_subframes and w.pcm is not None:

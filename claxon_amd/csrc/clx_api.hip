@@ -273,6 +273,7 @@ struct clx_batch {
     uint32_t* d_multi = nullptr;
     size_t n_multi = 0;
     bool any_bps_le16 = false, any_bps_gt16 = false;     // which of clx_k_lean / clx_k_lean24 can find work at all
+    uint64_t out_len = 0;            // samples the planar output spans (CLX_OUT_PCM16: the size of a flight's planar scratch)
     unsigned general_grid = 0;       // workgroups per run of the general lane kernels behind the tiers (clx_plan_general_grid)
     uint32_t* d_most_left = nullptr; // the longest list of groups the tiers left in any run so far (clx_k_left), and where the host
     uint32_t* h_most_left = nullptr; // finds a copy of it (pinned; read without waiting: it sizes later launches)
@@ -306,6 +307,7 @@ struct clx_batch {
         uint32_t* d_sf_start = nullptr; uint32_t* d_errkey = nullptr; uint64_t* d_endbits = nullptr;   // lane kernels' scratch
         uint32_t* d_taken = nullptr; uint32_t gen = 0;     // groups clx_k_lean took (marked with the run's generation number, never cleared)
         clx_crc_part* d_crc_part = nullptr; uint32_t* d_crc_todo = nullptr;
+        int32_t* d_planar = nullptr;             // CLX_OUT_PCM16: planar scratch for what the general kernels decode (allocated on first use, every flight its own)
         uint32_t* d_slot_frame = nullptr; uint32_t* d_first_slot = nullptr; uint32_t* d_fkey = nullptr;   // the run's slot maps (its own when waves are composed)
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
         hipEvent_t ev_rice = nullptr, ev_side = nullptr;   // Rice stage done | the submission's kernels on side_stream done
@@ -449,6 +451,7 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
         if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
         if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
+        if (F.d_planar) { (void)hipFree(F.d_planar); F.d_planar = nullptr; }
         if (i != 0 && F.d_fkey) { (void)hipFree(F.d_slot_frame); (void)hipFree(F.d_first_slot); (void)hipFree(F.d_fkey); }      // (its own maps)
     }
     if (b->ev_up) { (void)hipEventSynchronize(b->ev_up); (void)hipEventDestroy(b->ev_up); }
@@ -543,7 +546,16 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
         for (int k = 0; k < clx_batch::kMaxStreams; ++k)
             if (b->mstream[k] && !hip_ok(ctx, hipStreamSynchronize(b->mstream[k]), "hipStreamSynchronize")) return CLX_API_ERROR;
     }
+    if (flags & CLX_OUT_PCM16) {
+        // narrow output straight from the decode: <= 16-bit frames, the lane kernels' fused build with the tiers in front
+        if (flags & (CLX_PATH_WAVES | CLX_LANES_SPLIT | CLX_LANES_GENERAL)) { ctx->last_error = "CLX_OUT_PCM16 runs the fused lane kernels with the lean tier: not with CLX_PATH_WAVES / CLX_LANES_SPLIT / CLX_LANES_GENERAL"; return CLX_API_ERROR; }
+        for (size_t i = 0; i < n; ++i)
+            if (frames[i].bps > 16) { ctx->last_error = "CLX_OUT_PCM16: frame " + std::to_string(i) + " has more than 16 bits per sample"; return CLX_API_ERROR; }
+        flags |= CLX_PATH_LANES | CLX_LANES_FUSED;
+    }
     b->n = n; b->flags = flags;
+    b->out_len = 0;
+    for (size_t i = 0; i < n; ++i) b->out_len = std::max<uint64_t>(b->out_len, out_sample_offsets[i] + (uint64_t)frames[i].n_channels * frames[i].block_size);
     b->h_descs.assign(frames, frames + n);
     b->h_frames.resize(n ? n : 1);
     uint64_t slot = 0;
@@ -592,6 +604,7 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
         if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
         if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
+        if (F.d_planar) { (void)hipFree(F.d_planar); F.d_planar = nullptr; }
         if (i != 0 && F.d_fkey) { (void)hipFree(F.d_slot_frame); (void)hipFree(F.d_first_slot); (void)hipFree(F.d_fkey); }
         F.d_taken = nullptr; F.gen = 0; F.d_crc_part = nullptr; F.d_crc_todo = nullptr; F.d_slot_frame = nullptr; F.d_first_slot = nullptr; F.d_fkey = nullptr;
         if (i == 0) F.d_results = nullptr;
@@ -744,6 +757,10 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
         hipLaunchKernelGGL(clx_k_lanes_hi, dim3(ggrid, n_runs), dim3(64), 0, stream, runs,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
         if (listed && b->h_most_left) (void)hipMemcpyAsync(b->h_most_left, b->d_most_left, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (b->flags & CLX_OUT_PCM16) {          // what the general kernels decoded into the planar scratch: narrowed into the output
+            if (!mark("clx_k_narrow_left")) return false;
+            hipLaunchKernelGGL(clx_k_narrow_left, dim3(ggrid, n_runs), dim3(256), 0, stream, runs, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots);
+        }
     }
     else {
         if (n_runs != 1) return false;
@@ -763,6 +780,12 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
     }
     return true;
 }
+// CLX_OUT_PCM16: the flight's planar scratch (what the general kernels decode before clx_k_narrow_left narrows it), on first use
+int ensure_planar(clx_batch* b, clx_batch::Flight& F) {
+    if (!(b->flags & CLX_OUT_PCM16) || F.d_planar) return CLX_OK;
+    HIP_TRY(b->ctx, hipMalloc((void**)&F.d_planar, std::max<uint64_t>(b->out_len, 1) * sizeof(int32_t)));
+    return CLX_OK;
+}
 // the run that decodes (arena, arena_len) into `out` with a flight's scratch
 clx_run make_run(const clx_batch* b, const clx_batch::Flight& F, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, bool lean) {
     clx_run R;
@@ -771,12 +794,13 @@ clx_run make_run(const clx_batch* b, const clx_batch::Flight& F, const uint8_t* 
     R.taken = (lean && !(b->flags & CLX_LANES_GENERAL)) ? F.d_taken : nullptr;
     R.results = F.d_results; R.gen = F.gen;
     R.crc_part = F.d_crc_part; R.crc_todo = F.d_crc_todo;
+    R.planar = F.d_planar;
     // the run's slot maps: its own when its waves are composed by content (clx_k_compose rewrites the windows' parts), else the plan's
     const bool composed = lean && b->n_windows != 0 && F.d_fkey != nullptr;
     R.slot_frame = composed ? F.d_slot_frame : b->d_slot_frame;
     R.first_slot = composed ? F.d_first_slot : b->d_first_slot;
     R.fkey = composed ? F.d_fkey : nullptr;
-    R.flags = (b->flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u;
+    R.flags = ((b->flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((b->flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u);
     return R;
 }
 void launch_stage1_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
@@ -998,6 +1022,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         F0.d_results = b->d_results; F0.d_sf_start = b->d_sf_start; F0.d_errkey = b->d_errkey; F0.d_endbits = b->d_endbits; F0.d_taken = b->d_taken;
         F0.d_crc_part = b->d_crc_part; F0.d_crc_todo = b->d_crc_todo;
         F0.d_slot_frame = b->d_slot_frame_run; F0.d_first_slot = b->d_first_slot_run; F0.d_fkey = b->d_fkey;
+        if (ensure_planar(b, F0) != CLX_OK) return CLX_API_ERROR;
         if (++F0.gen == 0u) {
             HIP_TRY(ctx, hipMemsetAsync(b->d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), stream));
             HIP_TRY(ctx, hipMemsetAsync(b->d_crc_part, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_crc_part), stream));
@@ -1130,6 +1155,7 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
                 F.d_sf_start = sfs;                      // (last: the sentinel)
             }
         }
+        if (ensure_planar(b, F) != CLX_OK) return CLX_API_ERROR;
         // what cannot share a launch with the pending submissions goes after them: another caller stream (the launch waits for
         // ONE stream's inputs), an output buffer one of them writes, a plan that has to be uploaded again (the arena's length)
         bool apart = !b->pend.empty() && b->pend_stream != stream;

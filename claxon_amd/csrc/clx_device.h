@@ -65,10 +65,12 @@ struct clx_run {
     uint32_t* fkey;          // scratch, per frame: the content class clx_k_scan found (clx_k_compose's sort key); null: no composition
     clx_crc_part* crc_part;  // scratch, per predictor slot: what the lean kernels' lanes found of their frame's CRC-16 (clx_crct.h)
     uint32_t* crc_todo;      // scratch, per frame: clx_k_finalize -> clx_k_crc16_runs: 1 = the stand-alone kernel has to check this frame
+    int32_t* planar;         // CLX_RUN_PCM16 only: planar i32 scratch (laid out as `out` is without the flag) for what the general kernels decode
     uint32_t gen;
     uint32_t flags;          // CLX_RUN_CRC: the frames' CRC-16 is verified (the decode lanes gather it, clx_k_finalize judges it)
 };
 #define CLX_RUN_CRC 1u
+#define CLX_RUN_PCM16 2u     // `out` holds interleaved 16-bit PCM (claxon_hip.h: CLX_OUT_PCM16)
 struct clx_runs { clx_run r[CLX_MAX_MERGE]; };       // passed to the kernels by value
 
 // clx_k_compose: a window of consecutive stereo frames of one block size whose lanes are dealt by content class (clx_plan.h)
@@ -81,7 +83,7 @@ struct clx_window { uint32_t f_lo, f_hi, s_lo, pad; };   // frames [f_lo, f_hi),
 #define CLX_FKEY(special, order_class, assignment) (((special) ? 16u : 0u) | ((uint32_t)(order_class) << 2) | ((uint32_t)(assignment) & 3u))
 
 #ifdef __cplusplus
-static_assert(sizeof(clx_run) == 112, "clx_run layout");
+static_assert(sizeof(clx_run) == 120, "clx_run layout");
 static_assert(sizeof(clx_dev_frame) == 32, "clx_dev_frame layout");
 static_assert(sizeof(clx_sf_desc) == 80, "clx_sf_desc layout");
 // K1 writes the 16 bytes in front of `coef` as one store: {out_base | n, lim_log2, flags | order, shift, wasted, decor}

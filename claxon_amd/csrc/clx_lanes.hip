@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void clx_lanes_group(LanesLds& L, const clx_run& R, c
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
     const uint32_t* const sf_start = R.sf_start;
-    int32_t* const out = R.out;
+    int32_t* const out = (R.flags & CLX_RUN_PCM16) ? R.planar : R.out;       // (narrow output: planar scratch here, clx_k_narrow_left behind)
     uint32_t* const errkey = R.errkey;
     uint64_t* const end_bits = R.end_bits;
     CLX_TL_BEGIN();
@@ -1165,6 +1165,28 @@ void clx_k_left(const clx_runs runs, uint32_t n_groups, uint32_t* __restrict__ m
         const uint32_t i = atomicAdd(&left[0], 1u);
         left[1u + i] = g;
         if (most_left != nullptr) atomicMax(most_left, i + 1u);
+    }
+}
+// Narrow output (CLX_OUT_PCM16): the frames of the groups the tiers left were decoded into the run's planar scratch; one workgroup per
+// listed group narrows them into the run's interleaved 16-bit output (the low 16 bits of every sample, as clx_k_interleave does).
+extern "C" __global__ __launch_bounds__(256)
+void clx_k_narrow_left(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots) {
+    const clx_run& R = runs.r[blockIdx.y];
+    if (!(R.flags & CLX_RUN_PCM16) || R.taken == nullptr) return;
+    const uint32_t* const left = R.taken + (n_slots + 63u) / 64u;
+    const uint32_t n_left = left[0];
+    int16_t* const dst = reinterpret_cast<int16_t*>(R.out);
+    for (uint32_t i = blockIdx.x; i < n_left; i += gridDim.x) {
+        const uint32_t grp = left[1u + i];
+        for (uint32_t s = 64u * grp; s < 64u * grp + 64u && s < n_slots; ++s) {
+            const uint32_t f = R.slot_frame[s];
+            if (f == 0xffffffffu || R.first_slot[f] != s) continue;          // (a frame is narrowed where its first subframe's lane sits)
+            const clx_dev_frame fr = frames[f];
+            const uint32_t C = fr.n_channels, bs = fr.block_size;
+            const int32_t* __restrict__ src = R.planar + fr.out_off;
+            int16_t* __restrict__ d = dst + fr.out_off;
+            for (uint32_t k = threadIdx.x; k < C * bs; k += 256u) d[k] = (int16_t)src[(k % C) * bs + k / C];
+        }
     }
 }
 extern "C" __global__ __launch_bounds__(64)

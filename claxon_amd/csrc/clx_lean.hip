@@ -609,10 +609,33 @@ struct LMover {
     uint64_t base;             // wave-uniform
     uint32_t rowoff;           // this lane's row (bytes from `base`), or CLN_NO_ROW
     bool all_real;             // wave-uniform: every row of the wave exists
+    bool pcm16;                // wave-uniform: interleaved 16-bit output (CLX_RUN_PCM16): rowoff is the FRAME's place, the same in both lanes of its pair
 };
 #define CLN_NO_ROW 0xffffffffu
+// Narrow output (CLX_OUT_PCM16, round 5): the wave's rows are the two channels of 32 stereo frames (lanes 2F, 2F + 1), and a pair of tiles
+// holds 32 samples of each -- one 128-byte line of interleaved 16-bit PCM per frame.  Eight adjacent lanes write one frame's line
+// (lane q: sample pairs 4q .. 4q + 3, i.e. piece q & 3 of tile q >> 2 of BOTH rows, packed low halves left | right), a store
+// instruction covers eight frames, FOUR instructions the pair of tiles (planar i32: eight).  n_tiles: 2, or 1 for a lone last tile.
+__device__ __forceinline__ void cln_store_pcm16(const int4* stage0, const LMover& M, uint32_t t0, int lane, uint32_t n_tiles) {
+    clx_wave_sync();
+    const uint32_t q = (uint32_t)lane & 7u, t = q >> 2, p = q & 3u;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {
+        const uint32_t F = 8u * i + ((uint32_t)lane >> 3);                    // the frame (row pair) whose line this lane helps to write
+        const uint32_t r0 = 2u * F, r1 = 2u * F + 1u;
+        const int4 a = stage0[t * 256u + ((r0 ^ t) * 4u) + (p ^ ((r0 >> 1) & 3u))];
+        const int4 b = stage0[t * 256u + ((r1 ^ t) * 4u) + (p ^ ((r1 >> 1) & 3u))];
+        const uint32_t o = (uint32_t)__shfl((int)M.rowoff, (int)r0, 64);
+        int4 w;                                                              // (left: low half, right: high half of each dword)
+        w.x = (int32_t)clx_perm((uint32_t)b.x, (uint32_t)a.x, 0x05040100u); w.y = (int32_t)clx_perm((uint32_t)b.y, (uint32_t)a.y, 0x05040100u);
+        w.z = (int32_t)clx_perm((uint32_t)b.z, (uint32_t)a.z, 0x05040100u); w.w = (int32_t)clx_perm((uint32_t)b.w, (uint32_t)a.w, 0x05040100u);
+        if (o != CLN_NO_ROW && t < n_tiles) clx_store1x16_s(M.base, o + 4u * t0 + 16u * q, w);      // (a frame's sample t0 sits 4 t0 bytes into its block)
+    }
+    clx_wave_sync();
+}
 // the pair of tiles that starts at sample index t0 (a multiple of 32)
 __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
+    if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 2u); return; }
     clx_wave_sync();
     const uint32_t h = (uint32_t)lane >> 3, q = (uint32_t)lane & 7u, t = q >> 2;
     const int4* const src = stage0 + t * 256u + ((h ^ t) * 4u) + ((q & 3u) ^ ((h >> 1) & 3u));      // + 32 int4 per instruction (8 rows)
@@ -637,6 +660,7 @@ __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover&
 }
 // a lone tile 0 (the block's last 16 samples when the block size is an odd multiple of 16): 64 bytes x 16 rows per instruction
 __device__ __forceinline__ void cln_store_single(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
+    if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 1u); return; }
     clx_wave_sync();
     const uint32_t h = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
 #pragma unroll
@@ -1183,7 +1207,10 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     const uint32_t pos0 = r.pos;                           // where the lane's subframe starts
     // ---- does this wave qualify?  Every live lane: <= 16-bit audio, a FIXED / LPC subframe of at most 12 taps whose header
     //      parses, the wave's common block size (a multiple of 16, beyond the prologue), a 16-byte aligned row.
-    int32_t* const rowp = out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
+    // (narrow output: `out` holds interleaved 16-bit PCM, a lane's "row" is its FRAME's block there -- both lanes of a pair point to it)
+    const bool pcm16 = (R.flags & CLX_RUN_PCM16) != 0u;         // wave-uniform
+    int32_t* const rowp = pcm16 ? reinterpret_cast<int32_t*>(reinterpret_cast<int16_t*>(out) + (active ? fr.out_off : 0ull))
+                                : out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
     // (where the wave's rows are: the lowest one's address, wave-uniform, and every lane's distance from it -- LMover)
     uint64_t row_lo = active ? (uint64_t)(uintptr_t)rowp : ~0ull;
 #pragma unroll
@@ -1202,6 +1229,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     }
     if (active) {
         good = fr.bps <= (SPLIT ? 24u : 16u) && bs == bs0 && (bs & 15u) == 0u && bs >= (SPLIT ? 64u : 32u) && (((uintptr_t)rowp) & 15u) == 0u && row_far < 0xffffffffull &&
+               (!pcm16 || (!SPLIT && fr.n_channels == 2u && ch == (slot & 1u))) &&       // (narrow output: stereo frames, channel c in lane parity c)
                r.pos <= r.limit && (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
         if (good) {
             h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
@@ -1265,6 +1293,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     M.base = ((uint64_t)clx_uniform((uint32_t)(row_lo >> 32)) << 32) | clx_uniform((uint32_t)row_lo);
     M.rowoff = active ? (uint32_t)((uint64_t)(uintptr_t)rowp - row_lo) : CLN_NO_ROW;
     M.all_real = __all(active);
+    M.pcm16 = pcm16;
     (void)dump_all;                                         // (rows that do not exist are not written: no dump slots here)
     const Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
 

@@ -210,7 +210,17 @@ enum {
      * Default: on for windows whose descriptors differ in their channel assignment (streams as encoders write them), off where
      * every descriptor is the same (synthetic batches of one shape).  These flags force it on / off. */
     CLX_COMPOSE         = 1u << 11,
-    CLX_NO_COMPOSE      = 1u << 12
+    CLX_NO_COMPOSE      = 1u << 12,
+    /* Narrow output straight from the decode (planned batches: clx_batch_create + clx_batch_run / clx_batch_submit; round 5).  The
+     * batch's `d_out` buffers then hold channel-interleaved little-endian 16-bit PCM -- what lib.rs:473-520 (FlacSamples) walks and
+     * examples/decode.rs:48-62 writes to a .wav -- instead of planar i32: `d_out` points to int16_t, indexed by the SAME sample
+     * offsets (frame i's block starts at int16 index out_sample_offsets[i]; sample t of channel c at + t * n_channels + c), each
+     * sample's low 16 bits as clx_batch_interleave(.., 2) gives them.  Every frame must have at most 16 bits per sample.  The
+     * lean decode kernel writes a stereo frame's 32 samples as one 128-byte line from the tiles it stages anyway (half the bytes
+     * through the write path); whatever it leaves to the general kernels goes through a planar scratch per run in flight (as
+     * large as the planar output: allocated on first use) and a narrowing pass over those frames only.  Failed frames' bytes are
+     * unspecified, as the planar output's are.  Always the lane kernels, fused build. */
+    CLX_OUT_PCM16       = 1u << 13
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32

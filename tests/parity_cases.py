@@ -643,3 +643,52 @@ def crc_share_workload(seed=9090):
             fps.append(fp)
         ws.append(S.encode_frames("crc shares %d ch bs %d %d bit" % (channels, bs, bps), pcm, channels, bs, bps, fps))
     return synth.concat("crc shares", ws)
+
+
+def pcm16_workload():
+    """What the narrow output (CLX_OUT_PCM16) has to get right: stereo frames the lean kernel writes as whole interleaved lines, of every
+    channel assignment, with constant / verbatim subframes riding along, block sizes that are odd multiples of 16 (a lone last tile) and
+    16 mod 32; waves that give their group up (the general kernels decode into the planar scratch, clx_k_narrow_left narrows it); mono
+    and three-channel frames and blocks that are no multiple of 16 (never the lean kernel's: the same way round)."""
+    S = synth
+    rng = np.random.default_rng(606)
+    parts = [lean_workload(), giveup_workload(128), S.config5_unique(96)]
+    for ch, bs, n in ((1, 4096, 70), (3, 1152, 24), (2, 1000, 40), (2, 4096 + 16, 64), (2, 48, 64)):
+        t = np.arange(bs)
+        pcm = np.empty((n, ch, bs), dtype=np.int32)
+        for i in range(n):
+            for c in range(ch):
+                pcm[i, c] = np.clip(np.round(3000.0 * np.sin(2 * np.pi * (60 + 13 * i + 7 * c) * t / 44100.0 + 0.3 * c) + rng.normal(0, 5.0, bs)), -32768, 32767)
+        fp = [S.FrameParams() for _ in range(n)]
+        for i, f in enumerate(fp):
+            f.channel_assignment = (i % 4) if ch == 2 else 0
+            for c in range(ch):
+                f.sf[c] = S.sf(S.SF_LPC if (i + c) % 3 else S.SF_FIXED, order=8 if (i + c) % 3 else 2, precision=12, partition_order=min(3, max(0, int(np.log2(bs)) - 5)))
+        parts.append(S.encode_frames("pcm16 %dch bs%d" % (ch, bs), pcm, ch, bs, 16, fp))
+    return S.concat("pcm16", parts)
+
+
+def check_pcm16(oracle, backend, w, damage=0.0, seed=1):
+    """The narrow output against the oracle: every OK frame's bytes are the interleaved low 16 bits of the oracle's samples; statuses,
+    messages and end bits as in planar mode.  `backend.path` must carry cx.OUT_PCM16."""
+    rng = np.random.default_rng(seed)
+    arena = w.arena.copy()
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
+    for i in range(w.n):
+        if rng.uniform() < damage:
+            lo, hi = int(w.offs[i]) + int(descs["header_bytes"][i]), int(w.offs[i] + w.lens[i])
+            pos = int(rng.integers(8 * lo, 8 * hi))
+            arena[pos >> 3] ^= (0x80 >> (pos & 7))
+    out, res = backend.decode(arena, w.arena_len, descs, w.out_offs, True, fill=0x1111)
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, check_crc=True)
+    st, ms = np.asarray(res["status"]), np.asarray(res["msg"])
+    assert np.array_equal(st, r["statuses"]) and np.array_equal(ms, r["msgs"])
+    ok = np.nonzero(st == cx.OK)[0]
+    assert np.array_equal(np.asarray(res["end_bit"])[ok], r["end_bits"][ok])
+    out = np.asarray(out).view(np.int16) if np.asarray(out).dtype != np.int16 else np.asarray(out)
+    for i in ok:
+        a, c, bs = int(w.out_offs[i]), int(w.channels[i]), int(w.block_sizes[i])
+        want = ref[a:a + c * bs].reshape(c, bs).T.reshape(-1).astype(np.int16)
+        assert np.array_equal(out[a:a + c * bs], want), "frame %d (%d ch, bs %d)" % (int(i), c, bs)
+    return int(ok.size)

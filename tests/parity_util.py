@@ -42,7 +42,10 @@ class GpuBackend:
         total = int((out_offs + descs["n_channels"].astype(np.uint64) *
                      descs["block_size"].astype(np.uint64)).max()) if n else 0
         d_arena = torch.from_numpy(np.ascontiguousarray(arena)).to("cuda:0")
-        d_out = torch.full((max(total, 1),), int(np.int32(fill)), dtype=torch.int32, device="cuda:0")
+        if self.path & cx.OUT_PCM16:     # (narrow output: the buffer holds interleaved 16-bit PCM at the same sample offsets)
+            d_out = torch.full((max(total, 1) + 8,), int(fill) & 0x7fff, dtype=torch.int16, device="cuda:0")
+        else:
+            d_out = torch.full((max(total, 1),), int(np.int32(fill)), dtype=torch.int32, device="cuda:0")
         batch = self.ctx.plan(descs, out_offs, verify_crc=verify_crc, path=self.path)
         torch.cuda.synchronize()
         batch.run(d_arena.data_ptr(), int(arena_len), d_out.data_ptr())

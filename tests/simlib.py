@@ -59,7 +59,8 @@ def interleave(planar, descs, out_offs, sample_bytes, results=None, pcm=None):
 
 
 def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_only=False, fill=0, path=0):
-    """Run K1 (+K2, +K3) under simulation.  `arena` must be 16-byte padded beyond arena_len."""
+    """Run K1 (+K2, +K3) under simulation.  `arena` must be 16-byte padded beyond arena_len.  With cx.OUT_PCM16 in `path` the output
+    is interleaved 16-bit PCM: `out` is then (or is made) an int16 array indexed by the same sample offsets."""
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
     # the simulator reads the arena exactly like the GPU: 16-byte aligned base, padded allocation
     buf = np.zeros(arena.size + 64, dtype=np.uint8)
@@ -71,7 +72,7 @@ def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_onl
     n = descs.size
     total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
     if out is None:
-        out = np.full(total, fill, dtype=np.int32)
+        out = np.full(total + 8, fill & 0x7fff, dtype=np.int16)[:total] if (path & cx.OUT_PCM16) else np.full(total, fill, dtype=np.int32)
     res = np.zeros(n, dtype=cx.FRAME_RESULT_DTYPE)
     nslots = C.c_uint64(0)
     sfd = np.zeros(int(descs["n_channels"].sum()) + n + 2, dtype=SF_DESC_DTYPE)

@@ -165,3 +165,47 @@ def test_bench_line_with_the_collectives_through_rccl_on_one_rank():
     pg = j["config"]["process_group"]
     assert pg["backend"].startswith("nccl") and pg["world_size"] == 1 and pg["barrier_us"] is not None and pg["barrier_us"] >= 0
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["bit_exact"] is True
+
+
+@pytest.mark.gpu
+def test_narrow_output_parity_on_the_gpu(oracle):
+    """parity_cases.pcm16_workload through CLX_OUT_PCM16 on the GPU (one run at a time: the general kernels keep their full grid), in
+    stream order, composed, and with a fifth of the frames damaged: every OK frame's bytes against the oracle."""
+    from parity_util import GpuBackend
+    ctx = cx.Context(0, wait_s=120)
+    w = pc.pcm16_workload()
+    for extra in (cx.NO_COMPOSE, cx.COMPOSE):
+        assert pc.check_pcm16(oracle, GpuBackend(ctx, cx.OUT_PCM16 | extra), w) == w.n
+    assert pc.check_pcm16(oracle, GpuBackend(ctx, cx.OUT_PCM16), w, damage=0.2, seed=3) < w.n
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_narrow_output_pipelined_at_scale(oracle):
+    """4 096 config-3 frames + the give-up workload through pipelined submissions with CLX_OUT_PCM16 (merged launches; the groups that
+    are given up go through the planar scratch of their flight and clx_k_narrow_left with the SMALL grid): every output buffer
+    holds the interleaved low 16 bits of the source PCM."""
+    import torch
+    ctx = cx.Context(0, wait_s=120)
+    w = synth.concat("pcm16 at scale", [synth.config3(4096), pc.giveup_workload(1024)])
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.OUT_PCM16)
+    assert batch.submit_lanes
+    depth = min(batch.submit_depth, 6)
+    outs = [torch.full((w.pcm.size + 8,), 0x1111, dtype=torch.int16, device="cuda:0") for _ in range(depth)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(batch.submit_depth + 5):
+        batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    assert np.all(res["status"] == cx.OK)
+    want = np.zeros(w.pcm.size, dtype=np.int16)
+    for i in range(w.n):
+        a, c, bs = int(w.out_offs[i]), int(w.channels[i]), int(w.block_sizes[i])
+        want[a:a + c * bs] = w.pcm[a:a + c * bs].reshape(c, bs).T.reshape(-1).astype(np.int16)
+    d_want = torch.from_numpy(want).to("cuda:0")
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o[:w.pcm.size], d_want)), "output buffer %d" % k
+    batch.close(); ctx.close()

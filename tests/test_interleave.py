@@ -106,3 +106,37 @@ def test_gpu_decode_then_interleave_md5(oracle):
     assert np.all(batch.results()["status"] == cx.OK)
     assert np.array_equal(d_pcm.cpu().numpy(), ref_interleave(w.pcm, descs, w.out_offs, 2))
     batch.close()
+
+
+@pytest.mark.gpu
+def test_gpu_narrow_output_from_the_decode_md5(oracle):
+    """CLX_OUT_PCM16 (round 5): the decode itself writes interleaved 16-bit PCM -- no planar i32, no narrowing pass -- and the bytes
+    hash to the MD5 the 16-bit fixtures' STREAMINFO claims (pop.flac: stereo; short.flac: a block of four samples the lean kernel
+    never takes; wasted_bits.flac: mono -- both through the planar scratch and clx_k_narrow_left)."""
+    import torch
+    ctx = cx.Context(0, wait_s=120)
+    md5s = {"pop.flac": "68464288fa5e19835516972dcf47223c", "short.flac": "927598b89c89c1129a152eecfc14075e",
+            "wasted_bits.flac": "4fbca4cf30f188453c0676e0cd700c71"}
+    for name, md5 in md5s.items():
+        data = np.frombuffer(open(os.path.join(FIXTURES, name), "rb").read(), dtype=np.uint8)
+        st, _, si, audio_off = cx.read_stream_header(data)
+        assert st == cx.OK and si.bits_per_sample == 16, name
+        descs, hdrs, stop = cx.index_frames(data, audio_off)
+        sizes = descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+        total = int(sizes.sum())
+        arena = np.zeros(data.size + 64, dtype=np.uint8); arena[:data.size] = data
+        d_arena = torch.from_numpy(arena).cuda()
+        d_pcm = torch.zeros(total + 8, dtype=torch.int16, device="cuda")
+        batch = ctx.plan(descs, offs, verify_crc=True, path=cx.OUT_PCM16)
+        batch.run(d_arena.data_ptr(), data.size, d_pcm.data_ptr())
+        assert np.all(batch.results()["status"] == cx.OK), name
+        assert hashlib.md5(d_pcm[:total].cpu().numpy().tobytes()).hexdigest() == md5, name
+        batch.close()
+    # a batch with a 24-bit frame is refused, and so is the combination with the wave kernels
+    w = synth.config4(4)
+    with pytest.raises(cx.ClaxonError):
+        ctx.plan(workload_descs(w), w.out_offs, path=cx.OUT_PCM16)
+    w = synth.config3(8)
+    with pytest.raises(cx.ClaxonError):
+        ctx.plan(workload_descs(w), w.out_offs, path=cx.OUT_PCM16 | cx.PATH_WAVES)

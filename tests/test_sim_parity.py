@@ -372,3 +372,22 @@ def test_sim_consecutive_runs_on_one_scratch(oracle, compose, first_gen):
             assert np.array_equal(out[lo:hi], ref[lo:hi]), int(i)
         n_bad.append(int(np.sum(res["status"] != cx.OK)))
     assert n_bad[0] == 0 and n_bad[3] == 0 and min(n_bad[1], n_bad[2], n_bad[4]) >= 10, n_bad
+
+
+def test_sim_narrow_output_from_the_decode(oracle):
+    """CLX_OUT_PCM16 (round 5): the lean kernel writes a stereo frame's 32 samples as one 128-byte line of interleaved 16-bit PCM from the
+    tiles it stages anyway; what it leaves to the general kernels goes through the planar scratch and clx_k_narrow_left.  Every frame's
+    bytes against the oracle, in stream order and with the waves composed by content, intact and with a fifth of the frames damaged."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    w = pc.pcm16_workload()
+    for extra in (cx.NO_COMPOSE, cx.COMPOSE):
+        for i in range(64):
+            stats[i] = 0
+        n_ok = pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16 | extra), w)
+        assert n_ok == w.n
+        assert stats[52] >= 8 and stats[49] >= 4, (int(stats[52]), int(stats[49]))      # groups the lean kernel wrote itself | groups left to the general kernels
+    n_ok = pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w, damage=0.2, seed=3)
+    assert n_ok < w.n

@@ -24,6 +24,7 @@ struct SimLanes {
     std::vector<uint64_t> endbits;
     std::vector<clx_crc_part> crc_part;
     std::vector<clx_window> windows;
+    std::vector<int32_t> planar;       // CLX_OUT_PCM16: the run's planar scratch (what the general kernels decode; clx_k_narrow_left narrows it)
     bool lean = false;
     bool plan(const clx_frame_desc* frames, size_t n_, const uint64_t* out_offs, size_t arena_len, uint32_t flags_) {
         n = n_; flags = flags_;
@@ -43,6 +44,12 @@ struct SimLanes {
         const int cmode = (!lean || (flags & CLX_NO_COMPOSE)) ? -1 : (flags & CLX_COMPOSE) ? 1 : 0;
         n_windows = clx_plan_windows(dev.data(), n, cmode, windows.data());
         slot_frame_plan = slot_frame; first_slot_plan = first_slot;      // (what must stay untouched)
+        if (flags & CLX_OUT_PCM16) {
+            if (!lean) return false;
+            uint64_t out_len = 0;
+            for (size_t i = 0; i < n; ++i) out_len = std::max<uint64_t>(out_len, out_offs[i] + (uint64_t)frames[i].n_channels * frames[i].block_size);
+            planar.assign(out_len + 16, 0x2b2b2b2b);
+        }
         return true;
     }
     // one run, as launch_pending / launch_lanes make it (clx_api.hip): a new generation number, the wrap handled as the library does
@@ -59,7 +66,8 @@ struct SimLanes {
         runs.r[0].errkey = errkey.data(); runs.r[0].end_bits = endbits.data(); runs.r[0].taken = lean ? taken.data() : nullptr;
         runs.r[0].results = results; runs.r[0].gen = gen;
         runs.r[0].crc_part = crc_part.data(); runs.r[0].crc_todo = crc_todo.data();
-        runs.r[0].flags = (flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u;
+        runs.r[0].flags = ((flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u);
+        runs.r[0].planar = (flags & CLX_OUT_PCM16) ? planar.data() : nullptr;
         // the run's slot maps: the plan's, or its own when waves are composed by content (as the library does: clx_plan_windows)
         runs.r[0].slot_frame = slot_frame.data(); runs.r[0].first_slot = first_slot.data(); runs.r[0].fkey = n_windows ? fkey.data() : nullptr;
         if (n_multi) {
@@ -110,6 +118,7 @@ struct SimLanes {
             }
             SIM_LAUNCH(clx_k_lanes, ggrid, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
             SIM_LAUNCH(clx_k_lanes_hi, ggrid, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
+            if (flags & CLX_OUT_PCM16) SIM_LAUNCH(clx_k_narrow_left, ggrid, 256, runs, dev.data(), (uint32_t)n_slots);
         } else {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,

@@ -41,6 +41,7 @@ pipe)
       case $name in
         c3)  args="--steps 48 --warmup 6" ;;
         c3d) args="--steps 20 --warmup 5" ;;
+        c3l) args="--steps 96 --warmup 8" ;;
         c2)  args="--workload config2 --steps 48" ;;
         c5)  args="--workload config5 --total-frames 80000 --unique 4096 --shard-of 8 --shard-rank 3 --steps 48" ;;
         c4)  args="--workload config4 --steps 48" ;;
