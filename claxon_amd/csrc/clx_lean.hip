@@ -618,10 +618,14 @@ struct LMover {
 // instruction covers eight frames, FOUR instructions the pair of tiles (planar i32: eight).  n_tiles: 2, or 1 for a lone last tile.
 __device__ __forceinline__ void cln_store_pcm16(const int4* stage0, const LMover& M, uint32_t t0, int lane, uint32_t n_tiles) {
     clx_wave_sync();
-    const uint32_t q = (uint32_t)lane & 7u, t = q >> 2, p = q & 3u;
+    // (the lane's places in the stage are worked out HERE, every time: left to itself the compiler keeps eight addresses per lane alive
+    //  across the whole decode loop for this secondary mode -- and spills them, 168 registers being what they are)
+    uint32_t ln = (uint32_t)lane;
+    CLX_OPAQUE(ln);
+    const uint32_t q = ln & 7u, t = q >> 2, p = q & 3u;
 #pragma unroll
     for (uint32_t i = 0; i < 4u; ++i) {
-        const uint32_t F = 8u * i + ((uint32_t)lane >> 3);                    // the frame (row pair) whose line this lane helps to write
+        const uint32_t F = 8u * i + (ln >> 3);                                // the frame (row pair) whose line this lane helps to write
         const uint32_t r0 = 2u * F, r1 = 2u * F + 1u;
         const int4 a = stage0[t * 256u + ((r0 ^ t) * 4u) + (p ^ ((r0 >> 1) & 3u))];
         const int4 b = stage0[t * 256u + ((r1 ^ t) * 4u) + (p ^ ((r1 >> 1) & 3u))];
@@ -694,7 +698,31 @@ __device__ __forceinline__ int32_t cln_coef(const uint32_t (&C)[NP], int j) {
     return (j & 1) ? (int32_t)(int16_t)(C[j >> 1] & 0xffffu) : ((int32_t)C[j >> 1] >> 16);
 }
 
-// stereo decorrelation of the turn's sixteen samples (clx_lfinish, clx_lanes.hip) into the stage
+// stereo decorrelation of four of the turn's samples (the four `b` of the turn: clx_lfinish, clx_lanes.hip) into the stage.  Four at a
+// time, right behind the four's predictor steps: the outputs do not stay in registers until the end of the turn (round 5: twelve
+// registers less across the turn -- clx_k_lean24 and clx_k_lean sit at the edge of their register files).  (The stage is written
+// before the turn's vote: a turn that is taken again writes the same places again.)
+__device__ __forceinline__ void cln_finish4(const int32_t (&s0)[4], const Finish& F, int4* mine, uint32_t sw, uint32_t b) {
+    int32_t m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = s0[i];
+    if (F.any_wasted) {                                  // wasted-bits shift (subframe.rs:216-225): a wave with such a lane only
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = (int32_t)((uint32_t)m[i] << F.wasted);
+    }
+    int32_t y[4];
+    if (F.all_ms) clx_ms_short4(m, y, F.sgn, 1u + (F.sgn & 1u));                       // (exact below 2^29: part of the turn's range check)
+    else if (F.any_decor) clx_decor4(m, y, F.dsg, F.drm, F.dc, F.s1, F.pmask);        // (exact below 2^29: part of the turn's range check)
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = m[i];
+    }
+    mine[b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
+}
+
+// the same for the turn's sixteen samples at once, at the END of the turn (the 16-bit tier: its turn stays one basic block, the
+// wave-uniform choice of the stereo form is made once, and the asm statements of the stereo forms stay out of the compiler's way
+// while it schedules the Rice and predictor work)
 __device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Finish& F, int4* mine, uint32_t sw) {
     int32_t s[16];
 #pragma unroll
@@ -770,7 +798,7 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
     int32_t msh = 0;                                  // the smallest "bits left of the window after the code" -- negative: a code > 32 bits
     int32_t hi = -0x7fffffff - 1, lo = 0x7fffffff;
     uint32_t pw = c.p;
-    int32_t S16[16];
+    int32_t S16[SPLIT ? 1 : 16];
     const uint32_t pb = 4u + rice2, esc = rice2 ? 31u : 15u;
     // The four's Rice codes are decoded first (that fixes where the next four starts), the next four's window is requested from the
     // ring, and only then does the predictor run over the four samples: the LDS round trip hides behind it.
@@ -834,6 +862,7 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
         c.p += MODE == 0 ? 128u - shsum : ((128u - shsum) & K.bitmask);
         if (b < 3) { edge(); window(); }
         CLN_SCHED_FENCE();
+        int32_t S4[4];
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = 4 * b + ii;
@@ -869,12 +898,14 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             else if (!WIDE) P[NH + i] = clx_perm((uint32_t)s, P[NH + i - 1], 0x05040302u);          // (lo: the sample before, hi: this one)
             else hw[2 * NP + i] = s;
             hi = s > hi ? s : hi; lo = s < lo ? s : lo;
-            S16[i] = s;
+            S4[ii] = s;
+            if (!SPLIT) S16[SPLIT ? 0 : i] = s;
         }
         CLX_OPAQUE(hi); CLX_OPAQUE(lo);
+        // stereo decorrelation and the stage: the split tier four by four (its register file is full), the others at the end
+        if (SPLIT) cln_finish4(S4, F, mine, sw, (uint32_t)b);
     }
-    // stereo decorrelation and the stage: the wave-uniform choice of the form once per turn
-    cln_finish16(S16, F, mine, sw);
+    if constexpr (!SPLIT) cln_finish16(S16, F, mine, sw);
     // what was decoded is what the stream holds iff no code was longer than its window register, the last window lay inside the
     // ring's filled part and nothing reached past the end of the frame; the predictor was exact iff the outputs (the next turn's
     // history) stayed inside the range
