@@ -26,3 +26,13 @@ timeout 300 python bench.py --no-cpu-baseline --no-extras --workload config4 --s
 timeout 300 python bench.py --no-cpu-baseline --no-extras --workload config5 --total-frames 80000 --unique 4096 --shard-of 8 --shard-rank 3 --steps 48 > $O/c5_10k.json 2> $O/c5_10k.err; line $O/c5_10k.json "config5 10k"
 timeout 600 python bench.py --no-cpu-baseline --no-extras --workload config5 --shard-of 8 --shard-rank 3 --steps 24 > $O/c5_share.json 2> $O/c5_share.err; line $O/c5_share.json "config5 125003-frame share"
 timeout 600 python bench.py --gpus 2 --devices 0,0 --backend gloo --steps 20 --warmup 5 --no-extras > $O/bench_2ranks_1gpu.json 2> $O/bench_2ranks_1gpu.err; echo "2-rank rc=$?"; line $O/bench_2ranks_1gpu.json "2 ranks on one GPU (gloo)"
+# the N-rank line's collectives on the hardware that exists: ONE rank, process group through RCCL (init_process_group("nccl", device_id=...), barrier,
+# MAX / SUM all-reduces and the all-gather on device tensors)
+MASTER_ADDR=127.0.0.1 timeout 600 python bench.py --gpus 1 --process-group --backend nccl --steps 20 --warmup 5 --no-extras > $O/bench_rccl_one_rank.json 2> $O/bench_rccl_one_rank.err; echo "rccl one rank rc=$?"; line $O/bench_rccl_one_rank.json "1 rank, RCCL process group"
+python - $O/bench_rccl_one_rank.json <<'PY'
+import json,sys
+try:
+    j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print("   process_group:", j["config"]["process_group"])
+except Exception as e: print("ERR", e)
+PY
+
