@@ -38,6 +38,28 @@ import numpy as np  # noqa: E402
 PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+_REAL_STDOUT = None
+
+
+def _own_stdout():
+    """The contract is ONE JSON line on rank 0's stdout.  Libraries under this process write there too -- RCCL prints a version banner
+    of five lines when its first communicator comes up (seen with `--process-group --backend nccl`: profiles/r05_rccl_one_rank.log) -- so
+    file descriptor 1 is pointed at stderr for the life of the process and the line goes out through a private copy of the real one."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +97,7 @@ def main():
     # this process is one of its ranks already
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.shard_of:
         sys.exit(_spawn_ranks(args.gpus))
+    _own_stdout()
     if args.launcher_selftest:
         return _launcher_selftest(args)
 
@@ -364,7 +387,14 @@ def main():
             ms_c = 1e3 * el_c / args.steps
             cfg["without_crc16"] = {"value": round(samples_c / (ms_c * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
                                     "note": "the same steps with the CRC-16 footer check left out (BENCH_r01 / r02's `value`); `value` verifies"}
+    if extras and world == 1 and args.workload == "config3" and w.pcm is not None and path_tag:
+        cfg["wave_kernels_pipelined"] = _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
+    if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
+        cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
     if extras and world == 1 and pipelined and not w.bare_subframes and w.pcm is not None and int(np.max(w.bps)) <= 16:
+        # (BEHIND the host-buffer figures: the internal streams this batch creates and destroys change which hardware queues the host
+        #  pipeline's three streams get afterwards -- measured behind this block its upload-only figure read 1.61 ms, in front 1.40,
+        #  same library: tools/stream_probe.py)
         # ---- narrow output straight from the decode (CLX_OUT_PCM16: interleaved 16-bit PCM written by the lean kernel from the tiles it
         #      stages anyway -- half the bytes through the write path).  A secondary figure, never `value`: Claxon's Block is planar i32
         #      (frame.rs:402-411); this is what examples/decode.rs:48-62 and lib.rs:473-520 do with it right afterwards.
@@ -390,19 +420,15 @@ def main():
                                         "frac": round(alg16 / (ms_p * 1e-3) / 1e9 / PEAK_GBS, 4),
                                         "note": "CLX_OUT_PCM16: interleaved little-endian 16-bit PCM written by the decode kernel itself (2 bytes per sample "
                                                 "out instead of 4); secondary -- `value` is planar i32, Claxon's Block"}
-    if extras and world == 1 and args.workload == "config3" and w.pcm is not None and path_tag:
-        cfg["wave_kernels_pipelined"] = _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
-    if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
-        cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
     if rank == 0 and not args.no_cpu_baseline:
         # (at N > 1 too, on rank 0's share, behind the timed regions: north_star wants the CPU path timed in the same run at every N;
         #  the other ranks wait at the end)
         out["cpu_baseline"] = _cpu_baseline(w)
-    if rank == 0:
-        print(json.dumps(out))
     batch.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
+    if rank == 0:
+        _emit(json.dumps(out))
 
 
 def _device_of(devices, local_rank):
@@ -530,7 +556,7 @@ def _launcher_selftest(args):
     algs = [r[1] for r in per_rank]
     shard_info["imbalance"] = round(max(algs) / (sum(algs) / len(algs)) - 1.0, 5)
     if rank == 0:
-        print(json.dumps({"metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames", "value": None, "selftest": True,
+        _emit(json.dumps({"metric": "decoded Msamples/s (whole node), 4096-sample stereo 16-bit frames", "value": None, "selftest": True,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                           "scaling": scaling, "config": {"workload": workload_name, "samples_per_step": samples_all, "shard": shard_info,
                                                          "per_rank": [{"rank": i, "ms_per_step": r[0], "range": [int(r[2]), int(r[3])]} for i, r in enumerate(per_rank)],
@@ -692,14 +718,18 @@ def _link_rates():
         torch.cuda.synchronize()
         r[name] = 4 * n / (time.perf_counter() - t)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(4):
-        with torch.cuda.stream(s1):
-            d.copy_(h, non_blocking=True)
-        with torch.cuda.stream(s2):
-            h2.copy_(d2, non_blocking=True)
-    torch.cuda.synchronize()
-    r["both_each"] = 4 * n / (time.perf_counter() - t)
+    best = 0.0
+    for rep in range(3):          # (the first round sets the two streams' queues up -- round 5's boxes read 18 GB/s without it, 32 with -- best of the rest)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(4):
+            with torch.cuda.stream(s1):
+                d.copy_(h, non_blocking=True)
+            with torch.cuda.stream(s2):
+                h2.copy_(d2, non_blocking=True)
+        torch.cuda.synchronize()
+        if rep:
+            best = max(best, 4 * n / (time.perf_counter() - t))
+    r["both_each"] = best
     return r
 
 
