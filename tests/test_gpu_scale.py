@@ -430,3 +430,55 @@ def test_device_indexer_against_oracle_offsets(oracle, ctx):
         assert stop == (pos if not tail else starts[599])
         assert hdrs["block_size"].tolist() == [int(i.block_size) for i, _ in blocks[:n_idx]]
         assert hdrs["time"].tolist() == [int(i.time) for i, _ in blocks[:n_idx]]
+
+
+def test_everything_left_to_the_general_kernels_behind_the_tiers(oracle, ctx):
+    """16-bit audio with 20-tap predictors and no wider frame in the batch: clx_k_lean takes no group (more than 12 taps), the split tier
+    is not launched (nothing beyond 16 bits) -- EVERY group is on the list clx_k_left makes, for a reason only the stream knows.  Through
+    pipelined submissions: the first merged launch runs the general kernels with the small grid the descriptors suggest (each workgroup
+    loops over several groups), later ones with a grid sized by the longest list seen; every output buffer against the oracle."""
+    import torch
+    S = synth
+    n, bs = 3072, 1024
+    rng = np.random.default_rng(77)
+    t = np.arange(bs)
+    pcm = np.empty((n, 2, bs), dtype=np.int32)
+    for i in range(n):
+        for c in range(2):
+            pcm[i, c] = np.clip(np.round(4000.0 * np.sin(2 * np.pi * (50 + i % 97 + 11 * c) * t / 44100.0) + rng.normal(0, 6.0, bs)), -32768, 32767)
+    fp = [S.FrameParams() for _ in range(n)]
+    for i, f in enumerate(fp):
+        f.channel_assignment = i % 4
+        f.sf[0] = S.sf(S.SF_LPC, order=20, precision=12, partition_order=3)
+        f.sf[1] = S.sf(S.SF_LPC, order=16 + i % 5, precision=12, partition_order=2)
+    w = S.encode_frames("16-bit, 16-20 taps", pcm, 2, bs, 16, fp)
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True)
+    assert batch.submit_lanes
+    depth = min(batch.submit_depth, 5)
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(depth)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(3 * batch.submit_merge + 7):
+        batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+        if i == batch.submit_merge:          # (let the first launch's list length come back before the later launches are sized)
+            batch.flush(st); torch.cuda.synchronize()
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, nthreads=NTHREADS)
+    assert np.array_equal(res["status"], r["statuses"]) and np.all(res["status"] == cx.OK)
+    assert np.array_equal(res["end_bit"], r["end_bits"])
+    assert np.array_equal(ref, w.pcm)
+    d_ref = torch.from_numpy(ref).to("cuda:0")
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o, d_ref)), "output buffer %d differs from the oracle" % k
+    # which kernels worked: clx_k_lean found nothing to take, the order > 12 twin of the general kernels decoded everything
+    bl = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED)
+    bl.set_profiling(True)
+    bl.run(d_arena.data_ptr(), w.arena_len, outs[0].data_ptr())
+    torch.cuda.synchronize()
+    kt = bl.kernel_times()
+    assert "clx_k_left" in kt and kt["clx_k_lanes"] > 5.0 * kt["clx_k_lean"], kt
+    bl.close(); batch.close()
