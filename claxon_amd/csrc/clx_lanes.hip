@@ -603,6 +603,9 @@ struct Finish {
     bool any_decor, all_ms, any_wasted;
     // per-lane constants of clx_decor4's form  (even & pmask) + ((((odd ^ dsg) & drm) + dc) >> s1)
     uint32_t dsg, drm, dc, pmask;
+    // per-lane constants of clx_decor4_mad's form  (own * mo + other * mt + mc) >> 1, the wasted-bits shifts included (the 16-bit tier's)
+    int32_t mo, mt, mc;
+    bool ms_plain;                    // every lane in a mid/side pair and no wasted bits: clx_ms_short4
 };
 __device__ __forceinline__ Finish clx_lfinish_setup(uint32_t n, uint32_t wasted, uint32_t decor, bool pair_ok, int lane) {
     Finish F;
@@ -623,6 +626,12 @@ __device__ __forceinline__ Finish clx_lfinish_setup(uint32_t n, uint32_t wasted,
     F.any_decor = __any(pair_ok);
     F.all_ms = __all(n == 0u || d_ms);        // idle lanes (the tail of the last wave) do not spoil the short sequence
     F.any_wasted = __any(n != 0u && wasted != 0u);
+    F.ms_plain = F.all_ms && !F.any_wasted;
+    const uint32_t wo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wasted, 0xB1, 0xF, 0xF, false);      // the partner's wasted bits (lane ^ 1)
+    const int32_t own2 = (int32_t)(2u << wasted), other2 = (int32_t)(2u << wo);
+    F.mo = d_ms ? (odd ? -(own2 >> 1) : own2) : d_ls ? -own2 : own2;
+    F.mt = d_ms ? (odd ? other2 : (other2 >> 1)) : (d_ls || d_rs) ? other2 : 0;
+    F.mc = d_ms ? 1 : 0;
     return F;
 }
 __device__ __forceinline__ int32_t clx_lfinish(int32_t s, const Finish& F) {

@@ -225,8 +225,8 @@ __device__ __forceinline__ int32_t cln_careful_code(LaneReader& r, LCur& c, uint
 // the bit at which each later subframe starts -- subframe c+1 begins where subframe c ends, there is no length field
 // (frame.rs:705-742).  The round-2 build (clx_k_scan_general, clx_lanes.hip: lane-major ring, blocks of four codes with a vote
 // each) cost 14 vector instructions per code; this one runs the lean kernels' turn without its predictor and output: the
-// slot-major ring, sixteen codes per turn (four register windows of four codes; per code v_ffbh, v_min, one subtraction, half a
-// v_min3, one addition and one and a half v_alignbit), one vote per turn, the careful reader for everything rare.
+// slot-major ring, sixteen codes per turn (four register windows of four codes; per code v_ffbh, one subtraction, half a
+// v_max3, one addition and one and a half v_alignbit), one vote per turn, the careful reader for everything rare.
 // One turn of sixteen code lengths.  Returns 1 (cursor advanced for the live lanes), 0 (a rare case: the careful steps'), -2
 // (nothing but the ring having run dry).
 // ALL: every lane of the wave is live (the caller's vote): the masks that let lanes ride along are compiled out.
@@ -238,7 +238,8 @@ __device__ __forceinline__ int cln_scan_turn(const uint32_t* row, const LRing& g
     uint32_t c1 = 31u - c.k;
     CLX_OPAQUE(c1);
     bool bad = false;
-    int32_t msh = 0;                                  // the smallest "bits left of the window after the code" -- negative: a code > 32 bits
+    uint32_t zmax = 0;                                // the longest run of zeros (v_ffbh as it comes: all ones for an empty register) -- more
+                                                      // than 31 - k: a code > 32 bits (round 5; the lean turn's comment)
     uint32_t pw = c.p;
     const uint32_t pb = 4u + rice2, esc = rice2 ? 31u : 15u;
 #pragma unroll
@@ -269,24 +270,25 @@ __device__ __forceinline__ int cln_scan_turn(const uint32_t* row, const LRing& g
         uint32_t shsum = 0;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-            const uint32_t z = (uint32_t)__clz((int)wa);
+            const uint32_t z = clx_ffbh(wa);
             const int32_t sh = (int32_t)(c1 - z);     // 32 - (z + 1 + k): what is left of the window behind the code
-            msh = sh < msh ? sh : msh;
+            zmax = z > zmax ? z : zmax;
             shsum += (uint32_t)sh;
             wa = clx_alignbit(wa, wb, (uint32_t)sh); wb = clx_alignbit(wb, wc, (uint32_t)sh); wc = clx_alignbit(wc, wd, (uint32_t)sh); wd = clx_alignbit(wd, 0u, (uint32_t)sh);
         }
-        CLX_OPAQUE(msh);
+        if (EDGE) { bad = bad || zmax > c1; zmax = 0; }      // (the parameter may change with the next four)
         c.p += 128u - shsum;
     }
+    const bool toolong = !EDGE && zmax > c1;          // (one parameter for the whole turn)
     const bool covered = ((pw - 1u) >> 5) + 5u <= g.fill && c.p <= limit;
-    const bool ok = !live || (!bad && msh >= 0 && covered);
+    const bool ok = !live || (!bad && !toolong && covered);
     if (__all(ok)) {
         const uint32_t p_in = cur.p;
         cur = c;
         if (!live) cur.p = p_in;
         return 1;
     }
-    if (__any(live && (bad || msh < 0 || c.p > limit))) return 0;
+    if (__any(live && (bad || toolong || c.p > limit))) return 0;
     return -2;
 }
 
@@ -723,15 +725,8 @@ __device__ __forceinline__ void cln_finish4(const int32_t (&s0)[4], const Finish
 // the same for the turn's sixteen samples at once, at the END of the turn (the 16-bit tier: its turn stays one basic block, the
 // wave-uniform choice of the stereo form is made once, and the asm statements of the stereo forms stay out of the compiler's way
 // while it schedules the Rice and predictor work)
-__device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Finish& F, int4* mine, uint32_t sw) {
-    int32_t s[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = s0[i];
-    if (F.any_wasted) {                                  // wasted-bits shift (subframe.rs:216-225): a wave with such a lane only
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = (int32_t)((uint32_t)s[i] << F.wasted);
-    }
-    if (F.all_ms) {
+__device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finish& F, int4* mine, uint32_t sw) {
+    if (F.ms_plain) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
@@ -739,12 +734,15 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s0)[16], const Fini
             clx_ms_short4(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
             mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
         }
-    } else if (F.any_decor) {
+    } else if (F.any_decor || F.any_wasted) {
+        // any mix of stereo forms and wasted bits in the wave (round 5: four instructions per sample, the shift included, where the
+        // masked form took six and the shift a seventh).  Exact while a sample and its shifted value fit 24 bits: the turn's range
+        // check, whose limit cln_run lowers by the lane's wasted bits
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
             int32_t y[4];
-            clx_decor4(m, y, F.dsg, F.drm, F.dc, F.s1, F.pmask);        // (exact below 2^29: part of the turn's range check)
+            clx_decor4_mad(m, y, F.mo, F.mt, F.mc);
             mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
         }
     } else {
@@ -796,6 +794,7 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
     CLX_OPAQUE(c1);
     bool bad = false;
     int32_t msh = 0;                                  // the smallest "bits left of the window after the code" -- negative: a code > 32 bits
+    uint32_t zmax = 0;                                // MODE 0: the longest run of zeros instead (v_ffbh as it comes: all ones for an empty register)
     int32_t hi = -0x7fffffff - 1, lo = 0x7fffffff;
     uint32_t pw = c.p;
     int32_t S16[SPLIT ? 1 : 16];
@@ -838,14 +837,17 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             // one Rice code (subframe.rs:337-341): z zeros, a one, k remainder bits = 32 - sh bits
-            // (v_ffbh + v_min; a sentinel bit under the code instead of the clamp measured no faster: tools/gpu_ab.sh.  Round 4: v_ffbh taken
-            //  as it comes -- 0xffffffff for a zero register -- with one "was any register zero" per turn saves the sixteen v_min, but the
-            //  instruction has to be an asm statement then, which the compiler schedules around blindly: the pipelined step +15 %)
-            const uint32_t z = (uint32_t)__clz((int)wa);
+            // __clz is v_ffbh + v_min (32 for a register of zeros), and the smallest "bits left behind the code" of the turn said whether
+            // a code was longer than its window: v_ffbh, v_min, half a v_min3 per code.  Round 5: where every lane has Rice codes (MODE 0)
+            // the count is taken as the instruction gives it -- all ones for a register of zeros -- and the longest count is compared
+            // with what the window holds (unsigned: all ones is "too long" like 32 is), once per turn, or per four where the parameter may
+            // change: v_ffbh and half a v_max3 per code.  (Round 4 had the same idea with an asm volatile statement, which the compiler
+            // schedules around blindly: +15 %.  A plain asm statement is scheduled like any other instruction.)
+            const uint32_t z = MODE == 0 ? clx_ffbh(wa) : (uint32_t)__clz((int)wa);
             int32_t sh = (int32_t)(c14 - z);
             const uint32_t u = (z << kk) | clx_bfe(wa, (uint32_t)sh, k4);
             uint32_t xr = (u >> 1) ^ (0u - (u & 1u));                      // rice_to_signed (subframe.rs:157-170)
-            if (MODE == 0) msh = sh < msh ? sh : msh;
+            if (MODE == 0) zmax = z > zmax ? z : zmax;
             else {
                 // constants and verbatim fields (subframe.rs:382-415) ride along under masks -- no branch, no select on a condition
                 const int32_t shr = (int32_t)((uint32_t)sh & K.ricemask);   // (only a Rice code can be too long)
@@ -858,7 +860,10 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             wa = clx_alignbit(wa, wb, (uint32_t)sh); wb = clx_alignbit(wb, wc, (uint32_t)sh); wc = clx_alignbit(wc, wd, (uint32_t)sh); wd = clx_alignbit(wd, 0u, (uint32_t)sh);
             X[ii] = xr;
         }
-        CLX_OPAQUE(msh);                                          // (folded per four: no shift count of the block stays live for the vote)
+        if (MODE == 0) {
+            if (EDGE) { bad = bad || zmax > c14; zmax = 0; }      // (the parameter may change with the next four)
+        }
+        else CLX_OPAQUE(msh);                                     // (folded per four: no shift count of the block stays live for the vote)
         c.p += MODE == 0 ? 128u - shsum : ((128u - shsum) & K.bitmask);
         if (b < 3) { edge(); window(); }
         CLN_SCHED_FENCE();
@@ -909,6 +914,7 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
     // what was decoded is what the stream holds iff no code was longer than its window register, the last window lay inside the
     // ring's filled part and nothing reached past the end of the frame; the predictor was exact iff the outputs (the next turn's
     // history) stayed inside the range
+    if (MODE == 0 && !EDGE) msh = zmax > c1 ? -1 : 0;          // (one parameter for the whole turn)
     const bool covered = (((pw - 1u) >> 5) + 5u <= g.fill && c.p <= limit) || (MODE != 0 && K.bitmask == 0u);
     const bool ok = !live || (!bad && msh >= 0 && covered && hi < lim && lo >= -lim);
     const bool all = __all(ok);
@@ -1063,8 +1069,9 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     if (n == 0u) cur.p = 32u;            // a lane that decodes nothing rides along from a harmless position (never committed)
     // range in which the packed evaluation is exact: 16-bit factors, and no partial sum of the taps wraps 32 bits
     // (S.lim = min(2^23, (2^31 - 1) / sum|c|), clx_ltransition); a subframe without taps has nothing to keep in range
-    // (a subframe without taps has no history to keep in range; 2^29 is what the short mid/side form needs)
-    const int32_t cap = (1 << 29) >> (int)F.wasted;       // (what is shifted left by the wasted bits must still fit)
+    // (a subframe without taps has no history to keep in range; 2^23 before and after the wasted-bits shift is what the stereo
+    //  forms need: clx_decor4_mad.  16-bit audio -- 17 bits in a side channel -- never comes near it)
+    const int32_t cap = (1 << 23) >> (int)F.wasted;       // (what is shifted left by the wasted bits must still fit)
     const int32_t lim0 = S.order == 0u ? (1 << 29) : S.lim < 32768 ? S.lim : 32768;
     const int32_t lim = lim0 < cap ? lim0 : cap;
     int32_t CW[2 * NP];

@@ -202,6 +202,44 @@ __device__ __forceinline__ void clx_ms_short4(const int32_t (&y)[4], int32_t (&o
                  : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
                  : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(sgn), "v"(c));
 }
+// v_ffbh_u32 as it comes: the number of leading zeros, 0xffffffff for 0 (__clz adds a v_min for that case; __builtin_clz leaves it
+// undefined).  Not volatile: the compiler schedules it like any other instruction.
+__device__ __forceinline__ uint32_t clx_ffbh(uint32_t x) {
+    uint32_t z;
+    asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(x));
+    return z;
+}
+// Any stereo decorrelation (frame.rs:319-389) of four samples, or none, AND the wasted-bits shift (subframe.rs:216-225), by three
+// per-lane constants:   out = (own * mo + other * mt + c) >> 1   (other = the value of the lane's partner, lane ^ 1)
+//     mid/side    even (mid, w wasted bits; the side's: v): mo = 2 << w, mt = 1 << v, c = 1    odd (side): mo = -(1 << w), mt = 2 << v, c = 1
+//                 -- (2 mid + side + 1) >> 1 and (2 mid - side + 1) >> 1 are frame.rs:382-384's ((2 mid | side & 1) +- side) / 2
+//     left/side   even: mo = 2 << w, mt = 0      odd: mo = -(2 << w), mt = 2 << v  (left - side)
+//     right/side  even: mo = 2 << w, mt = 2 << v (side + right)      odd: mo = 2 << w, mt = 0
+//     no partner  mo = 2 << w, mt = 0
+// with v_mad_i32_i24: exact while both values lie in [-2^23, 2^23) BEFORE and AFTER their shifts (the caller's range check: then
+// nothing wraps here and nothing wraps in the reference's wrapping arithmetic).  Four instructions per sample, one of them DPP.
+__device__ __forceinline__ void clx_decor4_mad(const int32_t (&y)[4], int32_t (&out)[4], int32_t mo, int32_t mt, int32_t c) {
+    int32_t t;
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mad_i32_i24 %0, %5, %9, %11\n\t"
+                 "v_mad_i32_i24 %0, %4, %10, %0\n\t"
+                 "v_ashrrev_i32 %0, 1, %0\n\t"
+                 "v_mov_b32_dpp %4, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mad_i32_i24 %1, %6, %9, %11\n\t"
+                 "v_mad_i32_i24 %1, %4, %10, %1\n\t"
+                 "v_ashrrev_i32 %1, 1, %1\n\t"
+                 "v_mov_b32_dpp %4, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mad_i32_i24 %2, %7, %9, %11\n\t"
+                 "v_mad_i32_i24 %2, %4, %10, %2\n\t"
+                 "v_ashrrev_i32 %2, 1, %2\n\t"
+                 "v_mov_b32_dpp %4, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mad_i32_i24 %3, %8, %9, %11\n\t"
+                 "v_mad_i32_i24 %3, %4, %10, %3\n\t"
+                 "v_ashrrev_i32 %3, 1, %3"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
+                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(mo), "v"(mt), "v"(c));
+}
 // Any stereo decorrelation (frame.rs:319-389) of four samples, or none, by per-lane constants: in a pair of lanes (channel 0 in the
 // even one) the value that is added or subtracted is always the odd lane's and the value it is applied to the even lane's, so
 //     out = (even & pmask) + ((((odd ^ sg) & rmask) + c) >> s1)

@@ -335,6 +335,22 @@ def lean_workload(scale=1):
                 fp.sf[c] = S.sf(S.SF_LPC if i % 3 else S.SF_FIXED, int(g.integers(1, 5)) if i % 3 == 0 else int(g.integers(1, 13)), 12, int(g.integers(0, 5)))
             return (L, R), fp
         family(512, 32, 2, mk_h)
+        # (h2) wasted bits that differ between the two channels of a stereo form (the shift happens in front of the decorrelation,
+        #      per channel: subframe.rs:216-225 then frame.rs:319-389): left a multiple of 4 beside a free side, a right of multiples of 8 beside
+        #      a free side, a side of multiples of 8 beside a free mid
+        def mk_h2(i):
+            (L, R), g = music(i, 512, loud=0.2)
+            form = (1, 2, 3)[i % 3]                         # left/side, right/side, mid/side
+            if form == 1: L = (L >> 2) << 2
+            elif form == 2: R = (R >> 3) << 3
+            else: L = R + (((L - R) >> 3) << 3)
+            L = L.astype(np.int32); R = R.astype(np.int32)
+            assert L.min() >= -32768 and L.max() <= 32767
+            fp = S.FrameParams(form, 0, i)
+            for c in range(2):
+                fp.sf[c] = S.sf(S.SF_LPC if i % 4 else S.SF_FIXED, int(g.integers(1, 5)) if i % 4 == 0 else int(g.integers(1, 13)), 12, int(g.integers(0, 5)))
+            return (L, R), fp
+        family(512, 32, 2, mk_h2)
         # (g) blocks that end with (or right after) the prologue
         for bs in (32, 48):
             def mk_g(i, bs=bs):
