@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--process-group", action="store_true",
                     help="create the process group even when WORLD_SIZE is 1: the barrier and the MAX / SUM / all_gather reductions then go "
                          "through the backend (RCCL on device tensors with --backend nccl) on the one GPU that is there")
+    ap.add_argument("--pcm16-figure", action="store_true",
+                    help="internal: only the CLX_OUT_PCM16 secondary figure of this workload, as one JSON object (the default line runs this in a "
+                         "process of its own: the figure depends on which hardware queues the batch's streams get, i.e. on what ran before it)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no decode: only the launcher, the rank plan and the cross-rank reductions (CPU, gloo); prints a line with value null")
     args = ap.parse_args()
@@ -146,6 +149,10 @@ def main():
     # `value` is the VERIFIED step: every frame's CRC-16 footer is checked on the device inside it, as the reference does for every
     # frame it decodes (frame.rs:752-763) and as the cpu_baseline leg does; bare subframes (config 2) have no footer
     with_crc = (not w.bare_subframes) and not args.no_crc
+    if args.pcm16_figure:
+        fig = _pcm16_from_the_decode(torch, ctx, cx, w, descs, d_arena, dev, args.steps, args.repeats, with_crc, path)
+        _emit(json.dumps(fig))
+        return
     batch = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=path)
     # consecutive steps are submitted with up to batch.submit_depth of them in flight (clx_batch_submit: each step a whole run on
     # an internal stream of the library), so they rotate over that many output buffers -- when there is room for them
@@ -392,34 +399,13 @@ def main():
     if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
         cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
     if extras and world == 1 and pipelined and not w.bare_subframes and w.pcm is not None and int(np.max(w.bps)) <= 16:
-        # (BEHIND the host-buffer figures: the internal streams this batch creates and destroys change which hardware queues the host
-        #  pipeline's three streams get afterwards -- measured behind this block its upload-only figure read 1.61 ms, in front 1.40,
-        #  same library: tools/stream_probe.py)
-        # ---- narrow output straight from the decode (CLX_OUT_PCM16: interleaved 16-bit PCM written by the lean kernel from the tiles it
-        #      stages anyway -- half the bytes through the write path).  A secondary figure, never `value`: Claxon's Block is planar i32
-        #      (frame.rs:402-411); this is what examples/decode.rs:48-62 and lib.rs:473-520 do with it right afterwards.
-        bp = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=(path & (cx.COMPOSE | cx.NO_COMPOSE)) | cx.OUT_PCM16)
-        pouts = [torch.zeros(w.total_samples + 8, dtype=torch.int16, device=dev) for _ in range(bp.submit_depth)]
-        for i in range(len(pouts)):
-            bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i].data_ptr(), stream)
-        bp.flush(stream); torch.cuda.synchronize()
-        want16 = torch.from_numpy(w.pcm.reshape(-1, 2, w.pcm.size // (2 * w.n)).transpose(0, 2, 1).reshape(-1).astype(np.int16)).to(dev) \
-            if bool(np.all(w.channels == 2)) and bool(np.all(w.block_sizes == w.block_sizes[0])) else None
-        exact16 = (want16 is not None) and all(bool(torch.equal(o[:w.total_samples], want16)) for o in pouts) and bool(np.all(bp.results()["status"] == 0))
-        regs = []
-        for _ in range(max(1, args.repeats)):
-            barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
-            for i in range(args.steps):
-                bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i % len(pouts)].data_ptr(), stream)
-            bp.flush(stream); torch.cuda.synchronize(); regs.append(time.perf_counter() - t0)
-        bp.close(); del pouts
-        ms_p = 1e3 * float(np.median(regs)) / args.steps
-        alg16 = w.compressed_bytes + 2 * w.total_samples
-        cfg["pcm16_from_the_decode"] = {"value": round(w.total_samples / (ms_p * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_p, 4),
-                                        "bit_exact": exact16, "algorithmic_bytes": alg16, "achieved_GBps": round(alg16 / (ms_p * 1e-3) / 1e9, 1),
-                                        "frac": round(alg16 / (ms_p * 1e-3) / 1e9 / PEAK_GBS, 4),
-                                        "note": "CLX_OUT_PCM16: interleaved little-endian 16-bit PCM written by the decode kernel itself (2 bytes per sample "
-                                                "out instead of 4); secondary -- `value` is planar i32, Claxon's Block"}
+        # ---- narrow output straight from the decode (CLX_OUT_PCM16), in a process of its own: measured in this one the figure depended
+        #      on its place among the secondary figures (in front of the host-buffer block: 0.117 ms per step and that block's upload
+        #      figure 1.61 instead of 1.40 ms; behind it: 0.132 and 1.40 -- the internal streams a batch creates get their hardware queues
+        #      by what was created before them, tools/stream_probe.py).  A fresh process is the state `value` is measured in.
+        fig = _pcm16_subprocess(args)
+        if fig is not None:
+            cfg["pcm16_from_the_decode"] = fig
     if rank == 0 and not args.no_cpu_baseline:
         # (at N > 1 too, on rank 0's share, behind the timed regions: north_star wants the CPU path timed in the same run at every N;
         #  the other ranks wait at the end)
@@ -429,6 +415,52 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         _emit(json.dumps(out))
+
+
+def _pcm16_from_the_decode(torch, ctx, cx, w, descs, d_arena, dev, steps, repeats, with_crc, path):
+    """Narrow output straight from the decode (CLX_OUT_PCM16: interleaved 16-bit PCM written by the lean kernel from the tiles it stages
+    anyway -- half the bytes through the write path), consecutive steps like `value`'s.  A secondary figure, never `value`: Claxon's Block
+    is planar i32 (frame.rs:402-411); this is what examples/decode.rs:48-62 and lib.rs:473-520 do with it right afterwards."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bp = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=(path & (cx.COMPOSE | cx.NO_COMPOSE)) | cx.OUT_PCM16)
+    depth = bp.submit_depth
+    arenas = [d_arena] + [d_arena.clone() for _ in range(depth - 1)]          # (distinct copies of the input, like `value`'s steps)
+    pouts = [torch.zeros(w.total_samples + 8, dtype=torch.int16, device=dev) for _ in range(depth)]
+    for i in range(len(pouts)):
+        bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i].data_ptr(), stream)
+    bp.flush(stream); torch.cuda.synchronize()
+    want16 = torch.from_numpy(w.pcm.reshape(-1, 2, w.pcm.size // (2 * w.n)).transpose(0, 2, 1).reshape(-1).astype(np.int16)).to(dev) \
+        if bool(np.all(w.channels == 2)) and bool(np.all(w.block_sizes == w.block_sizes[0])) else None
+    exact16 = (want16 is not None) and all(bool(torch.equal(o[:w.total_samples], want16)) for o in pouts) and bool(np.all(bp.results()["status"] == 0))
+    regs = []
+    for _ in range(max(1, repeats)):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i % len(pouts)].data_ptr(), stream)
+        bp.flush(stream); torch.cuda.synchronize(); regs.append(time.perf_counter() - t0)
+    bp.close(); del pouts
+    ms_p = 1e3 * float(np.median(regs)) / steps
+    alg16 = w.compressed_bytes + 2 * w.total_samples
+    return {"value": round(w.total_samples / (ms_p * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_p, 4), "steps": steps,
+            "bit_exact": exact16, "algorithmic_bytes": alg16, "achieved_GBps": round(alg16 / (ms_p * 1e-3) / 1e9, 1),
+            "frac": round(alg16 / (ms_p * 1e-3) / 1e9 / PEAK_GBS, 4),
+            "note": "CLX_OUT_PCM16: interleaved little-endian 16-bit PCM written by the decode kernel itself (2 bytes per sample out instead "
+                    "of 4), measured in a process of its own; secondary -- `value` is planar i32, Claxon's Block"}
+
+
+def _pcm16_subprocess(args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--pcm16-figure", "--steps", str(args.steps), "--repeats", str(args.repeats),
+           "--workload", args.workload, "--frames", str(args.frames), "--total-frames", str(args.total_frames), "--unique", str(args.unique),
+           "--shard-of", str(args.shard_of), "--shard-rank", str(args.shard_rank), "--compose", args.compose, "--devices", args.devices]
+    if args.no_crc:
+        cmd.append("--no-crc")
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:                       # (a secondary figure: the line goes out without it)
+        print("bench: the CLX_OUT_PCM16 figure's process failed: %r" % (e,), file=sys.stderr)
+        return None
 
 
 def _device_of(devices, local_rank):
