@@ -708,3 +708,54 @@ def check_pcm16(oracle, backend, w, damage=0.0, seed=1):
         want = ref[a:a + c * bs].reshape(c, bs).T.reshape(-1).astype(np.int16)
         assert np.array_equal(out[a:a + c * bs], want), "frame %d (%d ch, bs %d)" % (int(i), c, bs)
     return int(ok.size)
+
+
+def ms_wild_workload(n=96, bs=1024, seed=31337):
+    """Mid/side 16-bit frames (order 8) whose quantisation shift has been lowered after encoding: the residual's codes still parse, the
+    predictor's loop gain is 2, 4 or 2^shift, and the samples run away -- past the 16-bit turns' range, past the wide turns', past 2^29,
+    wrapping.  What the reference computes from such a stream is defined (wrapping arithmetic: subframe.rs:575-582, frame.rs:371-389)
+    and the oracle computes it; clx_k_lean's short stereo forms are exact inside the turns' range checks only, so its waves must take
+    slow turn after slow turn and leave the group to the general kernels, whose stereo step is exact for every value.  Every third
+    family of 32 frames is left intact.  Returns (workload, patched arena)."""
+    S = synth
+    pcm = np.empty((n, 2, bs), dtype=np.int32)
+    fps = []
+    for i in range(n):
+        L, R, _ = S.pcm_music_like(seed + i, bs)
+        pcm[i, 0], pcm[i, 1] = L, R
+        fp = S.FrameParams(3, 0, i)
+        for c in range(2):
+            fp.sf[c] = S.sf(S.SF_LPC, 8, 12, 3)
+        fps.append(fp)
+    w = S.encode_frames("mid/side, shifts lowered", pcm, 2, bs, 16, fps)
+    arena = w.arena.copy()
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
+    for i in range(n):
+        fam = (i // 32) % 3
+        if fam == 2:
+            continue
+        # subframe 0: 8 header bits, 8 warm-up samples of 16 bits, 4 bits of precision, then the 5-bit shift
+        pos = 8 * (int(w.offs[i]) + int(descs["header_bytes"][i])) + 8 + 8 * 16 + 4
+        v = 0
+        for k in range(5):
+            v = (v << 1) | ((int(arena[(pos + k) >> 3]) >> (7 - ((pos + k) & 7))) & 1)
+        assert 2 <= v < 16, v
+        nv = (0 if i % 4 == 3 else v - 1 - (i % 2)) if fam == 0 else v - 1        # family 0: gains 2, 4, 2^shift; family 1: gain 2 only (runs away late)
+        for k in range(5):
+            byte, bit = (pos + k) >> 3, 7 - ((pos + k) & 7)
+            arena[byte] = (int(arena[byte]) & ~(1 << bit)) | (((nv >> (4 - k)) & 1) << bit)
+    return w, arena
+
+
+def check_ms_wild(oracle, backend):
+    w, arena = ms_wild_workload()
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
+    out, res = backend.decode(arena, w.arena_len, descs, w.out_offs, False, fill=0x5a5a5a5a)
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, check_crc=False)
+    assert np.array_equal(np.asarray(res["status"]), r["statuses"]) and np.array_equal(np.asarray(res["msg"]), r["msgs"])
+    assert np.all(r["statuses"] == cx.OK)
+    assert np.array_equal(np.asarray(res["end_bit"]), r["end_bits"])
+    assert int(np.abs(ref.astype(np.int64)).max()) > (1 << 29), "the samples were meant to run away"
+    assert np.array_equal(np.asarray(out)[:w.pcm.size], ref)
+    return int(np.count_nonzero(ref != w.pcm))

@@ -46,6 +46,12 @@ def test_gpu_lean24_tiers(oracle, gpu):
     pc.check_workload(oracle, gpu, pc.lean24_workload(scale=2))
 
 
+def test_gpu_mid_side_that_runs_away(oracle, gpu):
+    """parity_cases.ms_wild_workload: mid/side streams whose samples run away past every range check (and wrap): clx_k_lean's waves give
+    them up, the general kernels decode them -- the oracle's wrapping arithmetic everywhere, with every kernel selection"""
+    assert pc.check_ms_wild(oracle, gpu) > 0
+
+
 def test_gpu_edges(oracle, gpu):
     pc.check_workload(oracle, gpu, pc.edge_workload())
 

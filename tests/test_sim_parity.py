@@ -391,3 +391,30 @@ def test_sim_narrow_output_from_the_decode(oracle):
         assert stats[52] >= 8 and stats[49] >= 4, (int(stats[52]), int(stats[49]))      # groups the lean kernel wrote itself | groups left to the general kernels
     n_ok = pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w, damage=0.2, seed=3)
     assert n_ok < w.n
+
+
+def test_sim_mid_side_that_runs_away_is_left_to_the_general_kernels(oracle):
+    """parity_cases.ms_wild_workload: mid/side streams whose samples run away past every range check of clx_k_lean's turns (and past
+    2^29, where the short mid/side form stops being the reference's).  The waves that hold them keep needing the slow turn and are given
+    up; the general kernels decode them; the intact family stays with clx_k_lean.  Everything equals the oracle's wrapping arithmetic,
+    planar and narrow."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for i in range(64):
+        stats[i] = 0
+    changed = pc.check_ms_wild(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED))
+    assert changed > 0
+    given_up, taken = stats[57] // 64, stats[52]
+    assert (given_up, taken) == (2, 1), (given_up, taken)                  # three waves: two run away and are given up, one stays
+    # the narrow output of the same streams (the low halves of the same samples)
+    w, arena = pc.ms_wild_workload()
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
+    out, res = SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16).decode(arena, w.arena_len, descs, w.out_offs, False, fill=0x1111)
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    oracle.decode_batch(arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, check_crc=False)
+    out = np.asarray(out).view(np.int16) if np.asarray(out).dtype != np.int16 else np.asarray(out)
+    bs = int(w.block_sizes[0])
+    want = ref.reshape(-1, 2, bs).transpose(0, 2, 1).reshape(-1).astype(np.int16)
+    assert np.all(np.asarray(res["status"]) == cx.OK) and np.array_equal(out[:want.size], want)
