@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--order", type=int, default=0, help="config4 only: another predictor order than BASELINE's 32 (12: the split tier's <= 12-tap kernel)")
     ap.add_argument("--compose", choices=["auto", "on", "off"], default="auto",
                     help="waves composed by content (clx_k_compose): the library's choice by the descriptors, or forced on / off")
+    ap.add_argument("--pool", choices=["on", "off"], default="off",
+                    help="on: merged launches take the scan and the 16-bit tier as clx_k_pool's tickets (CLX_POOL: round 6's other launch form, measured slower)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process group backend for the barrier and the MAX / SUM reductions (nccl = RCCL)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="how often the timed region of --steps steps is repeated: `value` is the median region, min / max are carried beside it")
@@ -146,6 +148,7 @@ def main():
     path = {"auto": 0, "waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES, "lanes-fused": cx.PATH_LANES | cx.LANES_FUSED,
             "lanes-general": cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL}[args.path]
     path |= {"auto": 0, "on": cx.COMPOSE, "off": cx.NO_COMPOSE}[args.compose]
+    path |= cx.POOL if args.pool == "on" else 0
     # `value` is the VERIFIED step: every frame's CRC-16 footer is checked on the device inside it, as the reference does for every
     # frame it decodes (frame.rs:752-763) and as the cpu_baseline leg does; bare subframes (config 2) have no footer
     with_crc = (not w.bare_subframes) and not args.no_crc
@@ -216,7 +219,7 @@ def main():
     if pipelined and batch.submit_lanes and "clx_k_lanes" not in kernel_ms:
         # the pipelined steps run the fused lane kernels while one run at a time takes the wave kernels: the roofline block is
         # about the kernels of the TIMED steps, so their durations are taken from a batch forced onto them
-        bl = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=cx.PATH_LANES | cx.LANES_FUSED | (path & (cx.COMPOSE | cx.NO_COMPOSE)))
+        bl = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=cx.PATH_LANES | cx.LANES_FUSED | (path & (cx.COMPOSE | cx.NO_COMPOSE | cx.POOL)))
         kernel_ms = _kernel_ms(torch, bl, lambda: bl.run(d_arena.data_ptr(), w.arena_len, d_out.data_ptr(), stream), args.steps)
         bl.close()
         path_tag = "_lanes"
@@ -351,7 +354,7 @@ def main():
                              "barrier_note": "the closing barrier of a timed region, outside the clock (rank 0's median)"},
            "launcher": os.environ.get("CLX_BENCH_LAUNCHER", "external (WORLD_SIZE in the environment)" if world > 1 else "single process"),
            "bit_exact": True, "bit_exact_checked": "every output buffer vs the source PCM before the timed steps, and again -- on buffers cleared in between -- after them",
-           "crc16_in_step": bool(with_crc), "kernel_path": args.path, "compose": args.compose, "gen_seconds": round(gen_s, 1),
+           "crc16_in_step": bool(with_crc), "kernel_path": args.path, "compose": args.compose, "pool": args.pool, "gen_seconds": round(gen_s, 1),
            "steps_in_flight": depth if pipelined else 1, "distinct_input_copies_in_flight": len(arenas),
            "merged_launches_per_region": _launch_sizes(args.steps, batch.submit_merge) if (pipelined and batch.submit_lanes) else None,
            "devices": args.devices or None,
@@ -422,7 +425,7 @@ def _pcm16_from_the_decode(torch, ctx, cx, w, descs, d_arena, dev, steps, repeat
     anyway -- half the bytes through the write path), consecutive steps like `value`'s.  A secondary figure, never `value`: Claxon's Block
     is planar i32 (frame.rs:402-411); this is what examples/decode.rs:48-62 and lib.rs:473-520 do with it right afterwards."""
     stream = torch.cuda.current_stream(dev).cuda_stream
-    bp = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=(path & (cx.COMPOSE | cx.NO_COMPOSE)) | cx.OUT_PCM16)
+    bp = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=(path & (cx.COMPOSE | cx.NO_COMPOSE | cx.POOL)) | cx.OUT_PCM16)
     depth = bp.submit_depth
     arenas = [d_arena] + [d_arena.clone() for _ in range(depth - 1)]          # (distinct copies of the input, like `value`'s steps)
     pouts = [torch.zeros(w.total_samples + 8, dtype=torch.int16, device=dev) for _ in range(depth)]

@@ -277,6 +277,7 @@ struct clx_batch {
     unsigned general_grid = 0;       // workgroups per run of the general lane kernels behind the tiers (clx_plan_general_grid)
     uint32_t* d_most_left = nullptr; // the longest list of groups the tiers left in any run so far (clx_k_left), and where the host
     uint32_t* h_most_left = nullptr; // finds a copy of it (pinned; read without waiting: it sizes later launches)
+    uint32_t* h_most_left_dev = nullptr;     // the device's address of that copy (clx_k_left writes it)
     uint32_t* d_sf_start = nullptr;
     uint32_t* d_errkey = nullptr;
     uint64_t* d_endbits = nullptr;
@@ -288,7 +289,7 @@ struct clx_batch {
     clx_window* d_windows = nullptr; size_t n_windows = 0;
     uint32_t* d_slot_frame_run = nullptr; uint32_t* d_first_slot_run = nullptr; uint32_t* d_fkey = nullptr;
     bool profiling = false, profile_merged = false;
-    enum { kMaxKernels = 10 };
+    enum { kMaxKernels = 12 };
     hipEvent_t ev[kMaxKernels + 1] = {};
     const char* kname[kMaxKernels] = {};
     int n_kernels = 0;
@@ -332,6 +333,8 @@ struct clx_batch {
     bool launch_failed = false;                        // a merged launch was dropped; reported once more by the next flush / results
     hipStream_t pend_stream = nullptr;                 // the caller's stream the pending submissions came in on
     hipStream_t mstream[kMaxStreams] = {};
+    clx_pool_state* d_pool[kMaxStreams] = {};          // clx_k_pool's ticket counter of each stream's launch (zeroed in front of every launch)
+    unsigned pool_waves = 0;                           // waves of clx_k_pool the device holds at once (0: not asked yet)
     // An event behind each of a stream's last kEvRing launches: a later launch on ANOTHER stream that re-uses an output buffer or a
     // scratch set waits for exactly the launch that used it last -- not for whatever that stream has been given since (a region of
     // 20 steps goes out as 12 + 8: waiting for the other stream's LATEST launch would run the two one after the other).
@@ -433,6 +436,7 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     if (b->side_stream) { (void)hipStreamSynchronize(b->side_stream); (void)hipStreamDestroy(b->side_stream); }
     for (int k = 0; k < clx_batch::kMaxStreams; ++k) {
         if (b->mstream[k]) { (void)hipStreamSynchronize(b->mstream[k]); (void)hipStreamDestroy(b->mstream[k]); }
+        if (b->d_pool[k]) (void)hipFree(b->d_pool[k]);
         if (b->m_in[k]) (void)hipEventDestroy(b->m_in[k]);
         for (auto& e : b->m_done[k]) if (e) (void)hipEventDestroy(e);
     }
@@ -490,6 +494,7 @@ int plan_lanes_data(clx_batch* b) {
     if (!b->d_most_left && !hip_ok(ctx, hipMalloc((void**)&b->d_most_left, sizeof(uint32_t)), "hipMalloc most_left")) return CLX_API_ERROR;
     if (!b->h_most_left && !hip_ok(ctx, hipHostMalloc((void**)&b->h_most_left, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc most_left")) return CLX_API_ERROR;
     *b->h_most_left = 0u;
+    if (hipHostGetDevicePointer((void**)&b->h_most_left_dev, b->h_most_left, 0) != hipSuccess) { (void)hipGetLastError(); b->h_most_left_dev = nullptr; }      // (no hint then: full grids)
     if (!hip_ok(ctx, hipMemset(b->d_most_left, 0, sizeof(uint32_t)), "memset most_left")) return CLX_API_ERROR;
     if (!grow(ctx, &b->d_slot_frame, &b->cap[4], ns * sizeof(uint32_t), "hipMalloc slot_frame") ||
         !grow(ctx, &b->d_multi, &b->cap[5], nf * sizeof(uint32_t), "hipMalloc multi") ||
@@ -542,10 +547,11 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
     if (!b->pend.empty()) {
         // submissions that were accepted (CLX_OK) but still wait for company: they go out under the plan they were made for, and
         // are waited for here -- their scratch is released below
-        if (launch_pending(b) != CLX_OK) return CLX_API_ERROR;
+        if (launch_pending(b) != CLX_OK) { b->launch_failed = false; return CLX_API_ERROR; }      // (reported right here)
         for (int k = 0; k < clx_batch::kMaxStreams; ++k)
             if (b->mstream[k] && !hip_ok(ctx, hipStreamSynchronize(b->mstream[k]), "hipStreamSynchronize")) return CLX_API_ERROR;
     }
+    b->launch_failed = false;                  // (a new plan: nothing of it has been dropped)
     if (flags & CLX_OUT_PCM16) {
         // narrow output straight from the decode: <= 16-bit frames, the lane kernels' fused build with the tiers in front
         if (flags & (CLX_PATH_WAVES | CLX_LANES_SPLIT | CLX_LANES_GENERAL)) { ctx->last_error = "CLX_OUT_PCM16 runs the fused lane kernels with the lean tier: not with CLX_PATH_WAVES / CLX_LANES_SPLIT / CLX_LANES_GENERAL"; return CLX_API_ERROR; }
@@ -695,14 +701,49 @@ int use_lanes(clx_batch* b, size_t arena_len) {
     }
     return 1;
 }
+// How many waves clx_k_pool is launched with: as many as the device can hold at once, or as there are tickets.  The kernel's
+// registers allow three waves per SIMD (twelve per CU), its LDS ten per CU; waves beyond what fits wait for one that leaves and find
+// the counter run out.  (The runtime's occupancy query prices LDS for a 64 KiB CU -- four waves -- and is not asked.)
+unsigned pool_waves(clx_batch* b) {
+    if (b->pool_waves) return b->pool_waves;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    b->pool_waves = 12u * (unsigned)cus;
+    return b->pool_waves;
+}
 // The lane kernels of `n_runs` runs of the batch in one launch each (grid.y = the run): scan (where the later channels of
 // multi-channel frames start), the decode (the lean 16-bit tier, then the general kernels on the groups it left -- or the two-wave
 // build), the per-frame results, the CRC.  The runs' scratch (sf_start, errkey) is expected cleared to 0xff: the host does that when
 // it allocates it, clx_k_finalize leaves it so behind every run.
+// pool (merged launches; null: never) with CLX_POOL: the scan and the 16-bit tier as tickets of ONE kernel of resident waves
+// (clx_k_pool) when the batch's waves are not composed by content -- `pool` is the launch's stream's ticket counter, zeroed here in
+// front of the kernel.
 template <typename Mark>
-bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool split, hipStream_t stream, Mark&& mark) {
+bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool split, hipStream_t stream, Mark&& mark, clx_pool_state* pool = nullptr) {
     const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
-    if (b->n_multi) {
+    const bool composed = runs.r[0].fkey != nullptr && b->n_windows && b->n_multi;
+    const bool pooled = pool != nullptr && (b->flags & CLX_POOL) && !split && !composed && runs.r[0].taken != nullptr && b->any_bps_le16 && !(b->flags & CLX_LANES_GENERAL);
+#ifdef CLX_POOL_SCAN_APART      // (measurement builds: the scan as a kernel of its own in front of a pool of decode tickets only)
+    if (pooled && b->n_multi) {
+        if (!mark("clx_k_scan")) return false;
+        hipLaunchKernelGGL(clx_k_scan, dim3((unsigned)((b->n_multi + 63) / 64), n_runs), dim3(64), 0, stream, runs,
+                           (const clx_dev_frame*)b->d_frames, (const uint32_t*)b->d_multi, (uint32_t)b->n_multi);
+    }
+    const uint32_t pool_multi = 0u;
+#else
+    const uint32_t pool_multi = (uint32_t)b->n_multi;
+#endif
+    if (pooled) {
+        if (!mark("clx_k_pool")) return false;
+        if (hipMemsetAsync(pool, 0, sizeof(clx_pool_state), stream) != hipSuccess) return false;
+        clx_pool_args A;
+        A.runs = runs; A.frames = b->d_frames; A.multi = b->d_multi; A.ps = pool; A.order = nullptr; A.dump_all = b->d_dump;
+        A.n_runs = n_runs; A.n_slots = (uint32_t)b->n_slots; A.n_multi = pool_multi; A.pad = 0u;
+        const uint64_t tickets = (uint64_t)n_runs * ((uint64_t)groups + (pool_multi + 63u) / 64u);
+        hipLaunchKernelGGL(clx_k_pool, dim3((unsigned)std::min<uint64_t>(tickets, pool_waves(b))), dim3(64), 0, stream, A);
+    }
+    else if (b->n_multi) {
         if (!mark("clx_k_scan")) return false;
         if (b->flags & CLX_LANES_GENERAL)         // (the round-2 build of the scan, with the round-2 decode kernels: the comparison target)
             hipLaunchKernelGGL(clx_k_scan_general, dim3((unsigned)((b->n_multi + 63) / 64), n_runs), dim3(64), 0, stream, runs,
@@ -713,12 +754,12 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
     }
     if (!split) {
         // waves composed by content: the windows' frames dealt to the lanes by class (the scan has left every frame's class)
-        if (runs.r[0].fkey != nullptr && b->n_windows && b->n_multi) {
+        if (composed) {
             if (!mark("clx_k_compose")) return false;
             hipLaunchKernelGGL(clx_k_compose, dim3((unsigned)b->n_windows, n_runs), dim3(CLX_COMPOSE_THREADS), 0, stream, runs, (const clx_window*)b->d_windows);
         }
         // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them
-        if (runs.r[0].taken != nullptr && b->any_bps_le16) {
+        if (runs.r[0].taken != nullptr && b->any_bps_le16 && !pooled) {
             if (!mark("clx_k_lean")) return false;
             // CLX_LEAN_LDS_PAD (measurement builds only): extra dynamic LDS per wave, i.e. fewer decode waves per CU -- the knob behind
             // profiles/r05_occupancy_sweep.txt
@@ -745,7 +786,7 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
         const bool listed = runs.r[0].taken != nullptr;
         if (listed) {
             if (!mark("clx_k_left")) return false;
-            hipLaunchKernelGGL(clx_k_left, dim3((groups + 255) / 256, n_runs), dim3(256), 0, stream, runs, (uint32_t)groups, b->d_most_left);
+            hipLaunchKernelGGL(clx_k_left, dim3((groups + 255) / 256, n_runs), dim3(256), 0, stream, runs, (uint32_t)groups, b->d_most_left, b->h_most_left_dev);
             if (n_runs > 1 && b->general_grid) {
                 const unsigned seen = b->h_most_left ? *(volatile uint32_t*)b->h_most_left : 0u;
                 ggrid = std::min(groups, std::max(b->general_grid, 2u * seen + 16u));
@@ -756,7 +797,6 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
         hipLaunchKernelGGL(clx_k_lanes_hi, dim3(ggrid, n_runs), dim3(64), 0, stream, runs,
                            (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
-        if (listed && b->h_most_left) (void)hipMemcpyAsync(b->h_most_left, b->d_most_left, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (b->flags & CLX_OUT_PCM16) {          // what the general kernels decoded into the planar scratch: narrowed into the output
             if (!mark("clx_k_narrow_left")) return false;
             hipLaunchKernelGGL(clx_k_narrow_left, dim3(ggrid, n_runs), dim3(256), 0, stream, runs, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots);
@@ -893,9 +933,22 @@ int launch_pending(clx_batch* b, bool inputs_ready) {
     };
 #define LP_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(#expr, e_); } while (0)
     if (!b->mstream[k]) {
-        LP_TRY(hipStreamCreateWithFlags(&b->mstream[k], hipStreamNonBlocking));
-        LP_TRY(hipEventCreateWithFlags(&b->m_in[k], hipEventDisableTiming));
-        for (auto& e : b->m_done[k]) LP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // the stream, its events and its ticket counter into locals first: the batch gets them only when ALL of them exist (a stream
+        // without its events would make every later launch on it fail)
+        hipStream_t st = nullptr; hipEvent_t e_in = nullptr, e_done[clx_batch::kEvRing] = {}; clx_pool_state* pool = nullptr;
+        hipError_t e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e0 == hipSuccess) e0 = hipMalloc((void**)&pool, sizeof(clx_pool_state));
+        if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&e_in, hipEventDisableTiming);
+        for (auto& e : e_done) if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (e0 != hipSuccess) {
+            for (auto& e : e_done) if (e) (void)hipEventDestroy(e);
+            if (e_in) (void)hipEventDestroy(e_in);
+            if (pool) (void)hipFree(pool);
+            if (st) (void)hipStreamDestroy(st);
+            return fail("creating an internal stream", e0);
+        }
+        b->mstream[k] = st; b->m_in[k] = e_in; b->d_pool[k] = pool;
+        for (int j = 0; j < clx_batch::kEvRing; ++j) b->m_done[k][j] = e_done[j];
     }
     hipStream_t ms = b->mstream[k];
     // behind everything queued so far on the stream the submissions came in on (their inputs)
@@ -954,10 +1007,11 @@ int launch_pending(clx_batch* b, bool inputs_ready) {
     int nk = 0;
     auto mark = [&](const char* name) -> bool {          // (clx_batch_set_profiling(b, 2): an event in front of each kernel, one behind the last)
         if (!b->profile_merged) return true;
+        if (nk > (name ? clx_batch::kMaxKernels - 1 : clx_batch::kMaxKernels)) { ctx->last_error = "more kernels in one launch than profiling marks"; return false; }
         if (name) b->kname[nk] = name;
         return hip_ok(ctx, hipEventRecord(b->ev[nk++], ms), "hipEventRecord");
     };
-    if (!(launch_lanes(b, runs, n_runs, false, ms, mark) && hipGetLastError() == hipSuccess)) return fail("kernel launch", hipSuccess);
+    if (!(launch_lanes(b, runs, n_runs, false, ms, mark, b->d_pool[k]) && hipGetLastError() == hipSuccess)) return fail("kernel launch", hipSuccess);
     if (b->profile_merged) { if (!mark(nullptr)) return fail("hipEventRecord", hipSuccess); b->n_kernels = nk - 1; b->ev_valid = true; b->ev_runs = (int)n_runs; }
     LP_TRY(hipEventRecord(b->m_done[k][b->m_count[k] % clx_batch::kEvRing], ms));
 #undef LP_TRY
@@ -1009,6 +1063,7 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
     int nk = 0;
     auto mark = [&](const char* name) -> bool {          // event before each kernel (+ one after the last)
         if (!b->profiling) return true;
+        if (nk > (name ? clx_batch::kMaxKernels - 1 : clx_batch::kMaxKernels)) { ctx->last_error = "more kernels in one run than profiling marks"; return false; }
         if (name) b->kname[nk] = name;
         return hip_ok(ctx, hipEventRecord(b->ev[nk++], stream), "hipEventRecord");
     };

@@ -73,6 +73,24 @@ struct clx_run {
 #define CLX_RUN_PCM16 2u     // `out` holds interleaved 16-bit PCM (claxon_hip.h: CLX_OUT_PCM16)
 struct clx_runs { clx_run r[CLX_MAX_MERGE]; };       // passed to the kernels by value
 
+// clx_k_pool (clx_lean.hip): the scan waves and the 16-bit tier's decode waves of one merged launch as TICKETS that a grid of resident
+// waves takes off a counter -- first every run's scan waves, then every run's groups of 64 slots.  One of these per internal stream
+// (launches of one stream follow each other); zeroed in front of every launch.
+struct clx_pool_state {
+    uint32_t next;                       // the next ticket
+    uint32_t stuck;                      // decode tickets whose wave gave up waiting for its run's scan (their groups go to the general kernels)
+    uint32_t scan_done[CLX_MAX_MERGE];   // per run of the launch: scan tickets that are done
+};
+struct clx_pool_args {                   // clx_k_pool's arguments (one struct by value: the kernel reads it again for every ticket)
+    clx_runs runs;
+    const clx_dev_frame* frames;
+    const uint32_t* multi;               // the multi-channel frames (the scan's lanes)
+    clx_pool_state* ps;
+    const uint32_t* order;               // test hook: ticket i of the counter stands for ticket order[i] (null: itself)
+    int32_t* dump_all;
+    uint32_t n_runs, n_slots, n_multi, pad;
+};
+
 // clx_k_compose: a window of consecutive stereo frames of one block size whose lanes are dealt by content class (clx_plan.h)
 #define CLX_COMPOSE_WINDOW 16384u
 #define CLX_COMPOSE_KEYS 32u

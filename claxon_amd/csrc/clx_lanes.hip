@@ -1165,7 +1165,7 @@ __device__ __forceinline__ void clx_lanes_fused(const clx_runs& runs, const clx_
 //  general kernels' grid of LATER launches: what is left for reasons only the stream knows -- 16-bit audio of more than 12 taps in a
 //  batch without the split tier, waves that give up -- is left again in the next run of the same batch)
 extern "C" __global__ __launch_bounds__(256)
-void clx_k_left(const clx_runs runs, uint32_t n_groups, uint32_t* __restrict__ most_left) {
+void clx_k_left(const clx_runs runs, uint32_t n_groups, uint32_t* __restrict__ most_left, uint32_t* __restrict__ most_left_host) {
     const clx_run& R = runs.r[blockIdx.y];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_groups || R.taken == nullptr) return;
@@ -1173,7 +1173,10 @@ void clx_k_left(const clx_runs runs, uint32_t n_groups, uint32_t* __restrict__ m
         uint32_t* const left = R.taken + n_groups;
         const uint32_t i = atomicAdd(&left[0], 1u);
         left[1u + i] = g;
-        if (most_left != nullptr) atomicMax(most_left, i + 1u);
+        // (the host's copy, in pinned memory the device writes to: a plain store by whoever raised the maximum -- a hint that sizes
+        //  later launches' grids.  Round 5 copied it back in the stream behind the general kernels: 0.1 ms per launch in front of
+        //  clx_k_finalize, profiles/r06_pipelined_trace.txt)
+        if (most_left != nullptr && atomicMax(most_left, i + 1u) < i + 1u && most_left_host != nullptr) *(volatile uint32_t*)most_left_host = i + 1u;
     }
 }
 // Narrow output (CLX_OUT_PCM16): the frames of the groups the tiers left were decoded into the run's planar scratch; one workgroup per

@@ -372,18 +372,17 @@ __device__ __forceinline__ int cln_scan_turns(const uint32_t* row, const LRing& 
     return done;
 }
 
-extern "C" __global__ __launch_bounds__(64)
-void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ multi, uint32_t n_multi) {
-    __shared__ struct { uint32_t ring[CLN_ROW][64]; } L;        // (the ring only: 7 KiB per wave -- they fit beside the decode waves)
-    const clx_run& R = runs.r[blockIdx.y];
+// The scan of one wave's 64 multi-channel frames (wave `bx` of run R); ring0: a ring of CLN_ROW x 64 dwords of LDS.  clx_k_scan's body, and
+// the scan tickets' of clx_k_pool.
+__device__ __forceinline__ void cln_scan_wave(uint32_t* ring0, const clx_run& R, const clx_dev_frame* __restrict__ frames,
+                                              const uint32_t* __restrict__ multi, uint32_t n_multi, uint32_t bx, uint32_t run_idx, int lane) {
     CLX_TL_BEGIN();
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
     uint32_t* const sf_start = R.sf_start;
     uint32_t* const errkey = R.errkey;
-    const int lane = (int)threadIdx.x;
-    uint32_t* const row = &L.ring[0][lane];
-    const uint32_t t = blockIdx.x * 64u + (uint32_t)lane;
+    uint32_t* const row = ring0 + lane;
+    const uint32_t t = bx * 64u + (uint32_t)lane;
     const bool active = t < n_multi;
     const uint32_t f = active ? multi[t] : 0u;
     clx_dev_frame fr;
@@ -511,7 +510,7 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
         }
         if (on) {
             if (r.err) clx_report_error(errkey, f, ch, r.err);
-            else sf_start[fr.first_slot + ch + 1u] = r.pos;
+            else clx_poke_u32(&sf_start[fr.first_slot + ch + 1u], r.pos);      // (past the caches: a decode wave of the same kernel may be waiting for it, clx_k_pool)
         }
     }
     // ---- the frame's content class, with the last channel's header (the cursor stands in front of it)
@@ -528,7 +527,14 @@ void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, c
         }
         R.fkey[f] = key;
     }
-    CLX_TL_END_SEQ(2, ((uint64_t)R.gen << 32) | (blockIdx.y << 20) | blockIdx.x);
+    CLX_TL_END_SEQ(2, ((uint64_t)R.gen << 32) | (run_idx << 20) | bx);
+    (void)run_idx;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void clx_k_scan(const clx_runs runs, const clx_dev_frame* __restrict__ frames, const uint32_t* __restrict__ multi, uint32_t n_multi) {
+    __shared__ struct { uint32_t ring[CLN_ROW][64]; } L;        // (the ring only: 7 KiB per wave -- they fit beside the decode waves)
+    cln_scan_wave(&L.ring[0][0], runs.r[blockIdx.y], frames, multi, n_multi, blockIdx.x, blockIdx.y, (int)threadIdx.x);
 }
 
 // ---- C: waves composed by content ---------------------------------------------------------------------------------------------
@@ -769,7 +775,7 @@ __device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finis
 // is a multiple of 2^e2, and A_hi + (A_lo >> 12) stays inside 32 bits.  No 64-bit instruction per sample.
 template <int NP, int MODE, bool EDGE, int FORM, int HN>
 __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g, LCur& cur, uint32_t (&H)[HN], const uint32_t (&C)[NP],
-                                              const int32_t (&CW)[2 * NP], uint32_t shift, uint32_t e1, uint32_t e3, int32_t lim, uint32_t per, uint32_t rice2,
+                                              uint32_t shift, uint32_t e1, uint32_t e3, int32_t lim, uint32_t per, uint32_t rice2,
                                               uint32_t limit, bool live, const LKind& K, const Finish& F, int4* mine, uint32_t sw) {
     constexpr bool WIDE = FORM == 1, SPLIT = FORM == 2;
     constexpr int NH = 2 * NP - 1;                    // pairs carried from turn to turn
@@ -777,6 +783,11 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
     uint32_t P[NH + 16];                              // P[NH + m] = pair that ends at sample m of the turn (m = -NH .. 15); SPLIT: of lo pieces
     uint32_t PH[SPLIT ? NH + 16 : 1];                 // SPLIT: the same of hi pieces
     int32_t hw[2 * NP + 16];                          // WIDE: hw[2NP - 1 - j + i] = s[i - 1 - j]: the samples in time order, the turn's own appended
+    int32_t cw[WIDE ? 2 * NP : 1];                    // WIDE: the coefficients unpacked -- per turn: kept across the decode loop they cost 2 NP registers
+    if (WIDE) {                                       // that the packed turns, the usual ones, have no use for (round 6)
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) cw[WIDE ? j : 0] = cln_coef<NP>(C, j);
+    }
     if (!WIDE) {
 #pragma unroll
         for (int j = 0; j < NH; ++j) P[NH - 1 - j] = H[j];
@@ -892,7 +903,7 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
                 pred = acc >> shift;
             } else {
 #pragma unroll
-                for (int j = 2 * NP - 1; j >= 0; --j) acc = __mul24(CW[j], hw[2 * NP - 1 - j + i]) + acc;      // c[j] * s[i-1-j]: v_mad_i32_i24
+                for (int j = 2 * NP - 1; j >= 0; --j) acc = __mul24(cw[j], hw[2 * NP - 1 - j + i]) + acc;      // c[j] * s[i-1-j]: v_mad_i32_i24
                 pred = acc >> shift;
             }
             const int32_t s = (int32_t)(xr + (uint32_t)pred);                                       // + prediction (wrapping)
@@ -954,7 +965,7 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
 #endif
 template <int NP>
 __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRing& g, uint32_t* row, int4* stage, LCur& cur, uint32_t (&H)[2 * NP],
-                                         const uint32_t (&C)[NP], const int32_t (&CW)[2 * NP], uint32_t order, uint32_t shift, int32_t lim, int32_t lim24,
+                                         const uint32_t (&C)[NP], uint32_t order, uint32_t shift, int32_t lim, int32_t lim24,
                                          uint32_t per, uint32_t rice2,
                                          uint32_t n, uint32_t i0, uint32_t nmax, const LKind& K, int mode, const Finish& F, const LMover& M, LTile& T, int lane,
                                          LCrc& CR, bool crc, bool calm) {
@@ -995,10 +1006,10 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
           again_lean:
             if (mode == 0 || NP == 2) {                // (NP == 2 is only run with mode 0)
                 // a partition edge inside the turn?  (lanes that decode nothing never say yes; cur.pcnt of the others is exact)
-                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
-                else                                 done = cln_lean_turn<NP, 0, false, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
+                if (clx_any(live && cur.pcnt < 16u)) done = cln_lean_turn<NP, 0, true, 0>(row, g, cur, H, C, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
+                else                                 done = cln_lean_turn<NP, 0, false, 0>(row, g, cur, H, C, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
             }
-            else                      done = cln_lean_turn<NP, 1, true, 0>(row, g, cur, H, C, CW, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
+            else                      done = cln_lean_turn<NP, 1, true, 0>(row, g, cur, H, C, shift, 0u, 0u, lim, per, rice2, r.limit, live, K, F, mine, sw);
             if (done > 0) {
                 cln_done(T, t0);
                 CLX_STAT(50, 1);
@@ -1023,7 +1034,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             for (int j = 0; j < 2 * NP; ++j) in24 = in24 && (int32_t)H[j] < lim24 && (int32_t)H[j] >= -lim24;
             if (__all(in24 || !live || order == 0u)) {
               again_wide:
-                const int dw = cln_lean_turn<NP, 1, true, 1>(row, g, cur, H, C, CW, shift, 0u, 0u, lim24, per, rice2, r.limit, live, K, F, mine, sw);
+                const int dw = cln_lean_turn<NP, 1, true, 1>(row, g, cur, H, C, shift, 0u, 0u, lim24, per, rice2, r.limit, live, K, F, mine, sw);
                 if (dw > 0) {
                     cln_done(T, t0);
                     CLX_STAT(58, 1);
@@ -1074,13 +1085,10 @@ __device__ __forceinline__ bool cln_run(const clx_buf& buf, LaneState<12>& S, LR
     const int32_t cap = (1 << 23) >> (int)F.wasted;       // (what is shifted left by the wasted bits must still fit)
     const int32_t lim0 = S.order == 0u ? (1 << 29) : S.lim < 32768 ? S.lim : 32768;
     const int32_t lim = lim0 < cap ? lim0 : cap;
-    int32_t CW[2 * NP];
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) CW[j] = S.c[j];
     // the 24-bit evaluation's range (clx_ltransition), under the same cap for subframes without taps
     const int32_t lim24a = S.order == 0u ? (1 << 29) : S.lim;
     const int32_t lim24 = lim24a < cap ? lim24a : cap;
-    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, CW, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
+    const bool done = cln_body<NP>(buf, S.r, g, row, stage, cur, H, C, S.order, S.shift, lim, lim24, S.per, S.rice2, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
     S.r.pos = cur.p; S.k = cur.k; S.pcnt = cur.pcnt; S.next_cnt = cur.next; S.parts_left = cur.parts;
     return done;
 }
@@ -1116,9 +1124,6 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
     const uint32_t e1 = shift <= 12u ? 12u - shift : 0u, e2 = shift <= 12u ? shift : 12u, e3 = shift <= 12u ? 0u : shift - 12u;
     uint32_t H[2 * NH];
-    int32_t CW[2 * NP];                                  // (the split form does not look at the unpacked coefficients)
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) CW[j] = 0;
     {   // (a history outside the range cannot even be kept in the pieces: such a wave -- garbage, or audio beyond 24 bits -- gives
         //  the group up at once, here and behind a slow turn)
         int32_t U[2 * NP];
@@ -1139,7 +1144,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         {
             bool refilled = false;
           again:
-            const int done = cln_lean_turn<NP, 1, true, 2>(row, g, cur, H, C, CW, e2, e1, e3, lim, per, rice2, r.limit, live, K, F, mine, sw);
+            const int done = cln_lean_turn<NP, 1, true, 2>(row, g, cur, H, C, e2, e1, e3, lim, per, rice2, r.limit, live, K, F, mine, sw);
             if (done > 0) {
                 cln_done(T, t0);
                 CLX_STAT(9, 1);
@@ -1200,12 +1205,12 @@ __device__ __forceinline__ bool cln_run24(const clx_buf& buf, LaneState<OMAX>& S
 
 // The kernels' common body.  SPLIT = false: clx_k_lean (<= 16-bit audio, <= 12 taps); true: clx_k_lean24 (<= 24-bit audio -- a side
 // channel has 25 --, <= 32 taps, the groups clx_k_lean left).
+// (bx: the group of 64 slots of run R that the wave decodes -- the workgroup's index in clx_k_lean / clx_k_lean24, a decode ticket of clx_k_pool)
 template <bool SPLIT>
-__device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, const clx_dev_frame* __restrict__ frames,
-                                           uint32_t n_slots, int32_t* __restrict__ dump_all) {
+__device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const clx_dev_frame* __restrict__ frames,
+                                           uint32_t n_slots, int32_t* __restrict__ dump_all, uint32_t bx, uint32_t run_idx, int lane) {
     constexpr int OMAX = SPLIT ? 32 : 12;
-    const clx_run& R = runs.r[blockIdx.y];
-    if (SPLIT && R.taken[blockIdx.x] == R.gen) return;       // clx_k_lean has decoded this group
+    if (SPLIT && R.taken[bx] == R.gen) return;               // clx_k_lean has decoded this group
     CLX_TL_BEGIN();                                          // (-DCLX_TIMELINE builds only: tools/timeline_lean.py)
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
@@ -1215,8 +1220,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     uint64_t* const end_bits = R.end_bits;
     uint32_t* const taken = R.taken;
     const uint32_t gen = R.gen;
-    const int lane = (int)threadIdx.x;
-    const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+    const uint32_t slot = bx * 64u + (uint32_t)lane;
     // (which frame this lane decodes: the run's slot map -- the plan's, or what clx_k_compose dealt; what the scan and the CRC parts
     //  are indexed by is the PLAN's slot of the subframe, cslot)
     uint32_t f = 0xffffffffu;
@@ -1238,7 +1242,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     r.err = 0u;
     bool active = (f != 0xffffffffu);
     if (active && ch != 0u) {
-        const uint32_t sp = sf_start[cslot];
+        const uint32_t sp = clx_peek_u32(&sf_start[cslot]);      // (past the caches: the scan wave that wrote it may belong to this very kernel, clx_k_pool)
         if (sp == 0xffffffffu) active = false;             // an earlier channel failed (the scan reported it): decodes nothing
         else r.pos = sp;
     }
@@ -1281,7 +1285,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
         }
         return;
     }
-    if (lane == 0) taken[blockIdx.x] = gen;
+    if (lane == 0) taken[bx] = gen;
 
     // ---- the lane's share of its frame's CRC-16 (LCrc): from the granule in which its subframe starts to the granule in which
     //      the next one does (the scan has said where: sf_start), the last channel's to the end of the frame as the descriptor
@@ -1290,7 +1294,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
     const bool crc = (R.flags & CLX_RUN_CRC) != 0u;       // wave-uniform
     // (where the next subframe starts: the end of this lane's share of the frame's CRC, and how many bits its subframe holds)
     const bool last_ch = active && ch + 1u == (uint32_t)fr.n_channels;
-    const uint32_t next_sp = (active && !last_ch) ? sf_start[cslot + 1u] : 0xffffffffu;
+    const uint32_t next_sp = (active && !last_ch) ? clx_peek_u32(&sf_start[cslot + 1u]) : 0xffffffffu;
     // a calm wave: no lane's subframe holds more than 6 bits per sample -- its ring is pumped every other turn (cln_pump_now)
     const uint32_t sf_bits = !active ? 0u : last_ch ? o + fr.limit_bits - pos0 : next_sp - pos0;       // (a failed or unbounded one: huge)
     const bool calm = __all(sf_bits <= 6u * bs);
@@ -1395,7 +1399,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
             else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
         }
         if (!done) {                                       // given up: clx_k_lanes decodes the group
-            if (lane == 0) taken[blockIdx.x] = 0u;
+            if (lane == 0) taken[bx] = 0u;
             CLX_STAT(SPLIT ? 11 : 57, 1);
             return;
         }
@@ -1425,7 +1429,8 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
             R.crc_part[cslot] = part;
         }
     }
-    CLX_TL_END_SEQ(3, ((uint64_t)R.gen << 32) | (blockIdx.y << 20) | blockIdx.x);
+    CLX_TL_END_SEQ(3, ((uint64_t)R.gen << 32) | (run_idx << 20) | bx);
+    (void)run_idx;
 }
 
 #ifndef CLN_WAVES
@@ -1434,11 +1439,83 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_runs& runs, con
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CLN_WAVES)))
 void clx_k_lean(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;
-    cln_kernel<false>(L, runs, frames, n_slots, dump_all);
+    cln_kernel<false>(L, runs.r[blockIdx.y], frames, n_slots, dump_all, blockIdx.x, blockIdx.y, (int)threadIdx.x);
+}
+
+// ---- Q: the scan and the 16-bit tier of one merged launch as tickets (round 6) ---------------------------------------------------
+// clx_k_pool: a grid of waves that STAY (as many as the machine holds at once, or as there are tickets), each taking tickets off a
+// counter until none is left -- first the launch's scan waves (run by run), then its groups of 64 slots (run by run).  Why: a launch
+// of clx_k_lean over thousands of workgroups shares the machine's wave slots EVENLY with the other stream's launch, so that both run
+// out of workgroups -- and drain -- at the same time (profiles/r05_timeline_region_before.txt: the streams fall into step), and the
+// scan in front of it is a kernel boundary at which the stream's waves are gone.  Waves that stay hold their slots until their
+// launch's tickets are gone: the launches of the two streams take the machine one after the other, the next one's waves moving in
+// one by one as this one's leave, and a launch's decode waves start where its scan waves end.
+// A decode ticket needs its RUN's scan (sf_start): scan tickets are taken before any decode ticket, so whoever holds one is a
+// resident wave and the wait ends; all the same it is bounded -- a wave that waits longer than any scan can take leaves its group
+// unmarked, i.e. to the general kernels behind (which run when this kernel, and with it every scan ticket, is over).
+// order: a test hook (the wave simulator takes the tickets in a given order); null on the device.
+// What the scan waves hand to the decode waves is sf_start alone (errors go through atomics): written and read PAST the caches
+// (clx_poke_u32 / clx_peek_u32) instead of fenced -- an agent-scope acquire in front of every decode ticket invalidates the XCD's whole
+// L2, three times a microsecond, under the decode lanes' streams (eight 16-byte granules to a line): measured, the pool's launch of
+// twelve runs 2.29 ms with the fences against 2.0 ms for round 5's two kernels.
+#ifndef CLN_POOL_FENCES
+#define CLN_POOL_FENCES 0
+#endif
+#ifndef CLN_POOL_SPIN
+#define CLN_POOL_SPIN (1u << 18)        // looks at the counter before a decode wave gives up (about a second)
+#endif
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CLN_WAVES)))
+void clx_k_pool(const clx_pool_args args) {
+    __shared__ LeanLds L;
+    (void)args;
+#pragma unroll 1
+    for (;;) {
+        // (the arguments are read again for every ticket, through a pointer the compiler cannot see through: whatever it hoisted out
+        //  of this loop -- the arguments, what the bodies derive from them and from the lane number -- would stay in registers across
+        //  the decode loop, which has none to spare)
+        const clx_pool_args* A = CLX_KERNARGS(clx_pool_args);
+        CLX_OPAQUE_PTR(A);
+        const uint32_t scan_w = (A->n_multi + 63u) / 64u, groups = (A->n_slots + 63u) / 64u;
+        const uint32_t n_scan = A->n_runs * scan_w, total = n_scan + A->n_runs * groups;
+        clx_pool_state* const ps = A->ps;
+        int lane = (int)threadIdx.x;
+        CLX_OPAQUE(lane);                                     // (nothing derived from the lane number is carried from ticket to ticket)
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(&ps->next, 1u);
+        t = clx_readlane(t, 0u);
+        if (t >= total) break;
+        if (A->order != nullptr) t = A->order[t];
+        if (t < n_scan) {
+            const uint32_t run = t / scan_w, w = t - run * scan_w;
+            cln_scan_wave(&L.ring[0][0], A->runs.r[run], A->frames, A->multi, A->n_multi, w, run, lane);
+#if CLN_POOL_FENCES
+            clx_release();                                    // (every lane's sf_start / errkey / fkey stores)
+#else
+            clx_stores_done();                                // (every lane's sf_start stores went past the caches and have arrived; errkey is atomics)
+#endif
+            if (threadIdx.x == 0) atomicAdd(&ps->scan_done[run], 1u);
+        } else {
+            const uint32_t u = t - n_scan, run = u / groups, g = u - run * groups;
+            bool ready = scan_w == 0u;
+#pragma unroll 1
+            for (uint32_t looks = 0; !ready && looks < CLN_POOL_SPIN; ++looks) {
+                ready = clx_readlane(clx_peek_u32(&ps->scan_done[run]), 0u) >= scan_w;
+                if (!ready) clx_pause();
+            }
+            if (ready) {
+#if CLN_POOL_FENCES
+                clx_acquire();
+#endif
+                cln_kernel<false>(L, A->runs.r[run], A->frames, A->n_slots, A->dump_all, g, run, lane);
+            }
+            else if (threadIdx.x == 0) atomicAdd(&ps->stuck, 1u);
+        }
+        clx_wave_sync();                                      // (the next ticket's ring and stage start from scratch: one wave, program order)
+    }
 }
 
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 void clx_k_lean24(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots, int32_t* __restrict__ dump_all) {
     __shared__ LeanLds L;
-    cln_kernel<true>(L, runs, frames, n_slots, dump_all);
+    cln_kernel<true>(L, runs.r[blockIdx.y], frames, n_slots, dump_all, blockIdx.x, blockIdx.y, (int)threadIdx.x);
 }

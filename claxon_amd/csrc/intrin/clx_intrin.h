@@ -152,6 +152,9 @@ __device__ __forceinline__ void clx_ms_pair4(const int32_t (&y)[4], int32_t (&ou
 __device__ __forceinline__ bool clx_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // The value of x as something the optimiser cannot see through (no instruction): keeps an expression in the shape written.
 #define CLX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define CLX_OPAQUE_PTR(p) asm volatile("" : "+s"(p))      // the same for a wave-uniform pointer
+// the kernel's argument block where the dispatch packet put it (a kernel whose only argument is one T by value): read-only, scalar loads
+#define CLX_KERNARGS(T) ((const T*)(const void*)__builtin_amdgcn_kernarg_segment_ptr())
 // Four 16-byte stores as ONE asm statement.  hipcc makes the next write of a register that a store of its own has read wait for
 // that store's COMPLETION (s_waitcnt vmcnt(0): a round trip to the L2) -- the hardware only needs the two wait states behind the
 // last store of the statement (the data is read when the store issues).  An asm store is not in hipcc's vmcnt bookkeeping: its
@@ -301,6 +304,14 @@ __device__ __forceinline__ void clx_wg_barrier() { asm volatile("s_waitcnt lgkmc
 // A value the code knows to be wave-uniform, moved to a scalar register: everything computed from it afterwards runs on
 // the scalar unit instead of taking VALU issue slots (K1 is VALU-issue bound).  The simulator checks the claim.
 __device__ __forceinline__ uint32_t clx_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// what waves of one kernel tell each other through global memory (clx_k_pool): a counter read past the caches, a pause between two
+// looks at it, and the fences on both sides of the hand-over (agent scope: gfx950 has an L2 per XCD)
+__device__ __forceinline__ uint32_t clx_peek_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void clx_poke_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void clx_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void clx_pause() { __builtin_amdgcn_s_sleep(32); }
+__device__ __forceinline__ void clx_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void clx_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // lane `idx` (wave-uniform) of v, as a scalar
 __device__ __forceinline__ uint32_t clx_readlane(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); }
 #endif

@@ -220,7 +220,12 @@ enum {
      * through the write path); whatever it leaves to the general kernels goes through a planar scratch per run in flight (as
      * large as the planar output: allocated on first use) and a narrowing pass over those frames only.  Failed frames' bytes are
      * unspecified, as the planar output's are.  Always the lane kernels, fused build. */
-    CLX_OUT_PCM16       = 1u << 13
+    CLX_OUT_PCM16       = 1u << 13,
+    /* Pipelined submissions of the fused lane build, another launch form (round 6; off by default: measured slower, DESIGN.md
+     * section 4.4): a merged launch's scan waves and 16-bit-tier decode waves as TICKETS taken off a counter by one grid of waves
+     * that stay resident (clx_k_pool) instead of two kernels of one workgroup per wave (clx_k_scan, clx_k_lean).  Bit-exact like the
+     * default.  (Batches whose waves are composed by content keep the two kernels anyway.) */
+    CLX_POOL            = 1u << 14
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32

@@ -110,3 +110,49 @@ def decode_runs(arenas, arena_len, descs, out_offs, verify_crc=False, fill=0, pa
                                   VP(*[r.ctypes.data for r in ress]), flags, first_gen & 0xffffffff)
     assert st == 0
     return list(zip(outs, ress))
+
+
+def decode_pool(arenas, arena_len, descs, out_offs, verify_crc=False, fill=0, path=0, order=None, workers=3):
+    """ONE merged launch of len(arenas) runs of one planned batch through clx_k_pool under simulation (sim_decode_frames_pool): every
+    run on its own scratch, the tickets taken in the order `order` gives (a permutation of range(tickets); None: as they come) by
+    `workers` workgroups.  Returns ([(out, results), ...], stuck) -- stuck: decode tickets that gave up waiting for their run's scan."""
+    descs = np.ascontiguousarray(descs, dtype=cx.FRAME_DESC_DTYPE)
+    out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+    n = descs.size
+    total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
+    keep, ptrs = [], []
+    for a in arenas:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        buf = np.zeros(a.size + 64, dtype=np.uint8)
+        base = (-buf.ctypes.data) % 16
+        al = buf[base:base + a.size]
+        al[:] = a
+        keep.append((buf, al)); ptrs.append(al.ctypes.data)
+    outs = [np.full(total, fill, dtype=np.int32) for _ in arenas]
+    ress = [np.zeros(n, dtype=cx.FRAME_RESULT_DTYPE) for _ in arenas]
+    k = len(arenas)
+    VP = C.c_void_p * k
+    flags = (cx.VERIFY_CRC16 if verify_crc else 0) | path
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+    stuck = C.c_uint32(0)
+    L = lib()
+    L.sim_decode_frames_pool.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_uint32, C.c_void_p]
+    st = L.sim_decode_frames_pool(VP(*ptrs), arena_len, k, descs.ctypes.data, n, VP(*[o.ctypes.data for o in outs]), out_offs.ctypes.data,
+                                  VP(*[r.ctypes.data for r in ress]), flags, order.ctypes.data if order is not None else None, workers, C.byref(stuck))
+    assert st == 0
+    return list(zip(outs, ress)), int(stuck.value)
+
+
+def pool_tickets(descs, n_runs):
+    """(scan tickets, decode tickets) of a merged launch of n_runs runs of the batch `descs` describe (clx_k_pool's numbering: every
+    run's scan waves first -- run-major --, then every run's groups of 64 slots)."""
+    descs = np.ascontiguousarray(descs, dtype=cx.FRAME_DESC_DTYPE)
+    slot = 0
+    for ch, a in zip(descs["n_channels"], descs["channel_assignment"]):
+        if a != cx.CH_INDEPENDENT and (slot & 1):
+            slot += 1
+        slot += int(ch)
+    n_multi = int(np.sum(descs["n_channels"] > 1))
+    return n_runs * ((n_multi + 63) // 64), n_runs * ((slot + 63) // 64)

@@ -14,11 +14,12 @@ import claxon_amd as cx
 
 
 @pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED,
-                                        cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL],
-                ids=["waves", "lanes", "lanes-fused", "lanes-general"])
+                                        cx.PATH_LANES | cx.LANES_FUSED | cx.POOL, cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL],
+                ids=["waves", "lanes", "lanes-fused", "lanes-fused-pool", "lanes-general"])
 def sim(request):
     """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip: split build, fused build with
-    the lean 16-bit tier clx_k_lean in front, fused build with the general kernels alone).  (Waves composed by content --
+    the lean 16-bit tier in front -- as the two kernels clx_k_scan + clx_k_lean, and as clx_k_pool's tickets (`-pool`, round 6: merged
+    launches with CLX_POOL) --, fused build with the general kernels alone).  (Waves composed by content --
     clx_k_compose, round 4 -- need windows of at least 64 stereo frames: test_sim_waves_composed_by_content below and the
     `lanes-composed` selection of the GPU suite, whose workloads are that large.)"""
     import simlib
@@ -418,3 +419,61 @@ def test_sim_mid_side_that_runs_away_is_left_to_the_general_kernels(oracle):
     bs = int(w.block_sizes[0])
     want = ref.reshape(-1, 2, bs).transpose(0, 2, 1).reshape(-1).astype(np.int16)
     assert np.all(np.asarray(res["status"]) == cx.OK) and np.array_equal(out[:want.size], want)
+
+
+def test_sim_pool_tickets_in_any_order(oracle):
+    """clx_k_pool (round 6): ONE merged launch of several runs whose scan waves and decode waves are tickets off one counter.  The
+    tickets are taken (a) as they come, (b) in a random order that still puts every run's scan tickets in front of its decode
+    tickets -- runs interleaved, groups out of order, several workers --, (c) in ANY order: a decode ticket taken before its run's scan
+    is over gives up waiting (nobody else runs in the simulator) and leaves its group to the general kernels behind the pool, which
+    must decode it all the same.  Every run decodes different damage of the same frames; all of it against the oracle."""
+    import simlib
+    simlib.build()
+    w = synth.concat("pool", [synth.config3(40), synth.config5_unique(34), synth.small_mixed(30), pc.giveup_workload(64)])
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
+    rng = np.random.default_rng(611)
+
+    def damaged(frac):
+        a = w.arena.copy()
+        for i in range(w.n):
+            if rng.uniform() >= frac:
+                continue
+            lo, hi = int(w.offs[i]) + int(descs["header_bytes"][i]), int(w.offs[i] + w.lens[i])
+            pos = int(rng.integers(8 * lo, 8 * hi))
+            a[pos >> 3] ^= (0x80 >> (pos & 7))
+        return a
+
+    arenas = [w.arena.copy(), damaged(0.4), damaged(0.2)]
+    n_scan, n_dec = simlib.pool_tickets(descs, len(arenas))
+    assert n_scan >= 6 and n_dec >= 12
+    scan_per_run = n_scan // len(arenas)
+    dec_per_run = n_dec // len(arenas)
+    # (b) a random interleaving of the runs' ticket streams, each stream = its scan tickets (shuffled) then its groups (shuffled)
+    streams = []
+    for r in range(len(arenas)):
+        sc = rng.permutation(np.arange(r * scan_per_run, (r + 1) * scan_per_run))
+        de = rng.permutation(np.arange(n_scan + r * dec_per_run, n_scan + (r + 1) * dec_per_run))
+        streams.append(list(sc) + list(de))
+    ordered = []
+    while any(streams):
+        r = int(rng.integers(0, len(streams)))
+        if streams[r]:
+            ordered.append(streams[r].pop(0))
+    orders = {"as they come": (None, 2), "runs interleaved": (np.array(ordered, dtype=np.uint32), 5),
+              "any order": (rng.permutation(n_scan + n_dec).astype(np.uint32), 4)}
+    refs = []
+    for a in arenas:
+        ref = np.full(int(w.pcm.size), 0x17171717, dtype=np.int32)
+        refs.append((ref, oracle.decode_batch(a[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, check_crc=True)))
+    for name, (order, workers) in orders.items():
+        runs, stuck = simlib.decode_pool(arenas, w.arena_len, descs, w.out_offs, verify_crc=True, fill=0x17171717,
+                                         path=cx.PATH_LANES | cx.LANES_FUSED | cx.NO_COMPOSE | cx.POOL, order=order, workers=workers)
+        assert (stuck > 0) == (name == "any order"), (name, stuck)
+        for (out, res), (ref, r) in zip(runs, refs):
+            assert np.array_equal(res["status"], r["statuses"]) and np.array_equal(res["msg"], r["msgs"]), name
+            ok = np.nonzero(res["status"] == cx.OK)[0]
+            assert np.array_equal(res["end_bit"][ok], r["end_bits"][ok]), name
+            for i in ok:
+                lo, hi = int(w.out_offs[i]), int(w.out_offs[i]) + int(w.channels[i]) * int(w.block_sizes[i])
+                assert np.array_equal(out[lo:hi], ref[lo:hi]), (name, int(i))
+        assert sum(int(np.sum(res["status"] != cx.OK)) for _, res in runs[1:]) >= 10

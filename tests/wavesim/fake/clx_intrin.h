@@ -51,6 +51,8 @@ static inline uint4 clx_buf_load16(const clx_buf& b, uint32_t byte_off) {     //
 #define clx_ms_pair4(y, out, sgn, nsg, one) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_pair_(__LINE__, (y)[q_], (sgn), (nsg), (one)); } while (0)
 #define clx_any(p) (wavesim::any_(__LINE__, (p) ? 1 : 0) != 0)
 #define CLX_OPAQUE(x) ((void)(x))
+#define CLX_OPAQUE_PTR(p) ((void)(p))
+#define CLX_KERNARGS(T) ((const T*)sim_kernargs)      // (sim_lib.cpp points it at the argument block of the kernel it launches)
 #define CLX_SCHED_BARRIER() ((void)0)
 static inline void clx_store4x16(int32_t* p0, int32_t* p1, int32_t* p2, int32_t* p3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
     *reinterpret_cast<int4*>(p0) = w0; *reinterpret_cast<int4*>(p1) = w1; *reinterpret_cast<int4*>(p2) = w2; *reinterpret_cast<int4*>(p3) = w3;
@@ -98,5 +100,11 @@ static inline uint32_t clx_uniform_(int line, uint32_t v) {
     return first;
 }
 #define clx_uniform(v) clx_uniform_(__LINE__, (v))
+static inline uint32_t clx_peek_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+static inline void clx_poke_u32(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+static inline void clx_stores_done() {}
+static inline void clx_pause() {}
+static inline void clx_release() {}
+static inline void clx_acquire() {}
 #define clx_readlane(v, idx) ((uint32_t)__shfl((uint32_t)(v), (int)(idx), 64))
 #endif

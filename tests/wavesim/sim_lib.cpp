@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 extern "C" { uint64_t sim_stats[64]; }
+static const void* sim_kernargs = nullptr;       // where CLX_KERNARGS finds the running kernel's argument block
 #define CLX_STAT(i, n) (sim_stats[i] += (uint64_t)(n))
+#define CLN_POOL_SPIN 3u        // (lanes run one at a time here: a scan that is not over when a decode ticket asks will not be over later)
 #include "clx_kernels.hip"
 #include "clx_lanes.hip"
 #include "clx_lean.hip"
@@ -52,25 +54,57 @@ struct SimLanes {
         }
         return true;
     }
-    // one run, as launch_pending / launch_lanes make it (clx_api.hip): a new generation number, the wrap handled as the library does
-    int run(const uint8_t* arena, size_t arena_len, int32_t* out, clx_frame_result* results) {
+    // the run that decodes `arena` into `out` with this set of scratch, as launch_pending makes it (clx_api.hip): a new generation
+    // number, the wrap handled as the library does
+    clx_run make_run(const uint8_t* arena, size_t arena_len, int32_t* out, clx_frame_result* results) {
         const uint64_t alloc_len = ((uint64_t)arena_len + 15ull) & ~15ull;
         if (++gen == 0u) {       // (the generation number wrapped: nothing stale may look current)
             std::fill(taken.begin(), taken.begin() + (n_slots + 63) / 64, 0u);      // (the marks; the list behind them is empty between runs)
             memset(crc_part.data(), 0, crc_part.size() * sizeof(clx_crc_part));
             gen = 1u;
         }
+        clx_run R;
+        memset(&R, 0, sizeof R);
+        R.arena = arena; R.alloc_len = alloc_len + 16; R.out = out; R.sf_start = sf_start.data();
+        R.errkey = errkey.data(); R.end_bits = endbits.data(); R.taken = lean ? taken.data() : nullptr;
+        R.results = results; R.gen = gen;
+        R.crc_part = crc_part.data(); R.crc_todo = crc_todo.data();
+        R.flags = ((flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u);
+        R.planar = (flags & CLX_OUT_PCM16) ? planar.data() : nullptr;
+        // the run's slot maps: the plan's, or its own when waves are composed by content (as the library does: clx_plan_windows)
+        R.slot_frame = slot_frame.data(); R.first_slot = first_slot.data(); R.fkey = n_windows ? fkey.data() : nullptr;
+        return R;
+    }
+    // the library's rule (launch_lanes): the scan and the 16-bit tier as clx_k_pool's tickets unless the waves are composed by content
+    bool pooled() const { return lean && (flags & CLX_POOL) && !(n_windows && n_multi); }
+    // one run by itself: a launch of one run
+    int run(const uint8_t* arena, size_t arena_len, int32_t* out, clx_frame_result* results) {
         clx_runs runs;
         memset(&runs, 0, sizeof runs);
-        runs.r[0].arena = arena; runs.r[0].alloc_len = alloc_len + 16; runs.r[0].out = out; runs.r[0].sf_start = sf_start.data();
-        runs.r[0].errkey = errkey.data(); runs.r[0].end_bits = endbits.data(); runs.r[0].taken = lean ? taken.data() : nullptr;
-        runs.r[0].results = results; runs.r[0].gen = gen;
-        runs.r[0].crc_part = crc_part.data(); runs.r[0].crc_todo = crc_todo.data();
-        runs.r[0].flags = ((flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u);
-        runs.r[0].planar = (flags & CLX_OUT_PCM16) ? planar.data() : nullptr;
-        // the run's slot maps: the plan's, or its own when waves are composed by content (as the library does: clx_plan_windows)
-        runs.r[0].slot_frame = slot_frame.data(); runs.r[0].first_slot = first_slot.data(); runs.r[0].fkey = n_windows ? fkey.data() : nullptr;
-        if (n_multi) {
+        runs.r[0] = make_run(arena, arena_len, out, results);
+        if (pooled()) {      // (tickets in their own order; two workgroups: the second finds the counter run out)
+            clx_pool_state ps;
+            memset(&ps, 0, sizeof ps);
+            clx_pool_args A;
+            memset(&A, 0, sizeof A);
+            A.runs = runs; A.frames = dev.data(); A.multi = multi.data(); A.ps = &ps; A.order = nullptr; A.dump_all = nullptr;
+            A.n_runs = 1u; A.n_slots = (uint32_t)n_slots; A.n_multi = (uint32_t)n_multi;
+            sim_kernargs = &A;
+            SIM_LAUNCH(clx_k_pool, 2, 64, A);
+            sim_kernargs = nullptr;
+            if (ps.stuck != 0u) return CLX_API_ERROR;
+            sim_stats[31] += 1;      // (launches through clx_k_pool)
+        }
+        return back(runs, true);
+    }
+    // what follows the pool's tickets, or the whole launch when there is no pool: `front_done`: the scan and clx_k_lean have run
+    int back(const clx_runs& runs, bool maybe_front_done) {
+        const bool front_done = maybe_front_done && pooled();
+        clx_frame_result* const results = runs.r[0].results;
+        const uint8_t* const arena = runs.r[0].arena;
+        int32_t* const out = runs.r[0].out;
+        const uint64_t alloc_len = runs.r[0].alloc_len - 16;
+        if (n_multi && !front_done) {
             if (flags & CLX_LANES_GENERAL) SIM_LAUNCH(clx_k_scan_general, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
             else SIM_LAUNCH(clx_k_scan, (n_multi + 63) / 64, 64, runs, dev.data(), multi.data(), (uint32_t)n_multi);
         }
@@ -97,7 +131,7 @@ struct SimLanes {
             }
             // the lean kernel first (it marks the groups it decodes with this run's generation number), unless the caller
             // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
-            if (lean) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
+            if (lean && !front_done) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
             for (size_t gi = 0; gi < (n_slots + 63) / 64; ++gi) sim_stats[52] += taken[gi] == runs.r[0].gen;
             if (lean) {     // the split tier on what is left (the library launches it when the batch holds frames of more than 16 bits)
                 uint64_t before = 0, after = 0;
@@ -110,7 +144,7 @@ struct SimLanes {
             // is long whenever it can be (a third of what is left: every workgroup takes several groups)
             size_t ggrid = (n_slots + 63) / 64;
             if (lean) {
-                SIM_LAUNCH(clx_k_left, (ggrid + 255) / 256, 256, runs, (uint32_t)ggrid, (uint32_t*)nullptr);
+                SIM_LAUNCH(clx_k_left, (ggrid + 255) / 256, 256, runs, (uint32_t)ggrid, (uint32_t*)nullptr, (uint32_t*)nullptr);
                 const uint32_t n_left = taken[ggrid];
                 sim_stats[49] += n_left;
                 if (n_left > ggrid) return CLX_API_ERROR;
@@ -151,6 +185,45 @@ extern "C" int sim_decode_frames_runs(const uint8_t* const* arenas, size_t arena
     L.gen = first_gen - 1u;
     for (size_t r = 0; r < n_runs; ++r) {
         const int st = L.run(arenas[r], arena_len, outs[r], results[r]);
+        if (st != CLX_OK) return st;
+    }
+    return CLX_OK;
+}
+
+// ONE merged launch of n_runs (<= CLX_MAX_MERGE) runs of one planned batch through clx_k_pool, every run on a scratch set of its own
+// (the flights of the library), the tickets taken in the order `order` gives (a permutation of [0, tickets); null: as they come) by
+// `workers` workgroups one after the other; then every run's kernels behind the pool.  stuck_out: decode tickets that gave up
+// waiting for their run's scan (taken before it in `order`: their groups must come out right all the same, through the general kernels).
+extern "C" int sim_decode_frames_pool(const uint8_t* const* arenas, size_t arena_len, size_t n_runs, const clx_frame_desc* frames, size_t n,
+                                      int32_t* const* outs, const uint64_t* out_offs, clx_frame_result* const* results, uint32_t flags,
+                                      const uint32_t* order, uint32_t workers, uint32_t* stuck_out) {
+    if (!(flags & CLX_PATH_LANES) || n_runs < 1 || n_runs > CLX_MAX_MERGE) return CLX_API_ERROR;
+    std::vector<SimLanes> L(n_runs);
+    clx_runs runs;
+    memset(&runs, 0, sizeof runs);
+    for (size_t r = 0; r < n_runs; ++r) {
+        if (!L[r].plan(frames, n, out_offs, arena_len, flags)) return CLX_API_ERROR;
+        L[r].gen = 40u + (uint32_t)r;
+        runs.r[r] = L[r].make_run(arenas[r], arena_len, outs[r], results[r]);
+    }
+    if (!L[0].pooled()) return CLX_API_ERROR;
+    clx_pool_state ps;
+    memset(&ps, 0, sizeof ps);
+    clx_pool_args A;
+    memset(&A, 0, sizeof A);
+    A.runs = runs; A.frames = L[0].dev.data(); A.multi = L[0].multi.data(); A.ps = &ps; A.order = order; A.dump_all = nullptr;
+    A.n_runs = (uint32_t)n_runs; A.n_slots = (uint32_t)L[0].n_slots; A.n_multi = (uint32_t)L[0].n_multi;
+    sim_kernargs = &A;
+    SIM_LAUNCH(clx_k_pool, workers ? workers : 1u, 64, A);
+    sim_kernargs = nullptr;
+    if (stuck_out) *stuck_out = ps.stuck;
+    const uint32_t scan_w = (uint32_t)((L[0].n_multi + 63) / 64);
+    for (size_t r = 0; r < n_runs; ++r) if (ps.scan_done[r] != scan_w) return CLX_API_ERROR;
+    for (size_t r = 0; r < n_runs; ++r) {
+        clx_runs one;
+        memset(&one, 0, sizeof one);
+        one.r[0] = runs.r[r];
+        const int st = L[r].back(one, true);
         if (st != CLX_OK) return st;
     }
     return CLX_OK;

@@ -12,7 +12,7 @@ ctx = cx.Context(0, wait_s=120)
 w = synth.config3(n)
 descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
 d_arena = torch.from_numpy(w.arena).cuda()
-b = ctx.plan(descs, w.out_offs, verify_crc=True)
+b = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.POOL if os.environ.get("POOL", "off") == "on" else 0)      # POOL=on: clx_k_pool's tickets
 depth = b.submit_depth
 outs = [torch.zeros(w.total_samples, dtype=torch.int32, device="cuda") for _ in range(depth)]
 arenas = [d_arena] + [d_arena.clone() for _ in range(depth - 1)]

@@ -48,3 +48,15 @@ print("# steady middle of the stretch (us from its start):")
 mid = [r for r in g if r[2] in big][len(g) // 3: len(g) // 3 + 36]
 for a, b, n, q, s, _, _ in mid:
     print("%-16s q%-3s s%-3s start %9.1f  end %9.1f  dur %7.1f" % (n, q, s, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3))
+if len(sys.argv) > 2 and sys.argv[2] == "all":
+    # every kernel of the LAST timed region (behind the stretch's last gap of more than 0.2 ms with nothing running)
+    cuts = [0]
+    hi = g[0][1]
+    for i, r in enumerate(g[1:], 1):
+        if r[0] - hi > 200_000: cuts.append(i)
+        hi = max(hi, r[1])
+    last = g[cuts[-1]:]
+    z = last[0][0]
+    print("# the last region, every kernel (us from its start):")
+    for a, b, n, q, s, _, _ in last:
+        print("%-20s q%-3s start %9.1f  end %9.1f  dur %7.1f" % (n, q, (a - z) / 1e3, (b - z) / 1e3, (b - a) / 1e3))
