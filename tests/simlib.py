@@ -36,7 +36,7 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         _lib.sim_decode_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+                                           C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
         _lib.sim_interleave.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     return _lib
 
@@ -76,10 +76,11 @@ def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_onl
     res = np.zeros(n, dtype=cx.FRAME_RESULT_DTYPE)
     nslots = C.c_uint64(0)
     sfd = np.zeros(int(descs["n_channels"].sum()) + n + 2, dtype=SF_DESC_DTYPE)
-    flags = (cx.VERIFY_CRC16 if verify_crc else 0) | (0x100 if k1_only else 0) | path
+    flags = (cx.VERIFY_CRC16 if verify_crc else 0) | path          # (the ABI's flags and nothing else: k1_only is an argument of its own)
     st = lib().sim_decode_frames(al.ctypes.data, arena_len, descs.ctypes.data, n, out.ctypes.data, out_offs.ctypes.data,
-                                 res.ctypes.data, flags, sfd.ctypes.data, C.byref(nslots))
-    assert st == 0
+                                 res.ctypes.data, flags, sfd.ctypes.data, C.byref(nslots), 1 if k1_only else 0)
+    if st != 0:
+        raise cx.ClaxonError(cx.API_ERROR, 0, "the simulator rejects this combination of flags (0x%x)" % flags)
     return out, res, sfd[:nslots.value]
 
 

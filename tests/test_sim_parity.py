@@ -13,15 +13,17 @@ from parity_util import SimBackend
 import claxon_amd as cx
 
 
-@pytest.fixture(scope="module", params=[cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT, cx.PATH_LANES | cx.LANES_FUSED,
-                                        cx.PATH_LANES | cx.LANES_FUSED | cx.POOL, cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL],
-                ids=["waves", "lanes", "lanes-fused", "lanes-fused-pool", "lanes-general"])
+@pytest.fixture(scope="module", params=[cx.PATH_WAVES | cx.K2_LATENCY, cx.PATH_WAVES | cx.K2_THROUGHPUT, cx.PATH_WAVES, cx.PATH_LANES | cx.LANES_SPLIT,
+                                        cx.PATH_LANES | cx.LANES_FUSED, cx.PATH_LANES | cx.LANES_FUSED | cx.LANES_GENERAL,
+                                        cx.PATH_LANES | cx.LANES_FUSED | cx.COMPOSE, cx.PATH_LANES | cx.LANES_FUSED | cx.POOL],
+                ids=["waves", "waves-1w", "waves-mixed", "lanes", "lanes-fused", "lanes-general", "lanes-composed", "lanes-fused-pool"])
 def sim(request):
-    """Both kernel paths: wave-per-frame (clx_kernels.hip) and lane-per-subframe (clx_lanes.hip: split build, fused build with
-    the lean 16-bit tier in front -- as the two kernels clx_k_scan + clx_k_lean, and as clx_k_pool's tickets (`-pool`, round 6: merged
-    launches with CLX_POOL) --, fused build with the general kernels alone).  (Waves composed by content --
-    clx_k_compose, round 4 -- need windows of at least 64 stereo frames: test_sim_waves_composed_by_content below and the
-    `lanes-composed` selection of the GPU suite, whose workloads are that large.)"""
+    """The GPU suite's six kernel selections under the same names and the same ABI flags (tests/test_gpu_parity.py; round 6: the
+    simulator takes CLX_K2_LATENCY / CLX_K2_THROUGHPUT as the library does) -- wave-per-frame with the multi-wave and the one-wave
+    predictor kernels, lane-per-subframe with the split and the fused decode kernels, the fused build with the lean tiers in front,
+    with the general kernels alone and with the waves composed by content -- and two of the simulator's own: `waves-mixed` (no K2 flag:
+    every predictor build gets its turn by the parity of the slot count) and `lanes-fused-pool` (the scan and the 16-bit tier as
+    clx_k_pool's tickets: merged launches with CLX_POOL)."""
     import simlib
     simlib.build()
     return SimBackend(request.param)
@@ -477,3 +479,21 @@ def test_sim_pool_tickets_in_any_order(oracle):
                 lo, hi = int(w.out_offs[i]), int(w.out_offs[i]) + int(w.channels[i]) * int(w.block_sizes[i])
                 assert np.array_equal(out[lo:hi], ref[lo:hi]), (name, int(i))
         assert sum(int(np.sum(res["status"] != cx.OK)) for _, res in runs[1:]) >= 10
+
+
+def test_sim_takes_the_abi_flags(oracle):
+    """Round 5's review: `SimBackend(cx.PATH_WAVES | cx.K2_LATENCY)` returned residuals as PCM -- the harness kept a private "stop after K1"
+    switch in the flag word, at CLX_K2_LATENCY's bit.  The simulator now takes the ABI's flags and nothing else (its switch is an
+    argument), picks the predictor build by them as the library does, and refuses what the ABI does not define."""
+    import simlib
+    simlib.build()
+    w = synth.small_mixed(40, seed_off=90517)
+    for flags in (cx.PATH_WAVES | cx.K2_LATENCY, cx.PATH_WAVES | cx.K2_THROUGHPUT):
+        pc.check_workload(oracle, SimBackend(flags), w)
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
+    for bad in (cx.PATH_WAVES | cx.K2_LATENCY | cx.K2_THROUGHPUT, cx.PATH_LANES | cx.LANES_FUSED | cx.K2_LATENCY):
+        with pytest.raises(cx.ClaxonError):
+            simlib.decode(w.arena, w.arena_len, descs, w.out_offs, path=bad)
+    # the harness's own switch still works, apart from the flags: residuals, not samples
+    out, res, sfd = simlib.decode(w.arena, w.arena_len, descs, w.out_offs, path=cx.PATH_WAVES | cx.K2_LATENCY, k1_only=True)
+    assert np.all(res["status"] == 0) and not np.array_equal(out, w.pcm) and sfd.size > 0

@@ -229,9 +229,16 @@ extern "C" int sim_decode_frames_pool(const uint8_t* const* arenas, size_t arena
     return CLX_OK;
 }
 
+// flags: the ABI's (claxon_hip.h) and nothing else.  stop_after_k1 (the harness's own switch -- a flag bit of its own until round 6,
+// where it collided with CLX_K2_LATENCY): residual inspection, the wave path only.
+// The wave path's predictor build: CLX_K2_LATENCY / CLX_K2_THROUGHPUT as the library takes them (launch_waves, clx_api.hip); with
+// neither, every build gets its turn by the parity of the slot count (the library would go by the batch's size).
 extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const clx_frame_desc* frames, size_t n,
                                  int32_t* out, const uint64_t* out_offs, clx_frame_result* results, uint32_t flags,
-                                 clx_sf_desc* sfd_out /* optional, n_slots entries */, uint64_t* n_slots_out) {
+                                 clx_sf_desc* sfd_out /* optional, n_slots entries */, uint64_t* n_slots_out, int stop_after_k1) {
+    if ((flags & CLX_K2_LATENCY) && (flags & CLX_K2_THROUGHPUT)) return CLX_API_ERROR;
+    if ((flags & (CLX_K2_LATENCY | CLX_K2_THROUGHPUT)) && (flags & CLX_PATH_LANES)) return CLX_API_ERROR;      // (a build of the WAVE path's predictor)
+    if (stop_after_k1 && (flags & CLX_PATH_LANES)) return CLX_API_ERROR;
     if (flags & CLX_PATH_LANES) {
         SimLanes L;
         if (!L.plan(frames, n, out_offs, arena_len, flags)) return CLX_API_ERROR;
@@ -248,10 +255,14 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
     SIM_LAUNCH(clx_k_residual, n, 64, arena, alloc_len, dev.data(), (uint32_t)n, out, sfd.data(), results);
     if (n_slots_out) *n_slots_out = n_slots;
     if (sfd_out) memcpy(sfd_out, sfd.data(), n_slots * sizeof(clx_sf_desc));
-    if (flags & 0x100u) return CLX_OK;     // stop after K1 (residual inspection)
+    if (stop_after_k1) return CLX_OK;      // (residual inspection)
     std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
-    // every build of K2 is exercised: the one-wave one for odd slot counts, the multi-wave ones for even ones
-    if (n_slots & 1) {
+    bool all_narrow_aligned = true;        // (the library's rule for what follows clx_k_predict16: batch_plan_)
+    for (size_t i = 0; i < n; ++i) all_narrow_aligned = all_narrow_aligned && frames[i].bps <= 16 && (frames[i].block_size & 3u) == 0u && (out_offs[i] & 3ull) == 0ull;
+    const bool one_wave = (flags & CLX_K2_THROUGHPUT) ? true : (flags & CLX_K2_LATENCY) ? false : (n_slots & 1) != 0;
+    const bool behind16_1w = (flags & CLX_K2_LATENCY) ? all_narrow_aligned : (n_slots & 2) != 0;
+    // (without a flag every build of K2 is exercised: the one-wave one for odd slot counts, the multi-wave ones for even ones)
+    if (one_wave) {
         SIM_LAUNCH(clx_k_predict_1w, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 0u);
         SIM_LAUNCH(clx_k_predict_1w_hi, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 0u);
     }
@@ -259,7 +270,7 @@ extern "C" int sim_decode_frames(const uint8_t* arena, size_t arena_len, const c
         // the fast kernel first; what it leaves goes to the general kernel, or (slot counts 2 mod 4) to the one-wave kernels
         // told to skip its groups -- the library does the latter when every frame is 16-bit and aligned
         SIM_LAUNCH(clx_k_predict16, (n_slots + 63) / 64, 256, out, sfd.data(), (uint32_t)n_slots, dump.data());
-        if (n_slots & 2) {
+        if (behind16_1w) {
             SIM_LAUNCH(clx_k_predict_1w, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 1u);
             SIM_LAUNCH(clx_k_predict_1w_hi, (n_slots + 63) / 64, 64, out, sfd.data(), (uint32_t)n_slots, dump.data(), 1u);
         }
