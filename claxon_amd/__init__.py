@@ -27,6 +27,7 @@ LANES_GENERAL = 1024        # the fused lane build without clx_k_lean (the 16-bi
 COMPOSE, NO_COMPOSE = 2048, 4096   # waves composed by content (clx_k_compose) forced on / off (default: by the descriptors)
 OUT_PCM16 = 8192            # planned batches: the output buffers hold interleaved little-endian 16-bit PCM, written by the decode itself
 POOL = 16384                # pipelined submissions: the scan and the 16-bit tier as clx_k_pool's tickets (round 6's other launch form; off by default)
+OUT_PCM24 = 32768           # the same with packed 24-bit samples (3 bytes each), written by the general lane kernels
 SUBMIT_DEPTH = 24           # CLX_SUBMIT_DEPTH: the most submissions a Batch keeps in flight (Batch.submit_depth: this batch's)
 
 

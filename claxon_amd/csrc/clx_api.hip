@@ -275,6 +275,12 @@ struct clx_batch {
     bool any_bps_le16 = false, any_bps_gt16 = false;     // which of clx_k_lean / clx_k_lean24 can find work at all
     uint64_t out_len = 0;            // samples the planar output spans (CLX_OUT_PCM16: the size of a flight's planar scratch)
     unsigned general_grid = 0;       // workgroups per run of the general lane kernels behind the tiers (clx_plan_general_grid)
+    uint64_t general_sure = 0;       // groups that the descriptors say the tiers leave
+    // narrow output (CLX_OUT_PCM16 / _PCM24): the general kernels decode a group into staging rows of their workgroup's own and narrow
+    // them themselves: `stage_groups` workgroups per run at most, rows of `stage_stride` samples; one allocation per stream the
+    // kernels are launched on (launches of one stream follow each other), made when the first such launch goes out
+    uint32_t stage_stride = 0; unsigned stage_groups = 0;
+    int32_t* d_stage[6 + 1] = {}; size_t stage_cap[6 + 1] = {};      // (kMaxStreams of them and one more: plain runs on the caller's stream)
     uint32_t* d_most_left = nullptr; // the longest list of groups the tiers left in any run so far (clx_k_left), and where the host
     uint32_t* h_most_left = nullptr; // finds a copy of it (pinned; read without waiting: it sizes later launches)
     uint32_t* h_most_left_dev = nullptr;     // the device's address of that copy (clx_k_left writes it)
@@ -308,7 +314,6 @@ struct clx_batch {
         uint32_t* d_sf_start = nullptr; uint32_t* d_errkey = nullptr; uint64_t* d_endbits = nullptr;   // lane kernels' scratch
         uint32_t* d_taken = nullptr; uint32_t gen = 0;     // groups clx_k_lean took (marked with the run's generation number, never cleared)
         clx_crc_part* d_crc_part = nullptr; uint32_t* d_crc_todo = nullptr;
-        int32_t* d_planar = nullptr;             // CLX_OUT_PCM16: planar scratch for what the general kernels decode (allocated on first use, every flight its own)
         uint32_t* d_slot_frame = nullptr; uint32_t* d_first_slot = nullptr; uint32_t* d_fkey = nullptr;   // the run's slot maps (its own when waves are composed)
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
         hipEvent_t ev_rice = nullptr, ev_side = nullptr;   // Rice stage done | the submission's kernels on side_stream done
@@ -437,6 +442,7 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
     for (int k = 0; k < clx_batch::kMaxStreams; ++k) {
         if (b->mstream[k]) { (void)hipStreamSynchronize(b->mstream[k]); (void)hipStreamDestroy(b->mstream[k]); }
         if (b->d_pool[k]) (void)hipFree(b->d_pool[k]);
+        if (b->d_stage[k]) (void)hipFree(b->d_stage[k]);
         if (b->m_in[k]) (void)hipEventDestroy(b->m_in[k]);
         for (auto& e : b->m_done[k]) if (e) (void)hipEventDestroy(e);
     }
@@ -455,9 +461,9 @@ extern "C" void clx_batch_destroy(clx_batch* b) {
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
         if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
         if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
-        if (F.d_planar) { (void)hipFree(F.d_planar); F.d_planar = nullptr; }
         if (i != 0 && F.d_fkey) { (void)hipFree(F.d_slot_frame); (void)hipFree(F.d_first_slot); (void)hipFree(F.d_fkey); }      // (its own maps)
     }
+    if (b->d_stage[clx_batch::kMaxStreams]) (void)hipFree(b->d_stage[clx_batch::kMaxStreams]);
     if (b->ev_up) { (void)hipEventSynchronize(b->ev_up); (void)hipEventDestroy(b->ev_up); }
     if (b->h_up) (void)hipHostFree(b->h_up);
     delete b;
@@ -490,7 +496,15 @@ int plan_lanes_data(clx_batch* b) {
     b->n_windows = clx_plan_windows(b->h_frames.data(), n, cmode, windows.data());
     b->any_bps_le16 = b->any_bps_gt16 = false;
     for (size_t i = 0; i < n; ++i) { if (b->h_frames[i].bps <= 16u) b->any_bps_le16 = true; else b->any_bps_gt16 = true; }
-    b->general_grid = clx_plan_general_grid(b->h_frames.data(), slot_frame.data(), b->n_slots);
+    b->general_grid = clx_plan_general_grid(b->h_frames.data(), slot_frame.data(), b->n_slots, b->flags, &b->general_sure);
+    {   // narrow output: the general kernels' staging rows (clx_lanes_group) -- as long as the batch's largest block, and per run as many
+        // groups' worth as the descriptors say are left for certain, twice, and sixteen: the workgroups loop over what is left
+        uint32_t bs_max = 1;
+        for (size_t i = 0; i < n; ++i) bs_max = std::max<uint32_t>(bs_max, b->h_frames[i].block_size);
+        b->stage_stride = (bs_max + 3u) & ~3u;
+        const uint64_t groups = (b->n_slots + 63) / 64;
+        b->stage_groups = (unsigned)std::min<uint64_t>(std::max<uint64_t>(groups, 1), 2 * b->general_sure + 16);
+    }
     if (!b->d_most_left && !hip_ok(ctx, hipMalloc((void**)&b->d_most_left, sizeof(uint32_t)), "hipMalloc most_left")) return CLX_API_ERROR;
     if (!b->h_most_left && !hip_ok(ctx, hipHostMalloc((void**)&b->h_most_left, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc most_left")) return CLX_API_ERROR;
     *b->h_most_left = 0u;
@@ -552,11 +566,13 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
             if (b->mstream[k] && !hip_ok(ctx, hipStreamSynchronize(b->mstream[k]), "hipStreamSynchronize")) return CLX_API_ERROR;
     }
     b->launch_failed = false;                  // (a new plan: nothing of it has been dropped)
-    if (flags & CLX_OUT_PCM16) {
-        // narrow output straight from the decode: <= 16-bit frames, the lane kernels' fused build with the tiers in front
-        if (flags & (CLX_PATH_WAVES | CLX_LANES_SPLIT | CLX_LANES_GENERAL)) { ctx->last_error = "CLX_OUT_PCM16 runs the fused lane kernels with the lean tier: not with CLX_PATH_WAVES / CLX_LANES_SPLIT / CLX_LANES_GENERAL"; return CLX_API_ERROR; }
+    if (flags & (CLX_OUT_PCM16 | CLX_OUT_PCM24)) {
+        // narrow output straight from the decode: <= 16-bit (24-bit) frames, the lane kernels' fused build with the tiers in front
+        const uint32_t wide = (flags & CLX_OUT_PCM24) ? 24u : 16u;
+        if ((flags & CLX_OUT_PCM16) && (flags & CLX_OUT_PCM24)) { ctx->last_error = "CLX_OUT_PCM16 and CLX_OUT_PCM24 exclude each other"; return CLX_API_ERROR; }
+        if (flags & (CLX_PATH_WAVES | CLX_LANES_SPLIT | CLX_LANES_GENERAL)) { ctx->last_error = "CLX_OUT_PCM16 / CLX_OUT_PCM24 run the fused lane kernels with the lean tier: not with CLX_PATH_WAVES / CLX_LANES_SPLIT / CLX_LANES_GENERAL"; return CLX_API_ERROR; }
         for (size_t i = 0; i < n; ++i)
-            if (frames[i].bps > 16) { ctx->last_error = "CLX_OUT_PCM16: frame " + std::to_string(i) + " has more than 16 bits per sample"; return CLX_API_ERROR; }
+            if (frames[i].bps > wide) { ctx->last_error = std::string(wide == 16u ? "CLX_OUT_PCM16" : "CLX_OUT_PCM24") + ": frame " + std::to_string(i) + " has more than " + std::to_string(wide) + " bits per sample"; return CLX_API_ERROR; }
         flags |= CLX_PATH_LANES | CLX_LANES_FUSED;
     }
     b->n = n; b->flags = flags;
@@ -610,7 +626,6 @@ int batch_plan_(clx_batch* b, const clx_frame_desc* frames, size_t n, const uint
         if (i != 0 && F.d_taken) (void)hipFree(F.d_taken);
         if (i != 0 && F.d_crc_part) (void)hipFree(F.d_crc_part);
         if (i != 0 && F.d_crc_todo) (void)hipFree(F.d_crc_todo);
-        if (F.d_planar) { (void)hipFree(F.d_planar); F.d_planar = nullptr; }
         if (i != 0 && F.d_fkey) { (void)hipFree(F.d_slot_frame); (void)hipFree(F.d_first_slot); (void)hipFree(F.d_fkey); }
         F.d_taken = nullptr; F.gen = 0; F.d_crc_part = nullptr; F.d_crc_todo = nullptr; F.d_slot_frame = nullptr; F.d_first_slot = nullptr; F.d_fkey = nullptr;
         if (i == 0) F.d_results = nullptr;
@@ -720,10 +735,11 @@ unsigned pool_waves(clx_batch* b) {
 // (clx_k_pool) when the batch's waves are not composed by content -- `pool` is the launch's stream's ticket counter, zeroed here in
 // front of the kernel.
 template <typename Mark>
-bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool split, hipStream_t stream, Mark&& mark, clx_pool_state* pool = nullptr) {
+bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool split, hipStream_t stream, Mark&& mark, clx_pool_state* pool = nullptr,
+                  int stage_slot = clx_batch::kMaxStreams) {
     const unsigned groups = (unsigned)((b->n_slots + 63) / 64);
     const bool composed = runs.r[0].fkey != nullptr && b->n_windows && b->n_multi;
-    const bool pooled = pool != nullptr && (b->flags & CLX_POOL) && !split && !composed && runs.r[0].taken != nullptr && b->any_bps_le16 && !(b->flags & CLX_LANES_GENERAL);
+    const bool pooled = pool != nullptr && (b->flags & CLX_POOL) && !(b->flags & CLX_OUT_PCM24) && !split && !composed && runs.r[0].taken != nullptr && b->any_bps_le16 && !(b->flags & CLX_LANES_GENERAL);
 #ifdef CLX_POOL_SCAN_APART      // (measurement builds: the scan as a kernel of its own in front of a pool of decode tickets only)
     if (pooled && b->n_multi) {
         if (!mark("clx_k_scan")) return false;
@@ -759,7 +775,8 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
             hipLaunchKernelGGL(clx_k_compose, dim3((unsigned)b->n_windows, n_runs), dim3(CLX_COMPOSE_THREADS), 0, stream, runs, (const clx_window*)b->d_windows);
         }
         // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them
-        if (runs.r[0].taken != nullptr && b->any_bps_le16 && !pooled) {
+        const bool tiers = !(b->flags & CLX_OUT_PCM24);       // (packed 24-bit output is the general kernels': the tiers would leave every group)
+        if (runs.r[0].taken != nullptr && b->any_bps_le16 && !pooled && tiers) {
             if (!mark("clx_k_lean")) return false;
             // CLX_LEAN_LDS_PAD (measurement builds only): extra dynamic LDS per wave, i.e. fewer decode waves per CU -- the knob behind
             // profiles/r05_occupancy_sweep.txt
@@ -773,7 +790,7 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
         }
         // the split tier for audio of more than 16 bits (launched when the batch holds such frames: it also takes <= 16-bit groups of
         // more than 12 taps that share the batch, which otherwise stay with clx_k_lanes_hi)
-        if (runs.r[0].taken != nullptr && b->any_bps_gt16) {
+        if (runs.r[0].taken != nullptr && b->any_bps_gt16 && tiers) {
             if (!mark("clx_k_lean24")) return false;
             hipLaunchKernelGGL(clx_k_lean24, dim3(groups, n_runs), dim3(64), 0, stream, runs,
                                (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
@@ -792,15 +809,27 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
                 ggrid = std::min(groups, std::max(b->general_grid, 2u * seen + 16u));
             }
         }
-        if (!mark("clx_k_lanes")) return false;             // (+ clx_k_lanes_hi, its order > 12 twin)
-        hipLaunchKernelGGL(clx_k_lanes, dim3(ggrid, n_runs), dim3(64), 0, stream, runs,
-                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
-        hipLaunchKernelGGL(clx_k_lanes_hi, dim3(ggrid, n_runs), dim3(64), 0, stream, runs,
-                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
-        if (b->flags & CLX_OUT_PCM16) {          // what the general kernels decoded into the planar scratch: narrowed into the output
-            if (!mark("clx_k_narrow_left")) return false;
-            hipLaunchKernelGGL(clx_k_narrow_left, dim3(ggrid, n_runs), dim3(256), 0, stream, runs, (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots);
+        // narrow output: every workgroup of the general kernels decodes into 64 staging rows of its own and narrows them itself
+        // (clx_lanes_group) -- the stream's staging, grown here when this launch needs more of it than any before
+        clx_runs gruns = runs;
+        if (b->flags & (CLX_OUT_PCM16 | CLX_OUT_PCM24)) {
+            ggrid = std::min(ggrid, std::max(b->stage_groups, 1u));
+            const size_t per_run = (size_t)ggrid * 64u * b->stage_stride, need = per_run * n_runs * sizeof(int32_t);
+            if (b->stage_cap[stage_slot] < need) {
+                if (b->d_stage[stage_slot]) { (void)hipFree(b->d_stage[stage_slot]); b->d_stage[stage_slot] = nullptr; b->stage_cap[stage_slot] = 0; }      // (waits for what uses it)
+                if (!hip_ok(b->ctx, hipMalloc((void**)&b->d_stage[stage_slot], need), "hipMalloc staging rows (narrow output)")) return false;
+                b->stage_cap[stage_slot] = need;
+            }
+            for (unsigned r = 0; r < n_runs; ++r) {
+                gruns.r[r].planar = b->d_stage[stage_slot] + per_run * r;
+                gruns.r[r].flags |= CLX_RUN_STAGE_BITS(b->stage_stride);
+            }
         }
+        if (!mark("clx_k_lanes")) return false;             // (+ clx_k_lanes_hi, its order > 12 twin)
+        hipLaunchKernelGGL(clx_k_lanes, dim3(ggrid, n_runs), dim3(64), 0, stream, gruns,
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
+        hipLaunchKernelGGL(clx_k_lanes_hi, dim3(ggrid, n_runs), dim3(64), 0, stream, gruns,
+                           (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);
     }
     else {
         if (n_runs != 1) return false;
@@ -820,12 +849,6 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
     }
     return true;
 }
-// CLX_OUT_PCM16: the flight's planar scratch (what the general kernels decode before clx_k_narrow_left narrows it), on first use
-int ensure_planar(clx_batch* b, clx_batch::Flight& F) {
-    if (!(b->flags & CLX_OUT_PCM16) || F.d_planar) return CLX_OK;
-    HIP_TRY(b->ctx, hipMalloc((void**)&F.d_planar, std::max<uint64_t>(b->out_len, 1) * sizeof(int32_t)));
-    return CLX_OK;
-}
 // the run that decodes (arena, arena_len) into `out` with a flight's scratch
 clx_run make_run(const clx_batch* b, const clx_batch::Flight& F, const uint8_t* d_arena, size_t arena_len, int32_t* d_out, bool lean) {
     clx_run R;
@@ -834,13 +857,13 @@ clx_run make_run(const clx_batch* b, const clx_batch::Flight& F, const uint8_t* 
     R.taken = (lean && !(b->flags & CLX_LANES_GENERAL)) ? F.d_taken : nullptr;
     R.results = F.d_results; R.gen = F.gen;
     R.crc_part = F.d_crc_part; R.crc_todo = F.d_crc_todo;
-    R.planar = F.d_planar;
+    R.planar = nullptr;                        // (narrow output: launch_lanes hands the general kernels their staging rows)
     // the run's slot maps: its own when its waves are composed by content (clx_k_compose rewrites the windows' parts), else the plan's
     const bool composed = lean && b->n_windows != 0 && F.d_fkey != nullptr;
     R.slot_frame = composed ? F.d_slot_frame : b->d_slot_frame;
     R.first_slot = composed ? F.d_first_slot : b->d_first_slot;
     R.fkey = composed ? F.d_fkey : nullptr;
-    R.flags = ((b->flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((b->flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u);
+    R.flags = ((b->flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((b->flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u) | ((b->flags & CLX_OUT_PCM24) ? CLX_RUN_PCM24 : 0u);
     return R;
 }
 void launch_stage1_waves(clx_batch* b, const uint8_t* d_arena, uint64_t alloc_len, int32_t* d_out, clx_sf_desc* d_sfd, clx_frame_result* d_results,
@@ -1011,7 +1034,7 @@ int launch_pending(clx_batch* b, bool inputs_ready) {
         if (name) b->kname[nk] = name;
         return hip_ok(ctx, hipEventRecord(b->ev[nk++], ms), "hipEventRecord");
     };
-    if (!(launch_lanes(b, runs, n_runs, false, ms, mark, b->d_pool[k]) && hipGetLastError() == hipSuccess)) return fail("kernel launch", hipSuccess);
+    if (!(launch_lanes(b, runs, n_runs, false, ms, mark, b->d_pool[k], k) && hipGetLastError() == hipSuccess)) return fail("kernel launch", hipSuccess);
     if (b->profile_merged) { if (!mark(nullptr)) return fail("hipEventRecord", hipSuccess); b->n_kernels = nk - 1; b->ev_valid = true; b->ev_runs = (int)n_runs; }
     LP_TRY(hipEventRecord(b->m_done[k][b->m_count[k] % clx_batch::kEvRing], ms));
 #undef LP_TRY
@@ -1077,7 +1100,6 @@ extern "C" int clx_batch_run(clx_batch* b, const uint8_t* d_arena, size_t arena_
         F0.d_results = b->d_results; F0.d_sf_start = b->d_sf_start; F0.d_errkey = b->d_errkey; F0.d_endbits = b->d_endbits; F0.d_taken = b->d_taken;
         F0.d_crc_part = b->d_crc_part; F0.d_crc_todo = b->d_crc_todo;
         F0.d_slot_frame = b->d_slot_frame_run; F0.d_first_slot = b->d_first_slot_run; F0.d_fkey = b->d_fkey;
-        if (ensure_planar(b, F0) != CLX_OK) return CLX_API_ERROR;
         if (++F0.gen == 0u) {
             HIP_TRY(ctx, hipMemsetAsync(b->d_taken, 0, (size_t)((b->n_slots + 63) / 64) * sizeof(uint32_t), stream));
             HIP_TRY(ctx, hipMemsetAsync(b->d_crc_part, 0, (size_t)std::max<uint64_t>(b->n_slots, 1) * sizeof(clx_crc_part), stream));
@@ -1210,7 +1232,6 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
                 F.d_sf_start = sfs;                      // (last: the sentinel)
             }
         }
-        if (ensure_planar(b, F) != CLX_OK) return CLX_API_ERROR;
         // what cannot share a launch with the pending submissions goes after them: another caller stream (the launch waits for
         // ONE stream's inputs), an output buffer one of them writes, a plan that has to be uploaded again (the arena's length)
         bool apart = !b->pend.empty() && b->pend_stream != stream;

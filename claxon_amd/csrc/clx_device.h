@@ -65,12 +65,16 @@ struct clx_run {
     uint32_t* fkey;          // scratch, per frame: the content class clx_k_scan found (clx_k_compose's sort key); null: no composition
     clx_crc_part* crc_part;  // scratch, per predictor slot: what the lean kernels' lanes found of their frame's CRC-16 (clx_crct.h)
     uint32_t* crc_todo;      // scratch, per frame: clx_k_finalize -> clx_k_crc16_runs: 1 = the stand-alone kernel has to check this frame
-    int32_t* planar;         // CLX_RUN_PCM16 only: planar i32 scratch (laid out as `out` is without the flag) for what the general kernels decode
+    int32_t* planar;         // narrow output only: the general kernels' staging rows for this run -- 64 rows of CLX_RUN_STAGE_STRIDE samples per workgroup
     uint32_t gen;
     uint32_t flags;          // CLX_RUN_CRC: the frames' CRC-16 is verified (the decode lanes gather it, clx_k_finalize judges it)
 };
 #define CLX_RUN_CRC 1u
 #define CLX_RUN_PCM16 2u     // `out` holds interleaved 16-bit PCM (claxon_hip.h: CLX_OUT_PCM16)
+#define CLX_RUN_PCM24 4u     // `out` holds interleaved packed 24-bit PCM (CLX_OUT_PCM24)
+// narrow output: bits 16..31 of the flags = the length of a staging row in units of four samples (>= the batch's largest block size)
+#define CLX_RUN_STAGE_STRIDE(flags) (((flags) >> 16) * 4u)
+#define CLX_RUN_STAGE_BITS(stride) ((((uint32_t)(stride) + 3u) / 4u) << 16)
 struct clx_runs { clx_run r[CLX_MAX_MERGE]; };       // passed to the kernels by value
 
 // clx_k_pool (clx_lean.hip): the scan waves and the 16-bit tier's decode waves of one merged launch as TICKETS that a grid of resident

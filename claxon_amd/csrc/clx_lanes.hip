@@ -1063,6 +1063,22 @@ __device__ __forceinline__ void clx_lanes_run(LaneReader r, Ring& g, uint32_t* r
     *err_out = S.r.err;
 }
 
+// Narrow output: this lane's staging row (channel `ch` of frame `fr`, n samples; n = 0: nothing) into the run's interleaved output --
+// sample t of channel c at byte (out_off + t * channels + c) * bytes of `out` (lib.rs:473-520's order), the low 2 or 3 bytes of every
+// sample, little-endian (as clx_k_interleave gives them).  A row is written by several lanes of the wave (the turns' transposing
+// stores): what they wrote is made visible to the lane that narrows it first.  Slow and simple: the odd group the tiers left.
+__device__ __forceinline__ void clx_narrow_row(const clx_run& R, const clx_dev_frame& fr, uint32_t ch, uint32_t n, const int32_t* row, uint32_t narrow) {
+    clx_group_fence();
+    const uint32_t sb = (narrow & CLX_RUN_PCM24) ? 3u : 2u, step = (uint32_t)fr.n_channels * sb;
+    uint8_t* d = reinterpret_cast<uint8_t*>(R.out) + (fr.out_off + (uint64_t)ch) * sb;
+#pragma unroll 1
+    for (uint32_t t = 0; t < n; ++t, d += step) {
+        const uint32_t v = (uint32_t)row[t];
+        if (sb == 2u) *reinterpret_cast<uint16_t*>(d) = (uint16_t)v;
+        else { d[0] = (uint8_t)v; d[1] = (uint8_t)(v >> 8); d[2] = (uint8_t)(v >> 16); }
+    }
+}
+
 // Two kernels: waves whose highest predictor order is <= 12, and the rest (the 32-tap predictor state would otherwise
 // cost every wave its occupancy: 256 VGPRs = one wave per SIMD).  Both are launched over all slots; a wave leaves at once
 // when its subframes belong to the other kernel.
@@ -1073,7 +1089,13 @@ __device__ __forceinline__ void clx_lanes_group(LanesLds& L, const clx_run& R, c
     const uint8_t* const arena = R.arena;
     const uint64_t arena_alloc_len = R.alloc_len;
     const uint32_t* const sf_start = R.sf_start;
-    int32_t* const out = (R.flags & CLX_RUN_PCM16) ? R.planar : R.out;       // (narrow output: planar scratch here, clx_k_narrow_left behind)
+    // Narrow output (CLX_OUT_PCM16 / _PCM24): the group is decoded into staging rows of this workgroup's own -- 64 rows of `stride`
+    // samples, re-used for every group the workgroup takes -- and every lane then narrows ITS row into the run's interleaved output
+    // (clx_narrow_row).  (Until round 6 every run in flight had a planar scratch as large as the planar output for this, and a
+    // kernel of its own behind: ADVICE r05.)
+    const uint32_t narrow = R.flags & (CLX_RUN_PCM16 | CLX_RUN_PCM24);
+    const uint32_t stride = CLX_RUN_STAGE_STRIDE(R.flags);
+    int32_t* const out = narrow ? R.planar + (size_t)blockIdx.x * 64u * stride : R.out;
     uint32_t* const errkey = R.errkey;
     uint64_t* const end_bits = R.end_bits;
     CLX_TL_BEGIN();
@@ -1125,7 +1147,7 @@ __device__ __forceinline__ void clx_lanes_group(LanesLds& L, const clx_run& R, c
         uint32_t a = __shfl_xor(nmax, s, 64); nmax = a > nmax ? a : nmax;
         uint32_t b = __shfl_xor(omax, s, 64); omax = b > omax ? b : omax;
     }
-    int32_t* const row = out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
+    int32_t* const row = narrow ? out + (size_t)lane * stride : out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
     const bool row_aligned = (((uintptr_t)row) & 15u) == 0u;
     uint32_t end_pos = r.pos, err = r.err;
     int32_t* const dump = dump_all + (size_t)slot * 16u;                   // 64 bytes per lane for stores that fall outside a row
@@ -1136,6 +1158,7 @@ __device__ __forceinline__ void clx_lanes_group(LanesLds& L, const clx_run& R, c
         else if (omax <= 8u)  clx_lanes_run<8>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err, out, dump);
         else                  clx_lanes_run<12>(r, g, L.ring[lane], L.stage[lane], h, bs, decor, pair_ok, row, row_aligned, nmax, omax, lane, &end_pos, &err, out, dump);
     }
+    if (narrow) clx_narrow_row(R, fr, ch, active ? bs : 0u, row, narrow);
     if (active) {
         if (err) clx_report_error(errkey, f, ch, err);
         else if (ch + 1u == fr.n_channels) end_bits[f] = (uint64_t)(end_pos - o);
@@ -1177,28 +1200,6 @@ void clx_k_left(const clx_runs runs, uint32_t n_groups, uint32_t* __restrict__ m
         //  later launches' grids.  Round 5 copied it back in the stream behind the general kernels: 0.1 ms per launch in front of
         //  clx_k_finalize, profiles/r06_pipelined_trace.txt)
         if (most_left != nullptr && atomicMax(most_left, i + 1u) < i + 1u && most_left_host != nullptr) *(volatile uint32_t*)most_left_host = i + 1u;
-    }
-}
-// Narrow output (CLX_OUT_PCM16): the frames of the groups the tiers left were decoded into the run's planar scratch; one workgroup per
-// listed group narrows them into the run's interleaved 16-bit output (the low 16 bits of every sample, as clx_k_interleave does).
-extern "C" __global__ __launch_bounds__(256)
-void clx_k_narrow_left(const clx_runs runs, const clx_dev_frame* __restrict__ frames, uint32_t n_slots) {
-    const clx_run& R = runs.r[blockIdx.y];
-    if (!(R.flags & CLX_RUN_PCM16) || R.taken == nullptr) return;
-    const uint32_t* const left = R.taken + (n_slots + 63u) / 64u;
-    const uint32_t n_left = left[0];
-    int16_t* const dst = reinterpret_cast<int16_t*>(R.out);
-    for (uint32_t i = blockIdx.x; i < n_left; i += gridDim.x) {
-        const uint32_t grp = left[1u + i];
-        for (uint32_t s = 64u * grp; s < 64u * grp + 64u && s < n_slots; ++s) {
-            const uint32_t f = R.slot_frame[s];
-            if (f == 0xffffffffu || R.first_slot[f] != s) continue;          // (a frame is narrowed where its first subframe's lane sits)
-            const clx_dev_frame fr = frames[f];
-            const uint32_t C = fr.n_channels, bs = fr.block_size;
-            const int32_t* __restrict__ src = R.planar + fr.out_off;
-            int16_t* __restrict__ d = dst + fr.out_off;
-            for (uint32_t k = threadIdx.x; k < C * bs; k += 256u) d[k] = (int16_t)src[(k % C) * bs + k / C];
-        }
     }
 }
 extern "C" __global__ __launch_bounds__(64)

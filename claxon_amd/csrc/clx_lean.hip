@@ -617,7 +617,8 @@ struct LMover {
     uint64_t base;             // wave-uniform
     uint32_t rowoff;           // this lane's row (bytes from `base`), or CLN_NO_ROW
     bool all_real;             // wave-uniform: every row of the wave exists
-    bool pcm16;                // wave-uniform: interleaved 16-bit output (CLX_RUN_PCM16): rowoff is the FRAME's place, the same in both lanes of its pair
+    uint32_t pcm16;            // wave-uniform: interleaved 16-bit output (CLX_RUN_PCM16) -- 1: stereo frames, rowoff is the FRAME's place, the same in
+                               // both lanes of its pair; 2: mono frames, every lane its own (round 6); 0: planar i32
 };
 #define CLN_NO_ROW 0xffffffffu
 // Narrow output (CLX_OUT_PCM16, round 5): the wave's rows are the two channels of 32 stereo frames (lanes 2F, 2F + 1), and a pair of tiles
@@ -645,8 +646,30 @@ __device__ __forceinline__ void cln_store_pcm16(const int4* stage0, const LMover
     }
     clx_wave_sync();
 }
+// The same for MONO frames (round 6): a pair of tiles holds 32 samples of every row -- 64 bytes of 16-bit PCM.  Four adjacent lanes write
+// one row's 64 bytes (lane q: samples 8q .. 8q + 7, i.e. pieces 2 (q & 1) and 2 (q & 1) + 1 of tile q >> 1, low halves packed), a store
+// instruction covers sixteen rows, four instructions the pair of tiles.
+__device__ __forceinline__ void cln_store_pcm16_mono(const int4* stage0, const LMover& M, uint32_t t0, int lane, uint32_t n_tiles) {
+    clx_wave_sync();
+    uint32_t ln = (uint32_t)lane;
+    CLX_OPAQUE(ln);                                                          // (as above: nothing of this is kept across the decode loop)
+    const uint32_t q = ln & 3u, t = q >> 1, p = 2u * (q & 1u);
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {
+        const uint32_t r = 16u * i + (ln >> 2);                              // the row whose 64 bytes this lane helps to write
+        const int4 a = stage0[t * 256u + ((r ^ t) * 4u) + (p ^ ((r >> 1) & 3u))];
+        const int4 b = stage0[t * 256u + ((r ^ t) * 4u) + ((p + 1u) ^ ((r >> 1) & 3u))];
+        const uint32_t o = (uint32_t)__shfl((int)M.rowoff, (int)r, 64);
+        int4 w;                                                              // (eight samples' low halves, in order)
+        w.x = (int32_t)clx_perm((uint32_t)a.y, (uint32_t)a.x, 0x05040100u); w.y = (int32_t)clx_perm((uint32_t)a.w, (uint32_t)a.z, 0x05040100u);
+        w.z = (int32_t)clx_perm((uint32_t)b.y, (uint32_t)b.x, 0x05040100u); w.w = (int32_t)clx_perm((uint32_t)b.w, (uint32_t)b.z, 0x05040100u);
+        if (o != CLN_NO_ROW && t < n_tiles) clx_store1x16_s(M.base, o + 2u * t0 + 16u * q, w);      // (a mono frame's sample t0 sits 2 t0 bytes into its block)
+    }
+    clx_wave_sync();
+}
 // the pair of tiles that starts at sample index t0 (a multiple of 32)
 __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
+    if (M.pcm16 == 2u) { cln_store_pcm16_mono(stage0, M, t0, lane, 2u); return; }
     if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 2u); return; }
     clx_wave_sync();
     const uint32_t h = (uint32_t)lane >> 3, q = (uint32_t)lane & 7u, t = q >> 2;
@@ -672,6 +695,7 @@ __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover&
 }
 // a lone tile 0 (the block's last 16 samples when the block size is an odd multiple of 16): 64 bytes x 16 rows per instruction
 __device__ __forceinline__ void cln_store_single(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
+    if (M.pcm16 == 2u) { cln_store_pcm16_mono(stage0, M, t0, lane, 1u); return; }
     if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 1u); return; }
     clx_wave_sync();
     const uint32_t h = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
@@ -731,25 +755,53 @@ __device__ __forceinline__ void cln_finish4(const int32_t (&s0)[4], const Finish
 // the same for the turn's sixteen samples at once, at the END of the turn (the 16-bit tier: its turn stays one basic block, the
 // wave-uniform choice of the stereo form is made once, and the asm statements of the stereo forms stay out of the compiler's way
 // while it schedules the Rice and predictor work)
+// EIGHT: eight samples per statement, class by class: the plain adds and shifts run at twice the rate in runs of their own kind
+// (clx_ms_short8, round 6).  Not in the 12-tap build, whose register file has no room for eight outputs beside eight inputs.
+template <bool EIGHT>
 __device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finish& F, int4* mine, uint32_t sw) {
+    if (!EIGHT) {
+        if (F.ms_plain) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
+                int32_t y[4];
+                clx_ms_short4(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
+                mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
+            }
+        } else if (F.any_decor || F.any_wasted) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
+                int32_t y[4];
+                clx_decor4_mad(m, y, F.mo, F.mt, F.mc);
+                mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mine[(uint32_t)b ^ sw] = make_int4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
+        }
+        return;
+    }
     if (F.ms_plain) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
-            int32_t y[4];
-            clx_ms_short4(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
-            mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
+        for (int h = 0; h < 2; ++h) {
+            const int32_t m[8] = { s[8 * h], s[8 * h + 1], s[8 * h + 2], s[8 * h + 3], s[8 * h + 4], s[8 * h + 5], s[8 * h + 6], s[8 * h + 7] };
+            int32_t y[8];
+            clx_ms_short8(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
+            mine[(uint32_t)(2 * h) ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
+            mine[(uint32_t)(2 * h + 1) ^ sw] = make_int4(y[4], y[5], y[6], y[7]);
         }
     } else if (F.any_decor || F.any_wasted) {
         // any mix of stereo forms and wasted bits in the wave (round 5: four instructions per sample, the shift included, where the
         // masked form took six and the shift a seventh).  Exact while a sample and its shifted value fit 24 bits: the turn's range
         // check, whose limit cln_run lowers by the lane's wasted bits
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
-            int32_t y[4];
-            clx_decor4_mad(m, y, F.mo, F.mt, F.mc);
-            mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
+        for (int h = 0; h < 2; ++h) {
+            const int32_t m[8] = { s[8 * h], s[8 * h + 1], s[8 * h + 2], s[8 * h + 3], s[8 * h + 4], s[8 * h + 5], s[8 * h + 6], s[8 * h + 7] };
+            int32_t y[8];
+            clx_decor8_mad(m, y, F.mo, F.mt, F.mc);
+            mine[(uint32_t)(2 * h) ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
+            mine[(uint32_t)(2 * h + 1) ^ sw] = make_int4(y[4], y[5], y[6], y[7]);
         }
     } else {
 #pragma unroll
@@ -921,7 +973,7 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
         // stereo decorrelation and the stage: the split tier four by four (its register file is full), the others at the end
         if (SPLIT) cln_finish4(S4, F, mine, sw, (uint32_t)b);
     }
-    if constexpr (!SPLIT) cln_finish16(S16, F, mine, sw);
+    if constexpr (!SPLIT) cln_finish16<(NP <= 4)>(S16, F, mine, sw);
     // what was decoded is what the stream holds iff no code was longer than its window register, the last window lay inside the
     // ring's filled part and nothing reached past the end of the frame; the predictor was exact iff the outputs (the next turn's
     // history) stayed inside the range
@@ -1271,13 +1323,17 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     }
     if (active) {
         good = fr.bps <= (SPLIT ? 24u : 16u) && bs == bs0 && (bs & 15u) == 0u && bs >= (SPLIT ? 64u : 32u) && (((uintptr_t)rowp) & 15u) == 0u && row_far < 0xffffffffull &&
-               (!pcm16 || (!SPLIT && fr.n_channels == 2u && ch == (slot & 1u))) &&       // (narrow output: stereo frames, channel c in lane parity c)
+               (!pcm16 || (!SPLIT && ((fr.n_channels == 2u && ch == (slot & 1u)) || fr.n_channels == 1u))) &&       // (narrow output: stereo frames, channel c in lane parity c -- or mono frames)
+               !(R.flags & CLX_RUN_PCM24) &&                     // (packed 24-bit output: the general kernels')
                r.pos <= r.limit && (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
         if (good) {
             h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
             good = !r.err && h.order <= (uint32_t)OMAX;    // (constant and verbatim subframes have order 0)
         }
     }
+    // (narrow output: one kind of frame per wave -- the movers write stereo lines or mono rows)
+    const uint32_t nch0 = (uint32_t)__shfl((int)(uint32_t)fr.n_channels, (int)__ffsll((long long)__ballot(active)) - 1, 64);
+    if (pcm16 && active && fr.n_channels != nch0) good = false;
     if (!__all(good)) {                                    // clx_k_lanes / clx_k_lanes_hi decode this group
         if (!SPLIT) {
             CLX_STAT(60, 1); CLX_STAT(61, active && (fr.bps > 16u || bs != bs0 || (bs & 15u) != 0u || bs < 32u)); CLX_STAT(62, active && r.err != 0u);
@@ -1335,7 +1391,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     M.base = ((uint64_t)clx_uniform((uint32_t)(row_lo >> 32)) << 32) | clx_uniform((uint32_t)row_lo);
     M.rowoff = active ? (uint32_t)((uint64_t)(uintptr_t)rowp - row_lo) : CLN_NO_ROW;
     M.all_real = __all(active);
-    M.pcm16 = pcm16;
+    M.pcm16 = !pcm16 ? 0u : nch0 == 1u ? 2u : 1u;
     (void)dump_all;                                         // (rows that do not exist are not written: no dump slots here)
     const Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
 

@@ -205,6 +205,47 @@ __device__ __forceinline__ void clx_ms_short4(const int32_t (&y)[4], int32_t (&o
                  : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
                  : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(sgn), "v"(c));
 }
+// The same for EIGHT samples, instruction class by instruction class (round 6): eight DPP reads, then the sixteen v_add / v_ashrrev in
+// a row, then eight DPP adds.  The plain VOP2 adds, subtractions and shifts issue at twice the rate of everything else -- but only in
+// runs of their own kind: tools/ubench/coissue.hip, profiles/r06_ubench_coissue.txt: 8 S + 8 F in runs of eight 60.7 cycles per wave
+// at 8 waves per SIMD and 74.6 / 77.9 at 2 / 3, alternating 74.2 and 108.9 / 99.2 -- the form above (a run of two) pays full price.
+__device__ __forceinline__ void clx_ms_short8(const int32_t (&y)[8], int32_t (&out)[8], uint32_t sgn, uint32_t c) {
+    asm volatile("s_nop 1\n\t"
+                 "v_xor_b32_dpp %0, %8, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %1, %9, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %2, %10, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %3, %11, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %4, %12, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %5, %13, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %6, %14, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_xor_b32_dpp %7, %15, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32 %0, %0, %17\n\t"
+                 "v_add_u32 %1, %1, %17\n\t"
+                 "v_add_u32 %2, %2, %17\n\t"
+                 "v_add_u32 %3, %3, %17\n\t"
+                 "v_add_u32 %4, %4, %17\n\t"
+                 "v_add_u32 %5, %5, %17\n\t"
+                 "v_add_u32 %6, %6, %17\n\t"
+                 "v_add_u32 %7, %7, %17\n\t"
+                 "v_ashrrev_i32 %0, 1, %0\n\t"
+                 "v_ashrrev_i32 %1, 1, %1\n\t"
+                 "v_ashrrev_i32 %2, 1, %2\n\t"
+                 "v_ashrrev_i32 %3, 1, %3\n\t"
+                 "v_ashrrev_i32 %4, 1, %4\n\t"
+                 "v_ashrrev_i32 %5, 1, %5\n\t"
+                 "v_ashrrev_i32 %6, 1, %6\n\t"
+                 "v_ashrrev_i32 %7, 1, %7\n\t"
+                 "v_add_u32_dpp %0, %8, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %1, %9, %1 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %2, %10, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %3, %11, %3 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %4, %12, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %5, %13, %5 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %6, %14, %6 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %7, %15, %7 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(sgn), "v"(c));
+}
 // v_ffbh_u32 as it comes: the number of leading zeros, 0xffffffff for 0 (__clz adds a v_min for that case; __builtin_clz leaves it
 // undefined).  Not volatile: the compiler schedules it like any other instruction.
 __device__ __forceinline__ uint32_t clx_ffbh(uint32_t x) {
@@ -242,6 +283,45 @@ __device__ __forceinline__ void clx_decor4_mad(const int32_t (&y)[4], int32_t (&
                  "v_ashrrev_i32 %3, 1, %3"
                  : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
                  : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(mo), "v"(mt), "v"(c));
+}
+// The same for eight samples, class by class (clx_ms_short8): the eight v_ashrrev in a row.  (own * mo + other * mt + c = other * mt + c, then
+// + own * mo: the partner's value lands in the output register, no temporary.)
+__device__ __forceinline__ void clx_decor8_mad(const int32_t (&y)[8], int32_t (&out)[8], int32_t mo, int32_t mt, int32_t c) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %2, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %3, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %4, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %5, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %6, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %7, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mad_i32_i24 %0, %0, %17, %18\n\t"
+                 "v_mad_i32_i24 %1, %1, %17, %18\n\t"
+                 "v_mad_i32_i24 %2, %2, %17, %18\n\t"
+                 "v_mad_i32_i24 %3, %3, %17, %18\n\t"
+                 "v_mad_i32_i24 %4, %4, %17, %18\n\t"
+                 "v_mad_i32_i24 %5, %5, %17, %18\n\t"
+                 "v_mad_i32_i24 %6, %6, %17, %18\n\t"
+                 "v_mad_i32_i24 %7, %7, %17, %18\n\t"
+                 "v_mad_i32_i24 %0, %8, %16, %0\n\t"
+                 "v_mad_i32_i24 %1, %9, %16, %1\n\t"
+                 "v_mad_i32_i24 %2, %10, %16, %2\n\t"
+                 "v_mad_i32_i24 %3, %11, %16, %3\n\t"
+                 "v_mad_i32_i24 %4, %12, %16, %4\n\t"
+                 "v_mad_i32_i24 %5, %13, %16, %5\n\t"
+                 "v_mad_i32_i24 %6, %14, %16, %6\n\t"
+                 "v_mad_i32_i24 %7, %15, %16, %7\n\t"
+                 "v_ashrrev_i32 %0, 1, %0\n\t"
+                 "v_ashrrev_i32 %1, 1, %1\n\t"
+                 "v_ashrrev_i32 %2, 1, %2\n\t"
+                 "v_ashrrev_i32 %3, 1, %3\n\t"
+                 "v_ashrrev_i32 %4, 1, %4\n\t"
+                 "v_ashrrev_i32 %5, 1, %5\n\t"
+                 "v_ashrrev_i32 %6, 1, %6\n\t"
+                 "v_ashrrev_i32 %7, 1, %7"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(mo), "v"(mt), "v"(c));
 }
 // Any stereo decorrelation (frame.rs:319-389) of four samples, or none, by per-lane constants: in a pair of lanes (channel 0 in the
 // even one) the value that is added or subtracted is always the odd lane's and the value it is applied to the even lane's, so
@@ -309,6 +389,10 @@ __device__ __forceinline__ uint32_t clx_uniform(uint32_t v) { return (uint32_t)_
 __device__ __forceinline__ uint32_t clx_peek_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void clx_poke_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void clx_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// what the lanes of ONE wave (a one-wave workgroup) wrote to global memory for each other: made visible before it is read
+__device__ __forceinline__ void clx_group_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ void clx_pause() { __builtin_amdgcn_s_sleep(32); }
 __device__ __forceinline__ void clx_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 __device__ __forceinline__ void clx_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }

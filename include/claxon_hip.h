@@ -217,15 +217,21 @@ enum {
      * offsets (frame i's block starts at int16 index out_sample_offsets[i]; sample t of channel c at + t * n_channels + c), each
      * sample's low 16 bits as clx_batch_interleave(.., 2) gives them.  Every frame must have at most 16 bits per sample.  The
      * lean decode kernel writes a stereo frame's 32 samples as one 128-byte line from the tiles it stages anyway (half the bytes
-     * through the write path); whatever it leaves to the general kernels goes through a planar scratch per run in flight (as
-     * large as the planar output: allocated on first use) and a narrowing pass over those frames only.  Failed frames' bytes are
-     * unspecified, as the planar output's are.  Always the lane kernels, fused build. */
+     * through the write path), and a mono frame's as 64 bytes (round 6); whatever it leaves -- more channels, odd block sizes, waves that
+     * give up -- the general kernels decode into staging rows of their workgroup's own and narrow row by row (one allocation per
+     * internal stream, sized by what the descriptors say is left: round 5's planar scratch per run in flight is gone).  Failed frames'
+     * bytes are unspecified, as the planar output's are.  Always the lane kernels, fused build. */
     CLX_OUT_PCM16       = 1u << 13,
     /* Pipelined submissions of the fused lane build, another launch form (round 6; off by default: measured slower, DESIGN.md
      * section 4.4): a merged launch's scan waves and 16-bit-tier decode waves as TICKETS taken off a counter by one grid of waves
      * that stay resident (clx_k_pool) instead of two kernels of one workgroup per wave (clx_k_scan, clx_k_lean).  Bit-exact like the
      * default.  (Batches whose waves are composed by content keep the two kernels anyway.) */
-    CLX_POOL            = 1u << 14
+    CLX_POOL            = 1u << 14,
+    /* The same as CLX_OUT_PCM16 with packed little-endian 24-bit samples (3 bytes each; round 6): `d_out` points to bytes, frame i's
+     * block starts at byte 3 * out_sample_offsets[i], sample t of channel c at + 3 * (t * n_channels + c): what clx_batch_interleave(.., 3)
+     * gives.  Every frame must have at most 24 bits per sample.  Written by the general lane kernels (the lean tiers write planar i32
+     * and 16-bit PCM only): correct for every shape, at the general kernels' speed. */
+    CLX_OUT_PCM24       = 1u << 15
 };
 
 /* One-shot convenience: plan + run + fetch results.  `out` is planar i32

@@ -664,8 +664,9 @@ def crc_share_workload(seed=9090):
 def pcm16_workload():
     """What the narrow output (CLX_OUT_PCM16) has to get right: stereo frames the lean kernel writes as whole interleaved lines, of every
     channel assignment, with constant / verbatim subframes riding along, block sizes that are odd multiples of 16 (a lone last tile) and
-    16 mod 32; waves that give their group up (the general kernels decode into the planar scratch, clx_k_narrow_left narrows it); mono
-    and three-channel frames and blocks that are no multiple of 16 (never the lean kernel's: the same way round)."""
+    16 mod 32; waves that give their group up (the general kernels decode into staging rows and narrow them themselves: clx_narrow_row); waves of
+    mono frames (the lean kernel's since round 6: 64-byte rows); three-channel frames and blocks that are no multiple of 16 (never the
+    lean kernel's: the general kernels' way)."""
     S = synth
     rng = np.random.default_rng(606)
     parts = [lean_workload(), giveup_workload(128), S.config5_unique(96)]
@@ -707,6 +708,41 @@ def check_pcm16(oracle, backend, w, damage=0.0, seed=1):
         a, c, bs = int(w.out_offs[i]), int(w.channels[i]), int(w.block_sizes[i])
         want = ref[a:a + c * bs].reshape(c, bs).T.reshape(-1).astype(np.int16)
         assert np.array_equal(out[a:a + c * bs], want), "frame %d (%d ch, bs %d)" % (int(i), c, bs)
+    return int(ok.size)
+
+
+def pcm24_workload():
+    """What the packed 24-bit output (CLX_OUT_PCM24, round 6) has to get right -- every frame goes through the general kernels' staging
+    rows and clx_narrow_row: 24-bit stereo frames of every channel assignment and 32 taps (config 4's), 16-bit frames in the same
+    batch, mono and three-channel frames, blocks that are no multiple of 16, wasted bits."""
+    S = synth
+    return S.concat("pcm24", [S.config4(48), S.config5_unique(40), S.small_mixed(60), lean24_workload()])
+
+
+def check_pcm24(oracle, backend, w, damage=0.0, seed=1):
+    """The packed 24-bit output against the oracle: every OK frame's bytes are the interleaved low 24 bits of the oracle's samples, little
+    endian, from byte 3 * out_offs[i]; statuses, messages and end bits as in planar mode.  `backend.path` must carry cx.OUT_PCM24."""
+    rng = np.random.default_rng(seed)
+    arena = w.arena.copy()
+    descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
+    for i in range(w.n):
+        if rng.uniform() < damage:
+            lo, hi = int(w.offs[i]) + int(descs["header_bytes"][i]), int(w.offs[i] + w.lens[i])
+            pos = int(rng.integers(8 * lo, 8 * hi))
+            arena[pos >> 3] ^= (0x80 >> (pos & 7))
+    out, res = backend.decode(arena, w.arena_len, descs, w.out_offs, True, fill=0x11)
+    ref = np.zeros(w.pcm.size, dtype=np.int32)
+    r = oracle.decode_batch(arena[:w.arena_len], w.offs, w.lens, out=ref, out_offs=w.out_offs, check_crc=True)
+    st, ms = np.asarray(res["status"]), np.asarray(res["msg"])
+    assert np.array_equal(st, r["statuses"]) and np.array_equal(ms, r["msgs"])
+    ok = np.nonzero(st == cx.OK)[0]
+    assert np.array_equal(np.asarray(res["end_bit"])[ok], r["end_bits"][ok])
+    out = np.asarray(out).view(np.uint8)
+    for i in ok:
+        a, c, bs = int(w.out_offs[i]), int(w.channels[i]), int(w.block_sizes[i])
+        v = ref[a:a + c * bs].reshape(c, bs).T.reshape(-1).astype(np.int32).view(np.uint32)
+        want = np.stack([v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff], axis=1).astype(np.uint8).reshape(-1)
+        assert np.array_equal(out[3 * a:3 * (a + c * bs)], want), "frame %d (%d ch, bs %d)" % (int(i), c, bs)
     return int(ok.size)
 
 

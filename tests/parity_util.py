@@ -42,7 +42,10 @@ class GpuBackend:
         total = int((out_offs + descs["n_channels"].astype(np.uint64) *
                      descs["block_size"].astype(np.uint64)).max()) if n else 0
         d_arena = torch.from_numpy(np.ascontiguousarray(arena)).to("cuda:0")
-        if self.path & cx.OUT_PCM16:     # (narrow output: the buffer holds interleaved 16-bit PCM at the same sample offsets)
+        if self.path & cx.OUT_PCM24:     # (packed 24-bit PCM: bytes, frame i's block from byte 3 * out_offs[i])
+            d_out = torch.full((3 * max(total, 1) + 16,), int(fill) & 0xff, dtype=torch.uint8, device="cuda:0")
+            total *= 3
+        elif self.path & cx.OUT_PCM16:   # (narrow output: the buffer holds interleaved 16-bit PCM at the same sample offsets)
             d_out = torch.full((max(total, 1) + 8,), int(fill) & 0x7fff, dtype=torch.int16, device="cuda:0")
         else:
             d_out = torch.full((max(total, 1),), int(np.int32(fill)), dtype=torch.int32, device="cuda:0")

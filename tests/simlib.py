@@ -72,7 +72,10 @@ def decode(arena, arena_len, descs, out_offs, out=None, verify_crc=False, k1_onl
     n = descs.size
     total = int((out_offs + descs["n_channels"].astype(np.uint64) * descs["block_size"].astype(np.uint64)).max()) if n else 0
     if out is None:
-        out = np.full(total + 8, fill & 0x7fff, dtype=np.int16)[:total] if (path & cx.OUT_PCM16) else np.full(total, fill, dtype=np.int32)
+        if path & cx.OUT_PCM24:          # (packed 24-bit PCM: bytes, frame i's block from byte 3 * out_offs[i])
+            out = np.full(3 * total + 16, fill & 0xff, dtype=np.uint8)[:3 * total]
+        else:
+            out = np.full(total + 8, fill & 0x7fff, dtype=np.int16)[:total] if (path & cx.OUT_PCM16) else np.full(total, fill, dtype=np.int32)
     res = np.zeros(n, dtype=cx.FRAME_RESULT_DTYPE)
     nslots = C.c_uint64(0)
     sfd = np.zeros(int(descs["n_channels"].sum()) + n + 2, dtype=SF_DESC_DTYPE)

@@ -183,8 +183,8 @@ def test_narrow_output_parity_on_the_gpu(oracle):
 @pytest.mark.gpu
 def test_narrow_output_pipelined_at_scale(oracle):
     """4 096 config-3 frames + the give-up workload through pipelined submissions with CLX_OUT_PCM16 (merged launches; the groups that
-    are given up go through the planar scratch of their flight and clx_k_narrow_left with the SMALL grid): every output buffer
-    holds the interleaved low 16 bits of the source PCM."""
+    are given up go through the general kernels' staging rows -- one allocation per internal stream since round 6, not a planar scratch
+    per flight -- with the SMALL grid): every output buffer holds the interleaved low 16 bits of the source PCM."""
     import torch
     ctx = cx.Context(0, wait_s=120)
     w = synth.concat("pcm16 at scale", [synth.config3(4096), pc.giveup_workload(1024)])
@@ -208,4 +208,40 @@ def test_narrow_output_pipelined_at_scale(oracle):
     d_want = torch.from_numpy(want).to("cuda:0")
     for k, o in enumerate(outs):
         assert bool(torch.equal(o[:w.pcm.size], d_want)), "output buffer %d" % k
+    batch.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_packed_24_bit_output_on_the_gpu(oracle):
+    """CLX_OUT_PCM24 (round 6) on the GPU: parity_cases.pcm24_workload one run at a time, intact and damaged, and pipelined (merged
+    launches: several runs' staging rows side by side in the stream's allocation) -- every OK frame's bytes against the oracle."""
+    import torch
+    from parity_util import GpuBackend
+    ctx = cx.Context(0, wait_s=120)
+    w = pc.pcm24_workload()
+    assert pc.check_pcm24(oracle, GpuBackend(ctx, cx.OUT_PCM24), w) == w.n
+    assert pc.check_pcm24(oracle, GpuBackend(ctx, cx.OUT_PCM24), w, damage=0.2, seed=5) < w.n
+    descs = pc.workload_descs(w)
+    d_arena = torch.from_numpy(w.arena).to("cuda:0")
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.OUT_PCM24)
+    outs = [torch.full((3 * w.pcm.size + 16,), 0x11, dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(batch.submit_depth + 3):
+        batch.submit(d_arena.data_ptr(), w.arena_len, outs[i % 4].data_ptr(), st)
+    batch.flush(st)
+    torch.cuda.synchronize()
+    assert np.all(batch.results()["status"] == cx.OK)
+    v = np.zeros(w.pcm.size, dtype=np.int32)
+    for i in range(w.n):
+        a, c, bs = int(w.out_offs[i]), int(w.channels[i]), int(w.block_sizes[i])
+        v[a:a + c * bs] = w.pcm[a:a + c * bs].reshape(c, bs).T.reshape(-1)
+    u = v.view(np.uint32)
+    want = torch.from_numpy(np.stack([u & 0xff, (u >> 8) & 0xff, (u >> 16) & 0xff], axis=1).astype(np.uint8).reshape(-1)).to("cuda:0")
+    covered = np.zeros(3 * w.pcm.size, dtype=bool)
+    for i in range(w.n):
+        a, c, bs = int(w.out_offs[i]), int(w.channels[i]), int(w.block_sizes[i])
+        covered[3 * a:3 * (a + c * bs)] = True
+    d_cov = torch.from_numpy(covered).to("cuda:0")
+    for k, o in enumerate(outs):
+        assert bool(torch.equal(o[:3 * w.pcm.size][d_cov], want[d_cov])), "output buffer %d" % k
     batch.close(); ctx.close()

@@ -497,3 +497,41 @@ def test_sim_takes_the_abi_flags(oracle):
     # the harness's own switch still works, apart from the flags: residuals, not samples
     out, res, sfd = simlib.decode(w.arena, w.arena_len, descs, w.out_offs, path=cx.PATH_WAVES | cx.K2_LATENCY, k1_only=True)
     assert np.all(res["status"] == 0) and not np.array_equal(out, w.pcm) and sfd.size > 0
+
+
+def test_sim_packed_24_bit_output(oracle):
+    """CLX_OUT_PCM24 (round 6): packed little-endian 24-bit PCM straight from the decode -- every group through the general kernels, which
+    decode into staging rows of their workgroup's own and narrow every row themselves (clx_narrow_row; also what CLX_OUT_PCM16 does with
+    the groups the lean kernel leaves).  Every frame's bytes against the oracle, intact and with a fifth of the frames damaged."""
+    import simlib
+    simlib.build()
+    w = pc.pcm24_workload()
+    assert pc.check_pcm24(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM24), w) == w.n
+    assert pc.check_pcm24(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM24), w, damage=0.2, seed=5) < w.n
+
+
+def test_sim_narrow_output_of_mono_frames(oracle):
+    """CLX_OUT_PCM16, waves of MONO frames (round 6): the lean kernel's own -- 64 bytes of 16-bit PCM per row and pair of tiles, four lanes
+    to a row (cln_store_pcm16_mono) -- with block sizes that end in a lone tile and frames that fail."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    S = synth
+    rng = np.random.default_rng(77)
+    parts = []
+    for bs, n in ((4096, 70), (1024 + 16, 64), (64, 64)):
+        t = np.arange(bs)
+        pcm = np.empty((n, 1, bs), dtype=np.int32)
+        for i in range(n):
+            pcm[i, 0] = np.clip(np.round(4000.0 * np.sin(2 * np.pi * (50 + 11 * i) * t / 44100.0) + rng.normal(0, 6.0, bs)), -32768, 32767)
+        fp = [S.FrameParams() for _ in range(n)]
+        for i, f in enumerate(fp):
+            f.sf[0] = S.sf(S.SF_LPC if i % 3 else S.SF_FIXED, order=8 if i % 3 else 2, precision=12, partition_order=min(3, max(0, int(np.log2(bs)) - 5)))
+        parts.append(S.encode_frames("mono bs%d" % bs, pcm, 1, bs, 16, fp))
+    w = S.concat("mono pcm16", parts)
+    for i in range(64):
+        stats[i] = 0
+    assert pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w) == w.n
+    assert stats[52] >= 2 and stats[49] <= 2, (int(stats[52]), int(stats[49]))      # groups the lean kernel wrote itself | groups left (where block sizes meet)
+    assert pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w, damage=0.25, seed=9) < w.n

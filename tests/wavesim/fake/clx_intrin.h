@@ -66,6 +66,7 @@ static inline int32_t clx_ms_short_(int line, int32_t y, uint32_t sgn, uint32_t 
     const uint32_t mid = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xA0, 0xF, 0xF, false);
     return (int32_t)(mid + (uint32_t)((int32_t)((side ^ sgn) + c) >> 1));
 }
+#define clx_ms_short8(y, out, sgn, c) do { for (int q_ = 0; q_ < 8; ++q_) (out)[q_] = clx_ms_short_(__LINE__, (y)[q_], (sgn), (c)); } while (0)
 #define clx_ms_short4(y, out, sgn, c) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_short_(__LINE__, (y)[q_], (sgn), (c)); } while (0)
 static inline uint32_t clx_ffbh(uint32_t x) { return x ? (uint32_t)__builtin_clz(x) : 0xffffffffu; }
 static inline int32_t clx_mad24_(int32_t a, int32_t b, int32_t c) {      // v_mad_i32_i24: the low 24 bits of a and b, sign-extended
@@ -76,6 +77,7 @@ static inline int32_t clx_decor_mad_(int line, int32_t y, int32_t mo, int32_t mt
     const int32_t other = wavesim::update_dpp_(line, 0, y, 0xB1, 0xF, 0xF, false);                // quad_perm [1,0,3,2]
     return clx_mad24_(other, mt, clx_mad24_(y, mo, c)) >> 1;
 }
+#define clx_decor8_mad(y, out, mo, mt, c) do { for (int q_ = 0; q_ < 8; ++q_) (out)[q_] = clx_decor_mad_(__LINE__, (y)[q_], (mo), (mt), (c)); } while (0)
 #define clx_decor4_mad(y, out, mo, mt, c) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_decor_mad_(__LINE__, (y)[q_], (mo), (mt), (c)); } while (0)
 static inline int32_t clx_decor_(int line, int32_t y, uint32_t sg, uint32_t rmask, uint32_t c, uint32_t s1, uint32_t pmask) {
     const uint32_t odd = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xF5, 0xF, 0xF, false);       // quad_perm [1,1,3,3]
@@ -103,6 +105,7 @@ static inline uint32_t clx_uniform_(int line, uint32_t v) {
 static inline uint32_t clx_peek_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 static inline void clx_poke_u32(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 static inline void clx_stores_done() {}
+#define clx_group_fence() ((void)__ballot(1))       // (a per-wave rendezvous: every lane has written its share)
 static inline void clx_pause() {}
 static inline void clx_release() {}
 static inline void clx_acquire() {}

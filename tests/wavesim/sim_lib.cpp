@@ -26,7 +26,8 @@ struct SimLanes {
     std::vector<uint64_t> endbits;
     std::vector<clx_crc_part> crc_part;
     std::vector<clx_window> windows;
-    std::vector<int32_t> planar;       // CLX_OUT_PCM16: the run's planar scratch (what the general kernels decode; clx_k_narrow_left narrows it)
+    std::vector<int32_t> planar;       // narrow output: the general kernels' staging rows of the run (64 per workgroup, clx_lanes_group)
+    uint32_t stage_stride = 0;
     bool lean = false;
     bool plan(const clx_frame_desc* frames, size_t n_, const uint64_t* out_offs, size_t arena_len, uint32_t flags_) {
         n = n_; flags = flags_;
@@ -46,11 +47,11 @@ struct SimLanes {
         const int cmode = (!lean || (flags & CLX_NO_COMPOSE)) ? -1 : (flags & CLX_COMPOSE) ? 1 : 0;
         n_windows = clx_plan_windows(dev.data(), n, cmode, windows.data());
         slot_frame_plan = slot_frame; first_slot_plan = first_slot;      // (what must stay untouched)
-        if (flags & CLX_OUT_PCM16) {
+        if (flags & (CLX_OUT_PCM16 | CLX_OUT_PCM24)) {
             if (!lean) return false;
-            uint64_t out_len = 0;
-            for (size_t i = 0; i < n; ++i) out_len = std::max<uint64_t>(out_len, out_offs[i] + (uint64_t)frames[i].n_channels * frames[i].block_size);
-            planar.assign(out_len + 16, 0x2b2b2b2b);
+            uint32_t bs_max = 1;
+            for (size_t i = 0; i < n; ++i) bs_max = std::max<uint32_t>(bs_max, frames[i].block_size);
+            stage_stride = (bs_max + 3u) & ~3u;
         }
         return true;
     }
@@ -69,14 +70,14 @@ struct SimLanes {
         R.errkey = errkey.data(); R.end_bits = endbits.data(); R.taken = lean ? taken.data() : nullptr;
         R.results = results; R.gen = gen;
         R.crc_part = crc_part.data(); R.crc_todo = crc_todo.data();
-        R.flags = ((flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u);
-        R.planar = (flags & CLX_OUT_PCM16) ? planar.data() : nullptr;
+        R.flags = ((flags & CLX_VERIFY_CRC16) ? CLX_RUN_CRC : 0u) | ((flags & CLX_OUT_PCM16) ? CLX_RUN_PCM16 : 0u) | ((flags & CLX_OUT_PCM24) ? CLX_RUN_PCM24 : 0u);
+        R.planar = nullptr;            // (narrow output: handed out with the general kernels' grid, as the library does)
         // the run's slot maps: the plan's, or its own when waves are composed by content (as the library does: clx_plan_windows)
         R.slot_frame = slot_frame.data(); R.first_slot = first_slot.data(); R.fkey = n_windows ? fkey.data() : nullptr;
         return R;
     }
     // the library's rule (launch_lanes): the scan and the 16-bit tier as clx_k_pool's tickets unless the waves are composed by content
-    bool pooled() const { return lean && (flags & CLX_POOL) && !(n_windows && n_multi); }
+    bool pooled() const { return lean && (flags & CLX_POOL) && !(flags & CLX_OUT_PCM24) && !(n_windows && n_multi); }
     // one run by itself: a launch of one run
     int run(const uint8_t* arena, size_t arena_len, int32_t* out, clx_frame_result* results) {
         clx_runs runs;
@@ -131,7 +132,7 @@ struct SimLanes {
             }
             // the lean kernel first (it marks the groups it decodes with this run's generation number), unless the caller
             // asks for the general kernels alone (CLX_LANES_GENERAL: the pre-round-3 form, kept as a test target)
-            if (lean && !front_done) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
+            if (lean && !front_done && !(flags & CLX_OUT_PCM24)) SIM_LAUNCH(clx_k_lean, (n_slots + 63) / 64, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
             for (size_t gi = 0; gi < (n_slots + 63) / 64; ++gi) sim_stats[52] += taken[gi] == runs.r[0].gen;
             if (lean) {     // the split tier on what is left (the library launches it when the batch holds frames of more than 16 bits)
                 uint64_t before = 0, after = 0;
@@ -150,9 +151,14 @@ struct SimLanes {
                 if (n_left > ggrid) return CLX_API_ERROR;
                 ggrid = n_left >= 3 ? n_left / 3 : 1;
             }
-            SIM_LAUNCH(clx_k_lanes, ggrid, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
-            SIM_LAUNCH(clx_k_lanes_hi, ggrid, 64, runs, dev.data(), (uint32_t)n_slots, dump.data());
-            if (flags & CLX_OUT_PCM16) SIM_LAUNCH(clx_k_narrow_left, ggrid, 256, runs, dev.data(), (uint32_t)n_slots);
+            clx_runs gruns = runs;
+            if (flags & (CLX_OUT_PCM16 | CLX_OUT_PCM24)) {       // (the staging rows: 64 per workgroup, stale between launches)
+                planar.assign(ggrid * 64 * (size_t)stage_stride + 16, 0x2b2b2b2b);
+                gruns.r[0].planar = planar.data();
+                gruns.r[0].flags |= CLX_RUN_STAGE_BITS(stage_stride);
+            }
+            SIM_LAUNCH(clx_k_lanes, ggrid, 64, gruns, dev.data(), (uint32_t)n_slots, dump.data());
+            SIM_LAUNCH(clx_k_lanes_hi, ggrid, 64, gruns, dev.data(), (uint32_t)n_slots, dump.data());
         } else {
             std::vector<int32_t> dump(((n_slots + 127) / 128) * 128 * 16 + 16);
             SIM_LAUNCH(clx_k_lanes2, (n_slots + 127) / 128, 256, arena, alloc_len + 16, dev.data(), slot_frame.data(), (uint32_t)n_slots, sf_start.data(), out,

@@ -16,6 +16,11 @@
 #define LW "s_waitcnt lgkmcnt(0)\n\t"
 #define S4 "v_perm_b32 %0, %0, %9, %9\n\tv_perm_b32 %1, %1, %9, %9\n\tv_perm_b32 %2, %2, %9, %9\n\tv_perm_b32 %3, %3, %9, %9\n\t"
 #define F4 "v_add_u32 %0, %0, %9\n\tv_add_u32 %1, %1, %9\n\tv_add_u32 %2, %2, %9\n\tv_add_u32 %3, %3, %9\n\t"
+#define F4E "v_add_u32_e64 %0, %0, %9\n\tv_add_u32_e64 %1, %1, %9\n\tv_add_u32_e64 %2, %2, %9\n\tv_add_u32_e64 %3, %3, %9\n\t"
+#define G4 "v_lshrrev_b32 %0, 1, %0\n\tv_sub_u32 %1, %1, %9\n\tv_ashrrev_i32 %2, 1, %2\n\tv_xor_b32 %3, %3, %9\n\t"
+#define SF4 "v_perm_b32 %0, %0, %9, %9\n\tv_add_u32 %1, %1, %9\n\tv_perm_b32 %2, %2, %9, %9\n\tv_add_u32 %3, %3, %9\n\t"
+#define FS4 "v_add_u32 %0, %0, %9\n\tv_perm_b32 %1, %1, %9, %9\n\tv_add_u32 %2, %2, %9\n\tv_perm_b32 %3, %3, %9, %9\n\t"
+#define SSFF4 "v_perm_b32 %0, %0, %9, %9\n\tv_perm_b32 %1, %1, %9, %9\n\tv_add_u32 %2, %2, %9\n\tv_add_u32 %3, %3, %9\n\t"
 #define SD4 "v_perm_b32 %0, %0, %9, %9\n\tv_perm_b32 %0, %0, %9, %9\n\tv_perm_b32 %0, %0, %9, %9\n\tv_perm_b32 %0, %0, %9, %9\n\t"
 #define A1 "s_add_u32 %4, %4, %10\n\t"
 #define A2 "s_add_u32 %4, %4, %10\n\ts_add_u32 %5, %5, %10\n\t"
@@ -23,11 +28,13 @@
 #define X1 "s_and_saveexec_b64 %7, %12\n\ts_cbranch_execz 1f\n\t1:\n\ts_or_b64 exec, exec, %7\n\t"
 #define R1 "v_readlane_b32 %4, %8, 3\n\ts_nop 0\n\tv_writelane_b32 %8, %4, 3\n\t"
 
-enum { T_S16, T_S16_A4, T_S16_A8, T_S16_A16, T_S16_L1, T_S16_L2, T_S16_L4, T_F16, T_F16_A4, T_F16_A8, T_S8F8, T_MIX, T_S16_X2, T_S16_X4, T_S16_R4, T_SD16, T_SD16_A4, T_A16, T_L4, T_COUNT };
+enum { T_S16, T_S16_A4, T_S16_A8, T_S16_A16, T_S16_L1, T_S16_L2, T_S16_L4, T_F16, T_F16_A4, T_F16_A8, T_S8F8, T_MIX, T_S16_X2, T_S16_X4, T_S16_R4, T_SD16, T_SD16_A4, T_A16, T_L4, T_S8_F8, T_SFALT, T_SSFF, T_F16E, T_G16, T_S8_G8, T_COUNT };
 static const char* const names[T_COUNT] = {
     "16 S", "16 S + 4 A", "16 S + 8 A", "16 S + 16 A", "16 S + 1 L", "16 S + 2 L", "16 S + 4 L", "16 F", "16 F + 4 A", "16 F + 8 A", "8 S + 8 F",
     "12 S + 4 F + 4 A + 1 L (the kernels' mix)", "16 S + 2 X (6 scalar, 2 of them branches)", "16 S + 4 X", "16 S + 4 R (readlane + writelane)",
-    "16 S, ONE dependent chain", "16 S dependent + 4 A", "16 A alone", "4 L alone" };
+    "16 S, ONE dependent chain", "16 S dependent + 4 A", "16 A alone", "4 L alone",
+    "8 S then 8 F (runs of eight)", "S F S F ... (alternating, 8 + 8)", "S S F F ... (pairs, 8 + 8)", "16 F in the VOP3 encoding (v_add_u32_e64)",
+    "16 G (lshr / sub / ashr / xor, VOP2)", "8 S then 8 G" };
 
 template <int T>
 __global__ __launch_bounds__(64) void k_pat(uint64_t* out, int a0, int b0, int iters) {
@@ -59,6 +66,12 @@ __global__ __launch_bounds__(64) void k_pat(uint64_t* out, int a0, int b0, int i
         else if (T == T_SD16_A4) PAT(SD4 A1 SD4 A1 SD4 A1 SD4 A1);
         else if (T == T_A16) PAT(A2 A2 A2 A2 A2 A2 A2 A2);
         else if (T == T_L4) PAT(L1 L1 L1 L1 LW);
+        else if (T == T_S8_F8) PAT(S4 S4 F4 F4);
+        else if (T == T_SFALT) PAT(SF4 FS4 SF4 FS4);
+        else if (T == T_SSFF) PAT(SSFF4 SSFF4 SSFF4 SSFF4);
+        else if (T == T_F16E) PAT(F4E F4E F4E F4E);
+        else if (T == T_G16) PAT(G4 G4 G4 G4);
+        else if (T == T_S8_G8) PAT(S4 S4 G4 G4);
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
