@@ -401,14 +401,14 @@ def main():
         cfg["wave_kernels_pipelined"] = _wave_kernels_pipelined(torch, ctx, cx, w, descs, d_arena, dev, args.steps)
     if extras and world == 1 and not w.bare_subframes and w.pcm is not None:
         cfg["host_buffers"] = _host_buffer_rates(ctx, cx, w, descs)
-    if extras and world == 1 and pipelined and not w.bare_subframes and w.pcm is not None and int(np.max(w.bps)) <= 16:
-        # ---- narrow output straight from the decode (CLX_OUT_PCM16), in a process of its own: measured in this one the figure depended
+    if extras and world == 1 and pipelined and not w.bare_subframes and w.pcm is not None and int(np.max(w.bps)) <= 24:
+        # ---- narrow output straight from the decode (CLX_OUT_PCM16; config 4: CLX_OUT_PCM24), in a process of its own: measured in this one the figure depended
         #      on its place among the secondary figures (in front of the host-buffer block: 0.117 ms per step and that block's upload
         #      figure 1.61 instead of 1.40 ms; behind it: 0.132 and 1.40 -- the internal streams a batch creates get their hardware queues
         #      by what was created before them, tools/stream_probe.py).  A fresh process is the state `value` is measured in.
         fig = _pcm16_subprocess(args)
         if fig is not None:
-            cfg["pcm16_from_the_decode"] = fig
+            cfg["pcm16_from_the_decode" if fig.get("sample_bytes", 2) == 2 else "pcm24_from_the_decode"] = fig
     if rank == 0 and not args.no_cpu_baseline:
         # (at N > 1 too, on rank 0's share, behind the timed regions: north_star wants the CPU path timed in the same run at every N;
         #  the other ranks wait at the end)
@@ -420,35 +420,61 @@ def main():
         _emit(json.dumps(out))
 
 
+def _narrow_want(w, sample_bytes, dev, torch):
+    """(expected bytes of a narrow output buffer as a uint8 tensor, mask of the bytes some frame covers): frame by frame, whatever the
+    channel counts and block sizes -- interleaved, little-endian, the low `sample_bytes` bytes of every sample."""
+    inter = np.zeros(w.pcm.size, dtype=np.int32)
+    covered = np.zeros(w.pcm.size, dtype=bool)
+    for i in range(w.n):
+        a, c, bs = int(w.out_offs[i]), int(w.channels[i]), int(w.block_sizes[i])
+        inter[a:a + c * bs] = w.pcm[a:a + c * bs].reshape(c, bs).T.reshape(-1)
+        covered[a:a + c * bs] = True
+    u = inter.view(np.uint32)
+    by = np.stack([(u >> (8 * k)) & 0xff for k in range(sample_bytes)], axis=1).astype(np.uint8).reshape(-1)
+    return torch.from_numpy(by).to(dev), torch.from_numpy(np.repeat(covered, sample_bytes)).to(dev)
+
+
 def _pcm16_from_the_decode(torch, ctx, cx, w, descs, d_arena, dev, steps, repeats, with_crc, path):
-    """Narrow output straight from the decode (CLX_OUT_PCM16: interleaved 16-bit PCM written by the lean kernel from the tiles it stages
-    anyway -- half the bytes through the write path), consecutive steps like `value`'s.  A secondary figure, never `value`: Claxon's Block
-    is planar i32 (frame.rs:402-411); this is what examples/decode.rs:48-62 and lib.rs:473-520 do with it right afterwards."""
+    """Narrow output straight from the decode, consecutive steps like `value`'s: CLX_OUT_PCM16 (interleaved 16-bit PCM written by the
+    lean kernel from the tiles it stages anyway -- half the bytes through the write path) for audio of <= 16 bits, CLX_OUT_PCM24 (packed
+    24-bit, the split tier's: round 6) beyond.  A secondary figure, never `value`: Claxon's Block is planar i32 (frame.rs:402-411);
+    this is what examples/decode.rs:48-62 and lib.rs:473-520 do with it right afterwards.  Not bit-exact, no figure."""
     stream = torch.cuda.current_stream(dev).cuda_stream
-    bp = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=(path & (cx.COMPOSE | cx.NO_COMPOSE | cx.POOL)) | cx.OUT_PCM16)
+    sb = 2 if int(descs["bps"].max()) <= 16 else 3
+    flag = cx.OUT_PCM16 if sb == 2 else cx.OUT_PCM24
+    bp = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=(path & (cx.COMPOSE | cx.NO_COMPOSE | cx.POOL)) | flag)
     depth = bp.submit_depth
     arenas = [d_arena] + [d_arena.clone() for _ in range(depth - 1)]          # (distinct copies of the input, like `value`'s steps)
-    pouts = [torch.zeros(w.total_samples + 8, dtype=torch.int16, device=dev) for _ in range(depth)]
+    pouts = [torch.zeros(sb * w.total_samples + 16, dtype=torch.uint8, device=dev) for _ in range(depth)]
     for i in range(len(pouts)):
         bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i].data_ptr(), stream)
     bp.flush(stream); torch.cuda.synchronize()
-    want16 = torch.from_numpy(w.pcm.reshape(-1, 2, w.pcm.size // (2 * w.n)).transpose(0, 2, 1).reshape(-1).astype(np.int16)).to(dev) \
-        if bool(np.all(w.channels == 2)) and bool(np.all(w.block_sizes == w.block_sizes[0])) else None
-    exact16 = (want16 is not None) and all(bool(torch.equal(o[:w.total_samples], want16)) for o in pouts) and bool(np.all(bp.results()["status"] == 0))
+    want, cov = _narrow_want(w, sb, dev, torch)
+    n_by = sb * w.pcm.size
+    exact = all(bool(torch.equal(o[:n_by][cov], want[cov])) for o in pouts) and bool(np.all(bp.results()["status"] == 0))
+    if not exact:
+        bp.close()
+        raise RuntimeError("bench: the narrow output (%d bytes per sample) is not bit-exact" % sb)
+    for o in pouts:
+        o.zero_()
     regs = []
     for _ in range(max(1, repeats)):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(steps):
             bp.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, pouts[i % len(pouts)].data_ptr(), stream)
         bp.flush(stream); torch.cuda.synchronize(); regs.append(time.perf_counter() - t0)
+    exact = all(bool(torch.equal(o[:n_by][cov], want[cov])) for o in pouts[:min(steps, len(pouts))])      # (what the TIMED steps wrote)
     bp.close(); del pouts
+    if not exact:
+        raise RuntimeError("bench: the narrow output of the timed steps is not bit-exact")
     ms_p = 1e3 * float(np.median(regs)) / steps
-    alg16 = w.compressed_bytes + 2 * w.total_samples
+    alg = w.compressed_bytes + sb * w.total_samples
     return {"value": round(w.total_samples / (ms_p * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_p, 4), "steps": steps,
-            "bit_exact": exact16, "algorithmic_bytes": alg16, "achieved_GBps": round(alg16 / (ms_p * 1e-3) / 1e9, 1),
-            "frac": round(alg16 / (ms_p * 1e-3) / 1e9 / PEAK_GBS, 4),
-            "note": "CLX_OUT_PCM16: interleaved little-endian 16-bit PCM written by the decode kernel itself (2 bytes per sample out instead "
-                    "of 4), measured in a process of its own; secondary -- `value` is planar i32, Claxon's Block"}
+            "sample_bytes": sb, "bit_exact": True, "algorithmic_bytes": alg, "achieved_GBps": round(alg / (ms_p * 1e-3) / 1e9, 1),
+            "frac": round(alg / (ms_p * 1e-3) / 1e9 / PEAK_GBS, 4),
+            "note": ("CLX_OUT_PCM16: interleaved little-endian 16-bit PCM" if sb == 2 else "CLX_OUT_PCM24: interleaved packed little-endian 24-bit PCM") +
+                    " written by the decode kernel itself (%d bytes per sample out instead of 4), checked frame by frame before and after the timed "
+                    "steps, measured in a process of its own; secondary -- `value` is planar i32, Claxon's Block" % sb}
 
 
 def _pcm16_subprocess(args):
@@ -458,11 +484,13 @@ def _pcm16_subprocess(args):
            "--shard-of", str(args.shard_of), "--shard-rank", str(args.shard_rank), "--compose", args.compose, "--devices", args.devices]
     if args.no_crc:
         cmd.append("--no-crc")
+    cmd += ["--pool", args.pool]
+    r = None
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         return json.loads(r.stdout.decode().strip().splitlines()[-1])
     except Exception as e:                       # (a secondary figure: the line goes out without it)
-        print("bench: the CLX_OUT_PCM16 figure's process failed: %r" % (e,), file=sys.stderr)
+        print("bench: the narrow-output figure's process failed (no figure): %r %s" % (e, r.stderr.decode()[-300:] if r is not None else ""), file=sys.stderr)
         return None
 
 

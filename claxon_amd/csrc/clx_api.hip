@@ -775,8 +775,8 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
             hipLaunchKernelGGL(clx_k_compose, dim3((unsigned)b->n_windows, n_runs), dim3(CLX_COMPOSE_THREADS), 0, stream, runs, (const clx_window*)b->d_windows);
         }
         // the 16-bit tier first: it marks the groups it decodes with the run's generation number, the general kernels skip them
-        const bool tiers = !(b->flags & CLX_OUT_PCM24);       // (packed 24-bit output is the general kernels': the tiers would leave every group)
-        if (runs.r[0].taken != nullptr && b->any_bps_le16 && !pooled && tiers) {
+        const bool p24 = (b->flags & CLX_OUT_PCM24) != 0;     // (packed 24-bit output is the split tier's, for the batch's 16-bit frames too)
+        if (runs.r[0].taken != nullptr && b->any_bps_le16 && !pooled && !p24) {
             if (!mark("clx_k_lean")) return false;
             // CLX_LEAN_LDS_PAD (measurement builds only): extra dynamic LDS per wave, i.e. fewer decode waves per CU -- the knob behind
             // profiles/r05_occupancy_sweep.txt
@@ -790,7 +790,7 @@ bool launch_lanes(clx_batch* b, const clx_runs& runs, unsigned n_runs, bool spli
         }
         // the split tier for audio of more than 16 bits (launched when the batch holds such frames: it also takes <= 16-bit groups of
         // more than 12 taps that share the batch, which otherwise stay with clx_k_lanes_hi)
-        if (runs.r[0].taken != nullptr && b->any_bps_gt16 && tiers) {
+        if (runs.r[0].taken != nullptr && (b->any_bps_gt16 || p24)) {
             if (!mark("clx_k_lean24")) return false;
             hipLaunchKernelGGL(clx_k_lean24, dim3(groups, n_runs), dim3(64), 0, stream, runs,
                                (const clx_dev_frame*)b->d_frames, (uint32_t)b->n_slots, b->d_dump);

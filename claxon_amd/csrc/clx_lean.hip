@@ -618,7 +618,8 @@ struct LMover {
     uint32_t rowoff;           // this lane's row (bytes from `base`), or CLN_NO_ROW
     bool all_real;             // wave-uniform: every row of the wave exists
     uint32_t pcm16;            // wave-uniform: interleaved 16-bit output (CLX_RUN_PCM16) -- 1: stereo frames, rowoff is the FRAME's place, the same in
-                               // both lanes of its pair; 2: mono frames, every lane its own (round 6); 0: planar i32
+                               // both lanes of its pair; 2: mono frames, every lane its own (round 6); 3: packed 24-bit output of stereo frames
+                               // (CLX_RUN_PCM24, round 6; rowoff as for 1); 0: planar i32
 };
 #define CLN_NO_ROW 0xffffffffu
 // Narrow output (CLX_OUT_PCM16, round 5): the wave's rows are the two channels of 32 stereo frames (lanes 2F, 2F + 1), and a pair of tiles
@@ -667,8 +668,49 @@ __device__ __forceinline__ void cln_store_pcm16_mono(const int4* stage0, const L
     }
     clx_wave_sync();
 }
+// Packed 24-bit output (CLX_OUT_PCM24, round 6): a stereo frame's 32 sample pairs of a pair of tiles are 192 bytes -- L0 R0 L1 R1 ..., three
+// bytes each, little-endian -- twelve 16-byte pieces.  Sixteen adjacent lanes take one frame (twelve of them a piece each), a store
+// instruction covers four frames, eight instructions the pair of tiles.  A piece is four dwords; dword j of the block (j = 3m + k) holds
+// bytes of two consecutive samples of the interleaved sequence S[i] = (i even ? left : right)[i / 2], i = 4m + k:
+//     k = 0: S[i] bytes 0-2, S[i+1] byte 0     k = 1: S[i] bytes 1-2, S[i+1] bytes 0-1     k = 2: S[i] byte 2, S[i+1] bytes 0-2
+// -- one v_perm_b32 each.  Where S[i] sits in the stage depends on the lane (its piece) and, through a constant, on the frame: the
+// eight addresses are worked out per call (kept across the decode loop they would cost the split tier eight registers it does not
+// have) and the four frames-of-four steps differ by an immediate offset.  n_tiles: 2, or 1 for a lone last tile (six pieces).
+__device__ __forceinline__ void cln_store_pcm24(const int4* stage0, const LMover& M, uint32_t t0, int lane, uint32_t n_tiles) {
+    clx_wave_sync();
+    uint32_t ln = (uint32_t)lane;
+    CLX_OPAQUE(ln);
+    const uint32_t c = ln & 15u, fsub = ln >> 4;                            // the piece (0 .. 11; 12 .. 15: idle) and the frame among four
+    const int32_t* const st32 = reinterpret_cast<const int32_t*>(stage0);
+    uint32_t at[4][2], sel[4];                                              // where S[i], S[i+1] of the piece's four dwords sit for frame `fsub` (in int32)
+#pragma unroll
+    for (uint32_t d = 0; d < 4u; ++d) {
+        const uint32_t j = 4u * c + d, m = (j * 43u) >> 7, k = j - 3u * m;  // (j / 3 for j < 48)
+        sel[d] = k == 0u ? 0x04020100u : k == 1u ? 0x05040201u : 0x06050402u;
+#pragma unroll
+        for (uint32_t h = 0; h < 2u; ++h) {
+            const uint32_t i = 4u * m + k + h, par = i & 1u, sm = (i >> 1) & 31u, t = sm >> 4, p = (sm >> 2) & 3u, e = sm & 3u;
+            at[d][h] = 4u * (t * 256u + ((2u * fsub + (par ^ t)) * 4u) + (p ^ (fsub & 3u))) + e;      // (frame F = 4 it + fsub: row 2F + par, + 128 int32 per `it`)
+        }
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < 8u; ++it) {
+        const uint32_t o = (uint32_t)__shfl((int)M.rowoff, (int)(2u * (4u * it + fsub)), 64);
+        int4 w;
+        w.x = (int32_t)clx_perm((uint32_t)st32[at[0][1] + 128u * it], (uint32_t)st32[at[0][0] + 128u * it], sel[0]);
+        w.y = (int32_t)clx_perm((uint32_t)st32[at[1][1] + 128u * it], (uint32_t)st32[at[1][0] + 128u * it], sel[1]);
+        w.z = (int32_t)clx_perm((uint32_t)st32[at[2][1] + 128u * it], (uint32_t)st32[at[2][0] + 128u * it], sel[2]);
+        w.w = (int32_t)clx_perm((uint32_t)st32[at[3][1] + 128u * it], (uint32_t)st32[at[3][0] + 128u * it], sel[3]);
+        if (o != CLN_NO_ROW && c < 6u * n_tiles) clx_store1x16_s(M.base, o + 6u * t0 + 16u * c, w);      // (a frame's sample t0 sits 6 t0 bytes into its block)
+    }
+    clx_wave_sync();
+}
 // the pair of tiles that starts at sample index t0 (a multiple of 32)
+// (P24: the kernel writes packed 24-bit output too -- clx_k_lean24 alone: in a batch with that output it takes the 16-bit frames as well,
+//  and clx_k_lean's register file has no room for a fourth form of the store)
+template <bool P24>
 __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
+    if (P24 && M.pcm16 == 3u) { cln_store_pcm24(stage0, M, t0, lane, 2u); return; }
     if (M.pcm16 == 2u) { cln_store_pcm16_mono(stage0, M, t0, lane, 2u); return; }
     if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 2u); return; }
     clx_wave_sync();
@@ -694,7 +736,9 @@ __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover&
     clx_wave_sync();
 }
 // a lone tile 0 (the block's last 16 samples when the block size is an odd multiple of 16): 64 bytes x 16 rows per instruction
+template <bool P24>
 __device__ __forceinline__ void cln_store_single(const int4* stage0, const LMover& M, uint32_t t0, int lane) {
+    if (P24 && M.pcm16 == 3u) { cln_store_pcm24(stage0, M, t0, lane, 1u); return; }
     if (M.pcm16 == 2u) { cln_store_pcm16_mono(stage0, M, t0, lane, 1u); return; }
     if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 1u); return; }
     clx_wave_sync();
@@ -715,12 +759,14 @@ struct LTile { uint32_t n; uint32_t t0; };
 __device__ __forceinline__ void cln_done(LTile& T, uint32_t t0) {                 // the tile of sample index t0 is in the stage
     if ((t0 & 16u) == 0u) { T.n = 1u; T.t0 = t0; } else T.n = 2u;
 }
+template <bool P24>
 __device__ __forceinline__ void cln_flush(LTile& T, const int4* stage0, const LMover& M, int lane) {
-    if (T.n == 2u) { cln_store_pair(stage0, M, T.t0, lane); T.n = 0u; }          // (wave-uniform)
+    if (T.n == 2u) { cln_store_pair<P24>(stage0, M, T.t0, lane); T.n = 0u; }          // (wave-uniform)
 }
+template <bool P24>
 __device__ __forceinline__ void cln_flush_all(LTile& T, const int4* stage0, const LMover& M, int lane) {
-    if (T.n == 2u) cln_store_pair(stage0, M, T.t0, lane);
-    else if (T.n == 1u) cln_store_single(stage0, M, T.t0, lane);
+    if (T.n == 2u) cln_store_pair<P24>(stage0, M, T.t0, lane);
+    else if (T.n == 1u) cln_store_single<P24>(stage0, M, T.t0, lane);
     T.n = 0u;
 }
 
@@ -1029,7 +1075,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
     for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
         const bool live = n != 0u && !r.err;
 #ifndef CLN_LAND_FIRST
-        cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
+        cln_flush<false>(T, stage, M, lane);             // the pair of tiles before, once it is complete
 #endif
         int4* const mine = cln_mine(stage, t0, lane);
         if (slow) {
@@ -1049,7 +1095,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             CLX_STAT(46, 1);
         }
 #ifdef CLN_LAND_FIRST
-        cln_flush(T, stage, M, lane);                    // (measurement: the ring lands in FRONT of the tile stores)
+        cln_flush<false>(T, stage, M, lane);             // (measurement: the ring lands in FRONT of the tile stores)
 #endif
         const bool was_slow = slow;                      // (no lean turn is tried: the history does not fit the packed form)
         int done = 0;
@@ -1189,7 +1235,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
     uint32_t nslow = 0;
     for (uint32_t t0 = i0; t0 < nmax; t0 += 16u) {
         const bool live = n != 0u && !r.err;
-        cln_flush(T, stage, M, lane);                    // the pair of tiles before, once it is complete
+        cln_flush<true>(T, stage, M, lane);              // the pair of tiles before, once it is complete
         int4* const mine = cln_mine(stage, t0, lane);
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
         else if (cln_pump_now(calm, (t0 & 16u) == 0u)) { cln_land(g, row, CR, crc); cln_request(buf, g, cur.p, !calm || (t0 & 96u) == 0u); }
@@ -1302,8 +1348,9 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     // ---- does this wave qualify?  Every live lane: <= 16-bit audio, a FIXED / LPC subframe of at most 12 taps whose header
     //      parses, the wave's common block size (a multiple of 16, beyond the prologue), a 16-byte aligned row.
     // (narrow output: `out` holds interleaved 16-bit PCM, a lane's "row" is its FRAME's block there -- both lanes of a pair point to it)
-    const bool pcm16 = (R.flags & CLX_RUN_PCM16) != 0u;         // wave-uniform
+    const bool pcm16 = (R.flags & CLX_RUN_PCM16) != 0u, pcm24 = (R.flags & CLX_RUN_PCM24) != 0u;      // wave-uniform
     int32_t* const rowp = pcm16 ? reinterpret_cast<int32_t*>(reinterpret_cast<int16_t*>(out) + (active ? fr.out_off : 0ull))
+                        : pcm24 ? reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(out) + (active ? 3ull * fr.out_off : 0ull))
                                 : out + (active ? fr.out_off + (uint64_t)ch * fr.block_size : 0ull);
     // (where the wave's rows are: the lowest one's address, wave-uniform, and every lane's distance from it -- LMover)
     uint64_t row_lo = active ? (uint64_t)(uintptr_t)rowp : ~0ull;
@@ -1324,7 +1371,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     if (active) {
         good = fr.bps <= (SPLIT ? 24u : 16u) && bs == bs0 && (bs & 15u) == 0u && bs >= (SPLIT ? 64u : 32u) && (((uintptr_t)rowp) & 15u) == 0u && row_far < 0xffffffffull &&
                (!pcm16 || (!SPLIT && ((fr.n_channels == 2u && ch == (slot & 1u)) || fr.n_channels == 1u))) &&       // (narrow output: stereo frames, channel c in lane parity c -- or mono frames)
-               !(R.flags & CLX_RUN_PCM24) &&                     // (packed 24-bit output: the general kernels')
+               (!pcm24 || (SPLIT && fr.n_channels == 2u && ch == (slot & 1u))) &&        // (packed 24-bit output: stereo frames, the split tier -- 16-bit frames too)
                r.pos <= r.limit && (uint64_t)r.origin + 4ull * ((uint64_t)r.limit / 32ull + 16ull) < 0xffffffffull;
         if (good) {
             h = clx_lparse_sf_header(r, clx_channel_bps(fr, ch));
@@ -1333,7 +1380,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     }
     // (narrow output: one kind of frame per wave -- the movers write stereo lines or mono rows)
     const uint32_t nch0 = (uint32_t)__shfl((int)(uint32_t)fr.n_channels, (int)__ffsll((long long)__ballot(active)) - 1, 64);
-    if (pcm16 && active && fr.n_channels != nch0) good = false;
+    if ((pcm16 || pcm24) && active && fr.n_channels != nch0) good = false;
     if (!__all(good)) {                                    // clx_k_lanes / clx_k_lanes_hi decode this group
         if (!SPLIT) {
             CLX_STAT(60, 1); CLX_STAT(61, active && (fr.bps > 16u || bs != bs0 || (bs & 15u) != 0u || bs < 32u)); CLX_STAT(62, active && r.err != 0u);
@@ -1391,7 +1438,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     M.base = ((uint64_t)clx_uniform((uint32_t)(row_lo >> 32)) << 32) | clx_uniform((uint32_t)row_lo);
     M.rowoff = active ? (uint32_t)((uint64_t)(uintptr_t)rowp - row_lo) : CLN_NO_ROW;
     M.all_real = __all(active);
-    M.pcm16 = !pcm16 ? 0u : nch0 == 1u ? 2u : 1u;
+    M.pcm16 = pcm24 ? 3u : !pcm16 ? 0u : nch0 == 1u ? 2u : 1u;
     (void)dump_all;                                         // (rows that do not exist are not written: no dump slots here)
     const Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
 
@@ -1424,7 +1471,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
-        if ((i & 15u) == 0u) cln_flush(T, stage0, M, lane);
+        if ((i & 15u) == 0u) cln_flush<SPLIT>(T, stage0, M, lane);
         reinterpret_cast<int32_t*>(cln_mine(stage0, i, lane))[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
         if ((i & 15u) == 15u) cln_done(T, i & ~15u);
     }
@@ -1460,7 +1507,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
             return;
         }
     }
-    cln_flush_all(T, stage0, M, lane);                      // what is still in the stage
+    cln_flush_all<SPLIT>(T, stage0, M, lane);               // what is still in the stage
     // ---- trailing parameters of empty partitions are part of the stream (they move the next subframe / the CRC)
     if (n != 0u && !S.r.err && S.transitioned) {
         while (!S.r.err && S.parts_left != 0u) { (void)clx_lread_rice_param(S.r, S.rice2); S.parts_left -= 1u; }

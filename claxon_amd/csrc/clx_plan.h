@@ -102,7 +102,8 @@ static inline size_t clx_plan_lanes(const clx_dev_frame* dev, size_t n, uint64_t
 // that does not parse, a wave that gives its group up) is rare: an eighth of the groups is held ready for it.  (Waves composed by
 // content hold frames of one block size and width class: the count is the same in stream order.)
 // flags: the batch's (CLX_OUT_PCM16: the 16-bit tier writes narrow output for waves of stereo frames whose channel c sits in a lane of
-// parity c and whose blocks start on 16 bytes of int16, or of mono frames alone -- everything else is left for certain too).
+// parity c and whose blocks start on 16 bytes of int16, or of mono frames alone; CLX_OUT_PCM24: both tiers, stereo frames whose
+// blocks start on 16 bytes -- everything else is left for certain too).
 // sure_out (optional): the groups that are left for certain.
 static inline unsigned clx_plan_general_grid(const clx_dev_frame* dev, const uint32_t* slot_frame, uint64_t n_slots, uint32_t flags = 0, uint64_t* sure_out = nullptr) {
     const uint64_t groups = (n_slots + 63) / 64;
@@ -118,7 +119,8 @@ static inline unsigned clx_plan_general_grid(const clx_dev_frame* dev, const uin
             if (!bs0) { bs0 = bs; ch0 = d.n_channels; }
             const uint64_t row = d.out_off + (uint64_t)(s - d.first_slot) * bs;
             left = d.bps > 24u || bs != bs0 || (bs & 15u) != 0u || bs < (d.bps > 16u ? 64u : 32u) || (row & 3ull) != 0ull;
-            if (flags & CLX_OUT_PCM24) left = true;          // (packed 24-bit output: the general kernels')
+            if (flags & CLX_OUT_PCM24)                       // (packed 24-bit output: stereo frames whose blocks start on 16 bytes)
+                left = left || d.n_channels != 2u || (d.out_off & 15ull) != 0ull || ((s - d.first_slot) & 1u) != (s & 1u);
             if (flags & CLX_OUT_PCM16)
                 left = left || d.n_channels > 2u || d.n_channels != ch0 || (d.out_off & 7ull) != 0ull || (d.n_channels == 2u && ((s - d.first_slot) & 1u) != (s & 1u));
         }

@@ -229,8 +229,9 @@ enum {
     CLX_POOL            = 1u << 14,
     /* The same as CLX_OUT_PCM16 with packed little-endian 24-bit samples (3 bytes each; round 6): `d_out` points to bytes, frame i's
      * block starts at byte 3 * out_sample_offsets[i], sample t of channel c at + 3 * (t * n_channels + c): what clx_batch_interleave(.., 3)
-     * gives.  Every frame must have at most 24 bits per sample.  Written by the general lane kernels (the lean tiers write planar i32
-     * and 16-bit PCM only): correct for every shape, at the general kernels' speed. */
+     * gives.  Every frame must have at most 24 bits per sample.  The split tier (clx_k_lean24, which takes the batch's 16-bit frames too
+     * in this mode) writes a stereo frame's 32 sample pairs as twelve 16-byte pieces from the tiles it stages anyway (blocks that start on 16 bytes: out_sample_offsets[i] a multiple of 16); mono and
+     * multi-channel frames, odd block sizes and waves that give up go through the general kernels' staging rows. */
     CLX_OUT_PCM24       = 1u << 15
 };
 

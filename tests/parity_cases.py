@@ -716,7 +716,7 @@ def pcm24_workload():
     rows and clx_narrow_row: 24-bit stereo frames of every channel assignment and 32 taps (config 4's), 16-bit frames in the same
     batch, mono and three-channel frames, blocks that are no multiple of 16, wasted bits."""
     S = synth
-    return S.concat("pcm24", [S.config4(48), S.config5_unique(40), S.small_mixed(60), lean24_workload()])
+    return S.concat("pcm24", [S.config4(64), S.config5_unique(64), lean24_workload(), S.small_mixed(60)])
 
 
 def check_pcm24(oracle, backend, w, damage=0.0, seed=1):

@@ -500,13 +500,21 @@ def test_sim_takes_the_abi_flags(oracle):
 
 
 def test_sim_packed_24_bit_output(oracle):
-    """CLX_OUT_PCM24 (round 6): packed little-endian 24-bit PCM straight from the decode -- every group through the general kernels, which
-    decode into staging rows of their workgroup's own and narrow every row themselves (clx_narrow_row; also what CLX_OUT_PCM16 does with
-    the groups the lean kernel leaves).  Every frame's bytes against the oracle, intact and with a fifth of the frames damaged."""
+    """CLX_OUT_PCM24 (round 6): packed little-endian 24-bit PCM straight from the decode -- the split tier writes a stereo frame's 32 sample
+    pairs as twelve 16-byte pieces from its stage (cln_store_pcm24); everything else goes through the general kernels, which decode
+    into staging rows of their workgroup's own and narrow every row themselves (clx_narrow_row; also what CLX_OUT_PCM16 does with the
+    groups the lean kernel leaves).  Every frame's bytes against the oracle, intact and with a fifth of the frames damaged."""
+    import ctypes as C
     import simlib
     simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
     w = pc.pcm24_workload()
+    for i in range(64):
+        stats[i] = 0
     assert pc.check_pcm24(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM24), w) == w.n
+    # the split tier wrote the stereo frames' twelve pieces itself (16-bit frames too: clx_k_lean is not launched), the rest went
+    # through the general kernels' staging rows
+    assert stats[13] >= 4 and stats[52] == 0 and stats[49] >= 2, (int(stats[13]), int(stats[52]), int(stats[49]))
     assert pc.check_pcm24(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM24), w, damage=0.2, seed=5) < w.n
 
 
