@@ -1,17 +1,18 @@
 #!/bin/bash
-# A round's rocprofv3 evidence (run through gpurun; ROUND=r05 by default: the outputs' prefix).  For the bench workload (config 3, the kernels of the TIMED steps: fused lane
+# A round's rocprofv3 evidence (run through gpurun; ROUND=r06 by default: the outputs' prefix).  For the bench workload (config 3, the kernels of the TIMED steps: fused lane
 # kernels with the lean 16-bit tier): kernel trace + stats of steps one at a time, of ONE merged launch of twelve steps, and of the
 # pipelined steps (the timed mode); HBM counters and SQ instruction / wait counters in separate --pmc passes.  For configs 2 / 4 / 5:
 # kernel stats and HBM counters of steps one at a time.  Outputs under gpurun_out/prof_${ROUND}_<name>/; summaries go to profiles/.
-# usage: [ROUND=r05] tools/profile_round.sh [names...]     names: config3 config2 config4 config5 (default: all)
+# usage: [ROUND=r06] tools/profile_round.sh [names...]     names: config3 config2 config4 config5 config5share (default: the first four; config5share: one rank's share of the 1 M-frame job, 125 003 frames)
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 NAMES=${*:-config3 config2 config4 config5}
 cd /tmp && export TMPDIR=/tmp
 for NAME in $NAMES; do
   case $NAME in
     config5) ARGS="--workload config5 --total-frames 80000 --unique 4096 --shard-of 8 --shard-rank 3 --path lanes-fused";;
+    config5share) ARGS="--workload config5 --shard-of 8 --shard-rank 3 --path lanes-fused";;
     config4) ARGS="--workload config4 --frames 10000 --path lanes-fused";;
     *)       ARGS="--workload $NAME --frames 10000 --path lanes-fused";;
   esac

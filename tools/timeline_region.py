@@ -9,13 +9,21 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 binus = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
 n = 10000
 ctx = cx.Context(0, wait_s=120)
-w = synth.config3(n)
+# WORKLOAD=config5share: one rank's share of the 1 M-frame job (125 003 frames of 16 384 unique ones, tiled) instead of config 3
+if os.environ.get("WORKLOAD", "config3") == "config5share":
+    from claxon_amd import shard
+    ts = synth.config5_tiled(1_000_000, 16384)
+    lo, hi = shard.balanced_ranges(ts.weights(), 8)[3]
+    w = ts.slice(lo, hi)
+else:
+    w = synth.config3(n)
 descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens)
 d_arena = torch.from_numpy(w.arena).cuda()
 b = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.POOL if os.environ.get("POOL", "off") == "on" else 0)      # POOL=on: clx_k_pool's tickets
 depth = b.submit_depth
-outs = [torch.zeros(w.total_samples, dtype=torch.int32, device="cuda") for _ in range(depth)]
-arenas = [d_arena] + [d_arena.clone() for _ in range(depth - 1)]
+n_out = depth if depth * 4 * w.total_samples < (64 << 30) else 3        # (the share: 4.1 GB per output buffer)
+outs = [torch.zeros(w.total_samples, dtype=torch.int32, device="cuda") for _ in range(n_out)]
+arenas = [d_arena] + [d_arena.clone() for _ in range(min(depth, 4) - 1)]
 st = torch.cuda.current_stream().cuda_stream
 L = cx.lib()
 L.clx_debug_timeline.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
@@ -23,7 +31,7 @@ L.clx_debug_timeline_count.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
 def region():
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(steps):
-        b.submit(arenas[i % depth].data_ptr(), w.arena_len, outs[i % depth].data_ptr(), st)
+        b.submit(arenas[i % len(arenas)].data_ptr(), w.arena_len, outs[i % len(outs)].data_ptr(), st)
     b.flush(st); torch.cuda.synchronize()
     return time.perf_counter() - t0
 for _ in range(3):

@@ -1,4 +1,4 @@
-"""profiles/pmc_traffic.json entries from a round-3 profile directory (tools/profile_r03.sh): HBM bytes per launch per kernel
+"""profiles/pmc_traffic.json entries from a round-3 profile directory (tools/profile_round.sh): HBM bytes per launch per kernel
 ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc passes) and the instruction counts of the same kernels (SQ_INSTS_VALU / SALU /
 LDS, wave-instructions per launch).  usage: update_traffic.py <gpurun_out/prof_r03_NAME> <key> <source text>"""
 import csv, glob, json, os, sys
