@@ -168,15 +168,25 @@ __device__ __forceinline__ void clx_store4x16(int32_t* p0, int32_t* p1, int32_t*
                  :: "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
 // the same with a wave-uniform base and 32-bit byte offsets (global_store ... saddr: address = scalar base + zero-extended vector offset)
+// The decode kernels' output stores carry the streaming hint (`nt`, round 6): a decoded line is never read again, and while it sat in
+// the L2 it pushed out the lanes' INPUT lines -- a lane takes its stream 16 bytes at a time, eight requests to a 128-byte line, tens of
+// microseconds apart.  rocprofv3 FETCH_SIZE of clx_k_lean in ONE merged launch of twelve runs: 155 MB per run without the hint, 65 MB
+// with it (the run's input is 51.5 MB); the pipelined steps 1.5-3 % shorter, builds alternating on two boxes
+// (profiles/r06_store_policy_ab.txt).  `sc1` and `sc0 sc1 nt` were measured beside it: nothing / the same.  -DCLX_STORE_PLAIN: without.
+#ifdef CLX_STORE_PLAIN
+#define CLX_STORE_POLICY ""
+#else
+#define CLX_STORE_POLICY " nt"
+#endif
 __device__ __forceinline__ void clx_store4x16_s(uint64_t base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
     const clx_i32x4 a = { w0.x, w0.y, w0.z, w0.w }, b = { w1.x, w1.y, w1.z, w1.w }, c = { w2.x, w2.y, w2.z, w2.w }, d = { w3.x, w3.y, w3.z, w3.w };
-    asm volatile("global_store_dwordx4 %0, %4, %8\n\tglobal_store_dwordx4 %1, %5, %8\n\tglobal_store_dwordx4 %2, %6, %8\n\t"
-                 "global_store_dwordx4 %3, %7, %8\n\ts_nop 1"
+    asm volatile("global_store_dwordx4 %0, %4, %8" CLX_STORE_POLICY "\n\tglobal_store_dwordx4 %1, %5, %8" CLX_STORE_POLICY "\n\tglobal_store_dwordx4 %2, %6, %8" CLX_STORE_POLICY "\n\t"
+                 "global_store_dwordx4 %3, %7, %8" CLX_STORE_POLICY "\n\ts_nop 1"
                  :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(a), "v"(b), "v"(c), "v"(d), "s"(base) : "memory");
 }
 __device__ __forceinline__ void clx_store1x16_s(uint64_t base, uint32_t o, const int4& w) {
     const clx_i32x4 a = { w.x, w.y, w.z, w.w };
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(o), "v"(a), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2" CLX_STORE_POLICY "\n\ts_nop 1" :: "v"(o), "v"(a), "s"(base) : "memory");
 }
 // Mid/side reconstruction of four samples for lane pairs (even lane = mid -> left, odd lane = side -> right), the short form:
 //   left = mid + ((side + 1) >> 1),   right = mid - (side >> 1) = mid + ((-side + 1) >> 1)

@@ -245,3 +245,49 @@ def test_packed_24_bit_output_on_the_gpu(oracle):
     for k, o in enumerate(outs):
         assert bool(torch.equal(o[:3 * w.pcm.size][d_cov], want[d_cov])), "output buffer %d" % k
     batch.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_pool_tickets_on_the_gpu(oracle):
+    """CLX_POOL (round 6) on the GPU: merged launches whose scan waves and 16-bit-tier decode waves are tickets of one resident grid
+    (clx_k_pool) -- more submissions than output buffers (every buffer is re-used while launches are in flight), a workload with groups
+    the lean tier leaves and gives up (the general kernels behind the pool), and a damaged arena among the intact ones: every buffer
+    against the oracle's decode of what was submitted into it last."""
+    import torch
+    ctx = cx.Context(0, wait_s=120)
+    w = synth.concat("pool on the gpu", [synth.config3(1500), pc.giveup_workload(256), synth.config5_unique(300), synth.small_mixed(80)])
+    descs = pc.workload_descs(w)
+    rng = np.random.default_rng(2026)
+    bad = w.arena.copy()
+    for i in rng.choice(w.n, size=w.n // 10, replace=False):
+        lo, hi = int(w.offs[i]) + int(descs["header_bytes"][i]), int(w.offs[i] + w.lens[i])
+        pos = int(rng.integers(8 * lo, 8 * hi))
+        bad[pos >> 3] ^= (0x80 >> (pos & 7))
+    d_ok, d_bad = torch.from_numpy(w.arena).to("cuda:0"), torch.from_numpy(bad).to("cuda:0")
+    batch = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.PATH_LANES | cx.LANES_FUSED | cx.NO_COMPOSE | cx.POOL)
+    assert batch.submit_lanes
+    outs = [torch.full((w.pcm.size,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0") for _ in range(5)]
+    st = torch.cuda.current_stream().cuda_stream
+    n_sub = 2 * batch.submit_depth + 7
+    last = {}
+    for i in range(n_sub):
+        damaged = (i % 9 == 4)
+        batch.submit((d_bad if damaged else d_ok).data_ptr(), w.arena_len, outs[i % 5].data_ptr(), st)
+        last[i % 5] = damaged
+    batch.flush(st)
+    torch.cuda.synchronize()
+    res = batch.results()                                   # (the LAST submission's)
+    ref_ok = np.zeros(w.pcm.size, dtype=np.int32)
+    r_ok = oracle.decode_batch(w.arena[:w.arena_len], w.offs, w.lens, out=ref_ok, out_offs=w.out_offs, check_crc=True)
+    ref_bad = np.zeros(w.pcm.size, dtype=np.int32)
+    r_bad = oracle.decode_batch(bad[:w.arena_len], w.offs, w.lens, out=ref_bad, out_offs=w.out_offs, check_crc=True)
+    r_last = r_bad if ((n_sub - 1) % 9 == 4) else r_ok
+    assert np.array_equal(res["status"], r_last["statuses"]) and np.array_equal(res["msg"], r_last["msgs"])
+    assert np.all(r_ok["statuses"] == cx.OK) and int(np.sum(r_bad["statuses"] != cx.OK)) >= 10
+    for k, o in enumerate(outs):
+        got = o.cpu().numpy()
+        ref, r = (ref_bad, r_bad) if last[k] else (ref_ok, r_ok)
+        for i in np.nonzero(r["statuses"] == cx.OK)[0]:
+            lo, hi = int(w.out_offs[i]), int(w.out_offs[i]) + int(w.channels[i]) * int(w.block_sizes[i])
+            assert np.array_equal(got[lo:hi], ref[lo:hi]), (k, int(i))
+    batch.close(); ctx.close()

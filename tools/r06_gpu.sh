@@ -51,6 +51,27 @@ trace)
     python $REPO/tools/trace_pipelined.py $O/trace_$lib.$pool all > $O/trace_$lib.$pool.$STEPS.txt 2>&1
     rm -rf $O/trace_$lib.$pool
   done ;;
+m12pmc)
+  # HBM counters of ONE merged launch of twelve runs at a time (tools/merge_probe.py 12 3), separate --pmc passes: m12pmc "variants"
+  VARS=${1:-"head"}
+  cd /tmp && export TMPDIR=/tmp
+  for v in $VARS; do
+    if [ "$v" = head ]; then unset CLAXON_HIP_LIB; else export CLAXON_HIP_LIB=$REPO/claxon_amd/libclaxon_hip_$v.so; fi
+    for set in FETCH_SIZE WRITE_SIZE; do
+      rm -rf $O/m12_${v}_$set
+      timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/m12_${v}_$set -o p -- python $REPO/tools/merge_probe.py 12 3 > $O/m12_${v}_$set.log 2>&1
+      python - $O/m12_${v}_$set "$v $set" <<'PY' | tee -a $O/m12pmc.txt
+import csv,glob,sys
+f=glob.glob(sys.argv[1]+"/**/*counter_collection.csv", recursive=True)
+d={}
+for r in csv.DictReader(open(f[0])):
+    n=r["Kernel_Name"]
+    if n.startswith("clx_k_"): d.setdefault(n,[]).append(float(r["Counter_Value"]))
+print("%-16s" % sys.argv[2], {k[6:]: round(sum(v)/len(v)/12/1024, 1) for k,v in d.items() if sum(v)/len(v) > 1000}, "(MiB-units per run: FETCH x 2 = MB fetched)")
+PY
+      rm -rf $O/m12_${v}_$set
+    done
+  done ;;
 line)
   cd $REPO
   timeout 600 python bench.py "$@" > $O/bench_line.json 2> $O/bench_line.err; tail -c 1500 $O/bench_line.json ;;

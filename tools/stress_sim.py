@@ -11,7 +11,8 @@ from parity_util import SimBackend
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 names = sys.argv[2:] or ["waves"]
-sel = {"waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES | cx.LANES_SPLIT, "lanes-fused": cx.PATH_LANES | cx.LANES_FUSED}
+sel = {"waves": cx.PATH_WAVES, "lanes": cx.PATH_LANES | cx.LANES_SPLIT, "lanes-fused": cx.PATH_LANES | cx.LANES_FUSED,
+       "lanes-fused-pool": cx.PATH_LANES | cx.LANES_FUSED | cx.POOL}      # (round 6: the scan and the 16-bit tier as clx_k_pool's tickets)
 n_bad = n_all = 0
 
 
