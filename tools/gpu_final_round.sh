@@ -1,9 +1,9 @@
 #!/bin/bash
-# A round's figures of record on one box (ROUND=r05 by default: the output directory's suffix): the GPU suite, smoke(), the driver-style bench line (twice), the default line with its
+# A round's figures of record on one box (ROUND=r06 by default: the output directory's suffix): the GPU suite, smoke(), the driver-style bench line (twice), the default line with its
 # secondary figures, configs 2 / 4 / 5 pipelined, the 125 003-frame rank share of config 5, two ranks on one GPU (gloo).
 set -u
 cd "$(dirname "$0")/.."
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 O=gpurun_out/final_$ROUND; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 [ -n "${SKIP_TESTS:-}" ] || { timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -2 $O/pytest.log; }
