@@ -328,7 +328,7 @@ def main():
                              "valu_busy_ms": round(busy_ms * scale, 4), "valu_busy_frac": round(busy_ms * scale / t_path_ms, 4),
                              "waiting_frac": round(1.0 - busy_ms * scale / t_path_ms, 4),
                              "note": "instruction counts: committed rocprofv3 --pmc profile (traffic_source); valu_busy_frac = the vector pipes' "
-                                     "busy time / time of the step; scalar and LDS instructions co-issue (profiles/r05_ubench_coissue.txt) and are not added"}
+                                     "busy time / time of the step; scalar and LDS instructions co-issue (profiles/r05_ubench_coissue.txt, r06_ubench_coissue.txt) and are not added; in a full machine the launches also move ~4.5 TB/s of HBM traffic against a copy ceiling of ~5 (profiles/r06_final_figures.txt): the step is bound by both"}
 
     extras = rank == 0 and not args.no_extras
     if extras:

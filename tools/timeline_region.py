@@ -23,7 +23,8 @@ b = ctx.plan(descs, w.out_offs, verify_crc=True, path=cx.POOL if os.environ.get(
 depth = b.submit_depth
 n_out = depth if depth * 4 * w.total_samples < (64 << 30) else 3        # (the share: 4.1 GB per output buffer)
 outs = [torch.zeros(w.total_samples, dtype=torch.int32, device="cuda") for _ in range(n_out)]
-arenas = [d_arena] + [d_arena.clone() for _ in range(min(depth, 4) - 1)]
+n_in = int(os.environ.get("COPIES", "0")) or (depth if depth * w.arena_len < (8 << 30) else 4)       # distinct copies of the input (bench.py: one per step in flight)
+arenas = [d_arena] + [d_arena.clone() for _ in range(n_in - 1)]
 st = torch.cuda.current_stream().cuda_stream
 L = cx.lib()
 L.clx_debug_timeline.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
