@@ -128,12 +128,15 @@ __device__ __forceinline__ void cln_reset(const clx_buf& buf, LRing& g, uint32_t
 // the turn's tile stores included, which are issued right in front of it.  Landing in front of the stores instead, when all that is
 // in flight is a whole turn old, makes one run alone 4 % faster and a saturated machine 9 % slower (one merged launch of nine runs:
 // 1.27 -> 1.39 ms; tools/gpu_ab_sat.sh): the wait is what paces the waves' stores.)
+// (MAXP: granules a pump may have in flight -- three; two in the 12-tap build of the 16-bit tier, whose loop has no registers for the third:
+//  cln_body)
+template <int MAXP = 3>
 __device__ __forceinline__ void cln_land(LRing& g, uint32_t* row, LCrc& C, bool crc) {
     // (one vote per turn instead of a question per granule: up to three granules land, all of them the shares' next ones)
-    const int mode = !crc ? 0 : __all(C.next == g.fill && g.fill + 12u <= C.db) ? 1 : 2;
+    const int mode = !crc ? 0 : __all(C.next == g.fill && g.fill + 4u * (uint32_t)MAXP <= C.db) ? 1 : 2;
     if (g.np >= 1u) { cln_put(row, g.fs, g.pa, C, g.fill, mode); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
     if (g.np >= 2u) { cln_put(row, g.fs, g.pb, C, g.fill, mode); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
-    if (g.np >= 3u) { cln_put(row, g.fs, g.pc, C, g.fill, mode); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
+    if (MAXP >= 3 && g.np >= 3u) { cln_put(row, g.fs, g.pc, C, g.fill, mode); g.fill += 4u; g.fs = cln_wrap(g.fs + 4u); }
     if (mode == 1) C.next = g.fill;
     g.np = 0;
 }
@@ -142,6 +145,7 @@ __device__ __forceinline__ void cln_land(LRing& g, uint32_t* row, LCrc& C, bool 
 // every pump for the quarter of the lanes that had two in flight -- with the second granules asked for TOGETHER it runs at a quarter
 // of the pumps for most of them.  In between a lane falls at most 1.5 granules behind (6 bits per sample: the calm limit), which a
 // ring of 24 dwords holds beside the two turns' worth it must have landed.
+template <int MAXP = 3>
 __device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32_t p, bool more) {
     const uint32_t d = (p - 1u) >> 5;                                   // the oldest dword a window may still read
     const int32_t room = (int32_t)(CLN_RING + d - g.fill);                // slots that hold dwords before d
@@ -149,7 +153,7 @@ __device__ __forceinline__ void cln_request(const clx_buf& buf, LRing& g, uint32
     if (room >= 4) { g.pa = clx_buf_load16(buf, g.origin + 4u * g.fill); g.np = 1u; }
     if (!more) return;
     if (room >= 8) { g.pb = clx_buf_load16(buf, g.origin + 4u * g.fill + 16u); g.np = 2u; }
-    if (room >= 12) { g.pc = clx_buf_load16(buf, g.origin + 4u * g.fill + 32u); g.np = 3u; }
+    if (MAXP >= 3 && room >= 12) { g.pc = clx_buf_load16(buf, g.origin + 4u * g.fill + 32u); g.np = 3u; }
 }
 // The ring is pumped (landing + requests) every OTHER turn in CALM waves: at 5 bits per code a lane uses a granule in 1.6 turns,
 // and the wave paid for a landing, a CRC step and three request blocks per turn as soon as ONE lane had something in flight.
@@ -408,7 +412,7 @@ __device__ __forceinline__ void cln_scan_wave(uint32_t* ring0, const clx_run& R,
     KR.rice = true; KR.verb = false; KR.bitmask = 0xffffffffu; KR.ricemask = 0xffffffffu; KR.verbmask = 0u; KR.cor = 0u; KR.vsh = 0u; KR.vshm = 0u;
     const uint32_t bs = fr.block_size;
     // (a calm wave -- no frame above 6 bits per sample over all its channels: the ring is pumped every other turn, cln_pump_now)
-    const bool calm = __all(!active || fr.limit_bits <= 6u * bs * (uint32_t)fr.n_channels);
+    const bool calm = CLN_RING >= 24u && __all(!active || fr.limit_bits <= 6u * bs * (uint32_t)fr.n_channels);      // (a shorter ring is pumped at every turn)
     uint32_t nch = active ? (uint32_t)fr.n_channels - 1u : 0u;       // channels to scan
     uint32_t nch_max = nch;
 #pragma unroll
@@ -620,8 +624,20 @@ struct LMover {
     uint32_t pcm16;            // wave-uniform: interleaved 16-bit output (CLX_RUN_PCM16) -- 1: stereo frames, rowoff is the FRAME's place, the same in
                                // both lanes of its pair; 2: mono frames, every lane its own (round 6); 3: packed 24-bit output of stereo frames
                                // (CLX_RUN_PCM24, round 6; rowoff as for 1); 0: planar i32
+    bool ms;                   // wave-uniform: the stage holds mid and side as decoded -- the movers turn them into left and right (cln_ms4)
 };
 #define CLN_NO_ROW 0xffffffffu
+// Mid/side in the movers (round 6).  A lane that decodes a subframe holds ONE channel, so undoing mid/side there takes four
+// instructions per sample in each lane of the pair (the partner's value comes through DPP, the rounding through a per-lane constant).
+// A mover holds the same four samples of BOTH rows of a frame, and there
+//     left = ((mid << 1 | side & 1) + side) >> 1 = mid + ((side + 1) >> 1)        right = left - side        (frame.rs:382-384)
+// is four plain instructions per PAIR of samples.  So in waves in which every lane belongs to a mid/side pair without wasted bits the
+// turns stage what they decoded and the movers do this: two instructions per sample less.  a: mid -> left, b: side -> right.
+__device__ __forceinline__ void cln_ms4(int4& a, int4& b) {
+    const int32_t tx = (b.x + 1) >> 1, ty = (b.y + 1) >> 1, tz = (b.z + 1) >> 1, tw = (b.w + 1) >> 1;
+    a.x += tx; a.y += ty; a.z += tz; a.w += tw;
+    b.x = a.x - b.x; b.y = a.y - b.y; b.z = a.z - b.z; b.w = a.w - b.w;
+}
 // Narrow output (CLX_OUT_PCM16, round 5): the wave's rows are the two channels of 32 stereo frames (lanes 2F, 2F + 1), and a pair of tiles
 // holds 32 samples of each -- one 128-byte line of interleaved 16-bit PCM per frame.  Eight adjacent lanes write one frame's line
 // (lane q: sample pairs 4q .. 4q + 3, i.e. piece q & 3 of tile q >> 2 of BOTH rows, packed low halves left | right), a store
@@ -637,9 +653,10 @@ __device__ __forceinline__ void cln_store_pcm16(const int4* stage0, const LMover
     for (uint32_t i = 0; i < 4u; ++i) {
         const uint32_t F = 8u * i + (ln >> 3);                                // the frame (row pair) whose line this lane helps to write
         const uint32_t r0 = 2u * F, r1 = 2u * F + 1u;
-        const int4 a = stage0[t * 256u + ((r0 ^ t) * 4u) + (p ^ ((r0 >> 1) & 3u))];
-        const int4 b = stage0[t * 256u + ((r1 ^ t) * 4u) + (p ^ ((r1 >> 1) & 3u))];
+        int4 a = stage0[t * 256u + ((r0 ^ t) * 4u) + (p ^ ((r0 >> 1) & 3u))];
+        int4 b = stage0[t * 256u + ((r1 ^ t) * 4u) + (p ^ ((r1 >> 1) & 3u))];
         const uint32_t o = (uint32_t)__shfl((int)M.rowoff, (int)r0, 64);
+        if (M.ms) cln_ms4(a, b);
         int4 w;                                                              // (left: low half, right: high half of each dword)
         w.x = (int32_t)clx_perm((uint32_t)b.x, (uint32_t)a.x, 0x05040100u); w.y = (int32_t)clx_perm((uint32_t)b.y, (uint32_t)a.y, 0x05040100u);
         w.z = (int32_t)clx_perm((uint32_t)b.z, (uint32_t)a.z, 0x05040100u); w.w = (int32_t)clx_perm((uint32_t)b.w, (uint32_t)a.w, 0x05040100u);
@@ -713,8 +730,45 @@ __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover&
     if (P24 && M.pcm16 == 3u) { cln_store_pcm24(stage0, M, t0, lane, 2u); return; }
     if (M.pcm16 == 2u) { cln_store_pcm16_mono(stage0, M, t0, lane, 2u); return; }
     if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 2u); return; }
+    if (M.ms) {
+        // both rows of a frame per lane (cln_ms4): lane 8 fh + q takes piece q & 3 of tile q >> 2 of frames fh, fh + 8, fh + 16, fh + 24 --
+        // as many reads and stores as below, four more instructions per pair of samples
+        clx_wave_sync();
+        uint32_t ln = (uint32_t)lane;
+        CLX_OPAQUE(ln);                                   // (worked out per call, as in cln_store_pcm16: nothing of this is kept across the decode loop)
+        const uint32_t fh = ln >> 3, q = ln & 7u, t = q >> 2;
+        const uint32_t ia = t * 256u + (((2u * fh) ^ t) * 4u) + ((q & 3u) ^ (fh & 3u));     // row position 2 fh ^ t; + 64 int4 per eight frames
+        const int4* const sa = stage0 + ia;
+        const int4* const sb = stage0 + (ia ^ 4u);                                            // row position (2 fh + 1) ^ t
+        const uint32_t toff = 4u * t0 + 16u * q, pa = 8u * fh;                               // (pa: lane 2 fh's place for ds_bpermute)
+        if (M.all_real) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                int4 a0 = sa[128 * half], b0 = sb[128 * half], a1 = sa[128 * half + 64], b1 = sb[128 * half + 64];
+                uint32_t o[4];
+                if (half == 0) clx_bperm4<0, 4, 64, 68>(pa, M.rowoff, o);
+                else           clx_bperm4<128, 132, 192, 196>(pa, M.rowoff, o);
+                cln_ms4(a0, b0); cln_ms4(a1, b1);
+                clx_store4x16_s(M.base, o[0] + toff, o[1] + toff, o[2] + toff, o[3] + toff, a0, b0, a1, b1);
+            }
+        } else {
+            uint32_t o[4][2];
+            clx_bperm2<0, 4>(pa, M.rowoff, o[0]); clx_bperm2<64, 68>(pa, M.rowoff, o[1]); clx_bperm2<128, 132>(pa, M.rowoff, o[2]); clx_bperm2<192, 196>(pa, M.rowoff, o[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int4 a = sa[64 * i], b = sb[64 * i];
+                cln_ms4(a, b);
+                if (o[i][0] != CLN_NO_ROW) clx_store1x16_s(M.base, o[i][0] + toff, a);       // (rows that do not exist are not written)
+                if (o[i][1] != CLN_NO_ROW) clx_store1x16_s(M.base, o[i][1] + toff, b);
+            }
+        }
+        clx_wave_sync();
+        return;
+    }
     clx_wave_sync();
-    const uint32_t h = (uint32_t)lane >> 3, q = (uint32_t)lane & 7u, t = q >> 2;
+    uint32_t ln = (uint32_t)lane;
+    CLX_OPAQUE(ln);                                       // (worked out per call, as in cln_store_pcm16: the decode loop keeps the places of ONE planar mover)
+    const uint32_t h = ln >> 3, q = ln & 7u, t = q >> 2;
     const int4* const src = stage0 + t * 256u + ((h ^ t) * 4u) + ((q & 3u) ^ ((h >> 1) & 3u));      // + 32 int4 per instruction (8 rows)
     const uint32_t toff = 4u * t0 + 16u * q;
 #pragma unroll
@@ -722,7 +776,9 @@ __device__ __forceinline__ void cln_store_pair(const int4* stage0, const LMover&
         int4 w[4];
         uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { w[j] = src[32 * (4 * half + j)]; o[j] = (uint32_t)__shfl((int)M.rowoff, (int)h + 8 * (4 * half + j), 64); }
+        for (int j = 0; j < 4; ++j) w[j] = src[32 * (4 * half + j)];
+        if (half == 0) clx_bperm4<0, 32, 64, 96>(4u * h, M.rowoff, o);                      // (rows h + 8 k: lanes' places 4 h + 32 k)
+        else           clx_bperm4<128, 160, 192, 224>(4u * h, M.rowoff, o);
 #ifndef CLN_NO_STORES
         if (M.all_real) clx_store4x16_s(M.base, o[0] + toff, o[1] + toff, o[2] + toff, o[3] + toff, w[0], w[1], w[2], w[3]);
         else {
@@ -741,6 +797,21 @@ __device__ __forceinline__ void cln_store_single(const int4* stage0, const LMove
     if (P24 && M.pcm16 == 3u) { cln_store_pcm24(stage0, M, t0, lane, 1u); return; }
     if (M.pcm16 == 2u) { cln_store_pcm16_mono(stage0, M, t0, lane, 1u); return; }
     if (M.pcm16) { cln_store_pcm16(stage0, M, t0, lane, 1u); return; }
+    if (M.ms) {                                           // (cln_ms4: lane 4 fh + q takes piece q of frames fh and fh + 16)
+        clx_wave_sync();
+        const uint32_t fh = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+#pragma unroll
+        for (uint32_t i = 0; i < 2u; ++i) {
+            const uint32_t r0 = 2u * (fh + 16u * i), r1 = r0 + 1u, sz = q ^ (fh & 3u);
+            int4 a = stage0[r0 * 4u + sz], b = stage0[r1 * 4u + sz];
+            const uint32_t oa = (uint32_t)__shfl((int)M.rowoff, (int)r0, 64), ob = (uint32_t)__shfl((int)M.rowoff, (int)r1, 64);
+            cln_ms4(a, b);
+            if (oa != CLN_NO_ROW) clx_store1x16_s(M.base, oa + 4u * t0 + 16u * q, a);
+            if (ob != CLN_NO_ROW) clx_store1x16_s(M.base, ob + 4u * t0 + 16u * q, b);
+        }
+        clx_wave_sync();
+        return;
+    }
     clx_wave_sync();
     const uint32_t h = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
 #pragma unroll
@@ -798,60 +869,23 @@ __device__ __forceinline__ void cln_finish4(const int32_t (&s0)[4], const Finish
     mine[b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
 }
 
-// the same for the turn's sixteen samples at once, at the END of the turn (the 16-bit tier: its turn stays one basic block, the
-// wave-uniform choice of the stereo form is made once, and the asm statements of the stereo forms stay out of the compiler's way
-// while it schedules the Rice and predictor work)
-// EIGHT: eight samples per statement, class by class: the plain adds and shifts run at twice the rate in runs of their own kind
-// (clx_ms_short8, round 6).  Not in the 12-tap build, whose register file has no room for eight outputs beside eight inputs.
-template <bool EIGHT>
-__device__ __forceinline__ void cln_finish16(const int32_t (&s)[16], const Finish& F, int4* mine, uint32_t sw) {
-    if (!EIGHT) {
-        if (F.ms_plain) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
-                int32_t y[4];
-                clx_ms_short4(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
-                mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
-            }
-        } else if (F.any_decor || F.any_wasted) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int32_t m[4] = { s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3] };
-                int32_t y[4];
-                clx_decor4_mad(m, y, F.mo, F.mt, F.mc);
-                mine[(uint32_t)b ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) mine[(uint32_t)b ^ sw] = make_int4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
-        }
-        return;
-    }
-    if (F.ms_plain) {
+// the 16-bit tier: every four of a turn goes into the stage as decoded, right behind its predictor steps (nothing of the turn's output stays in
+// registers); a wave with stereo forms other than plain mid/side pairs, or with wasted bits, takes the tile out of the stage again at the END of
+// the turn, eight samples per statement (clx_decor8_mad: any mix of forms, the shift included, four instructions per sample -- exact while a
+// sample and its shifted value fit 24 bits: the turn's range check, whose limit cln_run lowers by the lane's wasted bits), and puts it back.  Waves
+// of plain mid/side pairs have no stereo here at all: their movers undo it (cln_ms4).  The turn stays one basic block up to this wave-uniform
+// choice, and the asm statements of the stereo form stay out of the compiler's way while it schedules the Rice and predictor work.
+__device__ __forceinline__ void cln_finish16(const Finish& F, int4* mine, uint32_t sw) {
+    if (F.any_decor || F.any_wasted) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int32_t m[8] = { s[8 * h], s[8 * h + 1], s[8 * h + 2], s[8 * h + 3], s[8 * h + 4], s[8 * h + 5], s[8 * h + 6], s[8 * h + 7] };
-            int32_t y[8];
-            clx_ms_short8(m, y, F.sgn, 1u + (F.sgn & 1u));      // (exact below 2^29: part of the turn's range check)
-            mine[(uint32_t)(2 * h) ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
-            mine[(uint32_t)(2 * h + 1) ^ sw] = make_int4(y[4], y[5], y[6], y[7]);
-        }
-    } else if (F.any_decor || F.any_wasted) {
-        // any mix of stereo forms and wasted bits in the wave (round 5: four instructions per sample, the shift included, where the
-        // masked form took six and the shift a seventh).  Exact while a sample and its shifted value fit 24 bits: the turn's range
-        // check, whose limit cln_run lowers by the lane's wasted bits
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int32_t m[8] = { s[8 * h], s[8 * h + 1], s[8 * h + 2], s[8 * h + 3], s[8 * h + 4], s[8 * h + 5], s[8 * h + 6], s[8 * h + 7] };
+            const int4 u = mine[(uint32_t)(2 * h) ^ sw], v = mine[(uint32_t)(2 * h + 1) ^ sw];
+            const int32_t m[8] = { u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w };
             int32_t y[8];
             clx_decor8_mad(m, y, F.mo, F.mt, F.mc);
             mine[(uint32_t)(2 * h) ^ sw] = make_int4(y[0], y[1], y[2], y[3]);
             mine[(uint32_t)(2 * h + 1) ^ sw] = make_int4(y[4], y[5], y[6], y[7]);
         }
-    } else {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) mine[(uint32_t)b ^ sw] = make_int4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
     }
 }
 
@@ -906,7 +940,6 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
     uint32_t zmax = 0;                                // MODE 0: the longest run of zeros instead (v_ffbh as it comes: all ones for an empty register)
     int32_t hi = -0x7fffffff - 1, lo = 0x7fffffff;
     uint32_t pw = c.p;
-    int32_t S16[SPLIT ? 1 : 16];
     const uint32_t pb = 4u + rice2, esc = rice2 ? 31u : 15u;
     // The four's Rice codes are decoded first (that fixes where the next four starts), the next four's window is requested from the
     // ring, and only then does the predictor run over the four samples: the LDS round trip hides behind it.
@@ -1013,13 +1046,13 @@ __device__ __forceinline__ int cln_lean_turn(const uint32_t* row, const LRing& g
             else hw[2 * NP + i] = s;
             hi = s > hi ? s : hi; lo = s < lo ? s : lo;
             S4[ii] = s;
-            if (!SPLIT) S16[SPLIT ? 0 : i] = s;
         }
         CLX_OPAQUE(hi); CLX_OPAQUE(lo);
-        // stereo decorrelation and the stage: the split tier four by four (its register file is full), the others at the end
+        // the stage, four by four: the split tier with its stereo form, the 16-bit tier as decoded (cln_finish16)
         if (SPLIT) cln_finish4(S4, F, mine, sw, (uint32_t)b);
+        else mine[(uint32_t)b ^ sw] = make_int4(S4[0], S4[1], S4[2], S4[3]);
     }
-    if constexpr (!SPLIT) cln_finish16<(NP <= 4)>(S16, F, mine, sw);
+    if constexpr (!SPLIT) cln_finish16(F, mine, sw);
     // what was decoded is what the stream holds iff no code was longer than its window register, the last window lay inside the
     // ring's filled part and nothing reached past the end of the frame; the predictor was exact iff the outputs (the next turn's
     // history) stayed inside the range
@@ -1091,7 +1124,11 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
         }
         if (!ring_ok) { cln_reset(buf, g, row, (cur.p - 1u) >> 5, CR, crc); ring_ok = true; }
         else if (cln_pump_now(calm, (t0 & 16u) == 0u)) {      // (the turns at whose start a pair of tiles leaves: the stores stay right in front of the landing's wait)
-            cln_land(g, row, CR, crc); cln_request(buf, g, cur.p, !calm || (t0 & 96u) == 0u);      // (calm: every fourth pump -- the pumps are at the even turns)
+            // (calm: a second and a third granule at every fourth pump -- the pumps are at the even turns.  The 12-tap build has two granules in
+            //  flight at most -- with a third the compiler spills it across the turn, 168 registers being what they are -- and asks for the second
+            //  at every other pump: 1.5 granules per pump either way, what a calm lane uses at most)
+            constexpr int MAXP = NP == 6 ? 2 : 3;
+            cln_land<MAXP>(g, row, CR, crc); cln_request<MAXP>(buf, g, cur.p, !calm || (t0 & (NP == 6 ? 32u : 96u)) == 0u);
             CLX_STAT(46, 1);
         }
 #ifdef CLN_LAND_FIRST
@@ -1400,7 +1437,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     const uint32_t next_sp = (active && !last_ch) ? clx_peek_u32(&sf_start[cslot + 1u]) : 0xffffffffu;
     // a calm wave: no lane's subframe holds more than 6 bits per sample -- its ring is pumped every other turn (cln_pump_now)
     const uint32_t sf_bits = !active ? 0u : last_ch ? o + fr.limit_bits - pos0 : next_sp - pos0;       // (a failed or unbounded one: huge)
-    const bool calm = __all(sf_bits <= 6u * bs);
+    const bool calm = CLN_RING >= 24u && __all(sf_bits <= 6u * bs);
     LCrc CR;
     CR.c.r = 0u; CR.c.x = 0u; CR.next = 0u; CR.db = CLN_CRC_NONE;
     bool crc_mine = false, crc_last = false;
@@ -1440,7 +1477,11 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     M.all_real = __all(active);
     M.pcm16 = pcm24 ? 3u : !pcm16 ? 0u : nch0 == 1u ? 2u : 1u;
     (void)dump_all;                                         // (rows that do not exist are not written: no dump slots here)
-    const Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
+    Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
+    // every lane in a mid/side pair, no wasted bits (the 16-bit tier; planar or interleaved 16-bit output): the stage takes mid and side as
+    // they are decoded and the movers undo the pair (cln_ms4) -- to the turns, the slow turn and the prologue such a wave has no stereo at all
+    M.ms = !SPLIT && F.ms_plain && M.pcm16 <= 1u;
+    if (M.ms) { F.all_ms = false; F.any_decor = false; F.ms_plain = false; }
 
     // ---- careful prologue (as clx_lanes_body's): warm-up samples, the transition, the first residuals -- one sample per turn of
     //      a rolled loop, i64 predictor; leaves every lane on a multiple of 16 samples, past its transition
@@ -1471,7 +1512,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
-        if ((i & 15u) == 0u) cln_flush<SPLIT>(T, stage0, M, lane);
+        if constexpr (SPLIT) { if ((i & 15u) == 0u) cln_flush<SPLIT>(T, stage0, M, lane); }      // (the 16-bit tier's prologue is ONE tile: i0 = 16 for <= 12 taps)
         reinterpret_cast<int32_t*>(cln_mine(stage0, i, lane))[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
         if ((i & 15u) == 15u) cln_done(T, i & ~15u);
     }

@@ -184,6 +184,25 @@ __device__ __forceinline__ void clx_store4x16_s(uint64_t base, uint32_t o0, uint
                  "global_store_dwordx4 %3, %7, %8" CLX_STORE_POLICY "\n\ts_nop 1"
                  :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(a), "v"(b), "v"(c), "v"(d), "s"(base) : "memory");
 }
+// Four (two) ds_bpermute_b32 off ONE address register: r[k] = the value of v in lane (byte_addr + Ok) / 4.  The offsets are instruction fields;
+// the compiler's own form of __shfl(v, lane term + constant) computes an address register per read and keeps all of them alive across
+// the decode loop (the movers' eight row places: eight registers of the 168, some of them spilled).  byte_addr + Ok < 256.
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void clx_bperm4(uint32_t byte_addr, uint32_t v, uint32_t (&r)[4]) {
+    asm volatile("ds_bpermute_b32 %0, %4, %5 offset:%6\n\tds_bpermute_b32 %1, %4, %5 offset:%7\n\tds_bpermute_b32 %2, %4, %5 offset:%8\n\t"
+                 "ds_bpermute_b32 %3, %4, %5 offset:%9\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(byte_addr), "v"(v), "n"(O0), "n"(O1), "n"(O2), "n"(O3));
+}
+template <int O0, int O1>
+__device__ __forceinline__ void clx_bperm2(uint32_t byte_addr, uint32_t v, uint32_t (&r)[2]) {
+    asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%4\n\tds_bpermute_b32 %1, %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(byte_addr), "v"(v), "n"(O0), "n"(O1));
+}
+__device__ __forceinline__ void clx_store2x16_s(uint64_t base, uint32_t o0, uint32_t o1, const int4& w0, const int4& w1) {
+    const clx_i32x4 a = { w0.x, w0.y, w0.z, w0.w }, b = { w1.x, w1.y, w1.z, w1.w };
+    asm volatile("global_store_dwordx4 %0, %2, %4" CLX_STORE_POLICY "\n\tglobal_store_dwordx4 %1, %3, %4" CLX_STORE_POLICY "\n\ts_nop 1"
+                 :: "v"(o0), "v"(o1), "v"(a), "v"(b), "s"(base) : "memory");
+}
 __device__ __forceinline__ void clx_store1x16_s(uint64_t base, uint32_t o, const int4& w) {
     const clx_i32x4 a = { w.x, w.y, w.z, w.w };
     asm volatile("global_store_dwordx4 %0, %1, %2" CLX_STORE_POLICY "\n\ts_nop 1" :: "v"(o), "v"(a), "s"(base) : "memory");
@@ -214,47 +233,6 @@ __device__ __forceinline__ void clx_ms_short4(const int32_t (&y)[4], int32_t (&o
                  "v_add_u32_dpp %3, %8, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
                  : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
                  : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(sgn), "v"(c));
-}
-// The same for EIGHT samples, instruction class by instruction class (round 6): eight DPP reads, then the sixteen v_add / v_ashrrev in
-// a row, then eight DPP adds.  The plain VOP2 adds, subtractions and shifts issue at twice the rate of everything else -- but only in
-// runs of their own kind: tools/ubench/coissue.hip, profiles/r06_ubench_coissue.txt: 8 S + 8 F in runs of eight 60.7 cycles per wave
-// at 8 waves per SIMD and 74.6 / 77.9 at 2 / 3, alternating 74.2 and 108.9 / 99.2 -- the form above (a run of two) pays full price.
-__device__ __forceinline__ void clx_ms_short8(const int32_t (&y)[8], int32_t (&out)[8], uint32_t sgn, uint32_t c) {
-    asm volatile("s_nop 1\n\t"
-                 "v_xor_b32_dpp %0, %8, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_xor_b32_dpp %1, %9, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_xor_b32_dpp %2, %10, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_xor_b32_dpp %3, %11, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_xor_b32_dpp %4, %12, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_xor_b32_dpp %5, %13, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_xor_b32_dpp %6, %14, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_xor_b32_dpp %7, %15, %16 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32 %0, %0, %17\n\t"
-                 "v_add_u32 %1, %1, %17\n\t"
-                 "v_add_u32 %2, %2, %17\n\t"
-                 "v_add_u32 %3, %3, %17\n\t"
-                 "v_add_u32 %4, %4, %17\n\t"
-                 "v_add_u32 %5, %5, %17\n\t"
-                 "v_add_u32 %6, %6, %17\n\t"
-                 "v_add_u32 %7, %7, %17\n\t"
-                 "v_ashrrev_i32 %0, 1, %0\n\t"
-                 "v_ashrrev_i32 %1, 1, %1\n\t"
-                 "v_ashrrev_i32 %2, 1, %2\n\t"
-                 "v_ashrrev_i32 %3, 1, %3\n\t"
-                 "v_ashrrev_i32 %4, 1, %4\n\t"
-                 "v_ashrrev_i32 %5, 1, %5\n\t"
-                 "v_ashrrev_i32 %6, 1, %6\n\t"
-                 "v_ashrrev_i32 %7, 1, %7\n\t"
-                 "v_add_u32_dpp %0, %8, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %1, %9, %1 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %2, %10, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %3, %11, %3 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %4, %12, %4 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %5, %13, %5 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %6, %14, %6 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %7, %15, %7 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
-                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
-                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(sgn), "v"(c));
 }
 // v_ffbh_u32 as it comes: the number of leading zeros, 0xffffffff for 0 (__clz adds a v_min for that case; __builtin_clz leaves it
 // undefined).  Not volatile: the compiler schedules it like any other instruction.
@@ -294,7 +272,9 @@ __device__ __forceinline__ void clx_decor4_mad(const int32_t (&y)[4], int32_t (&
                  : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(t)
                  : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(mo), "v"(mt), "v"(c));
 }
-// The same for eight samples, class by class (clx_ms_short8): the eight v_ashrrev in a row.  (own * mo + other * mt + c = other * mt + c, then
+// The same for eight samples, instruction class by instruction class (round 6): the plain VOP2 adds, subtractions and shifts issue at
+// twice the rate of everything else -- but only in runs of their own kind (tools/ubench/coissue.hip, profiles/r06_ubench_coissue.txt: 8 S + 8 F
+// in runs of eight 60.7 cycles per wave at 8 waves per SIMD and 74.6 / 77.9 at 2 / 3, alternating 74.2 and 108.9 / 99.2) -- so the eight v_ashrrev sit in a row.  (own * mo + other * mt + c = other * mt + c, then
 // + own * mo: the partner's value lands in the output register, no temporary.)
 __device__ __forceinline__ void clx_decor8_mad(const int32_t (&y)[8], int32_t (&out)[8], int32_t mo, int32_t mt, int32_t c) {
     asm volatile("s_nop 1\n\t"

@@ -795,3 +795,36 @@ def check_ms_wild(oracle, backend):
     assert int(np.abs(ref.astype(np.int64)).max()) > (1 << 29), "the samples were meant to run away"
     assert np.array_equal(np.asarray(out)[:w.pcm.size], ref)
     return int(np.count_nonzero(ref != w.pcm))
+
+
+def ms_mover_workload(lone_tail=False):
+    """Waves in which EVERY lane belongs to a plain mid/side pair (no wasted bits): clx_k_lean stages mid and side as decoded and its movers
+    undo the pair (cln_ms4, round 6).  Whole pairs of tiles and a lone last tile (block sizes 16 mod 32), the shortest blocks, side channels
+    loud enough for wide turns and for a 17th bit, every predictor build (<= 4 / 8 / 12 taps), a verbatim channel among them; families of whole
+    waves, and a ragged last wave (rows that do not exist: the movers' per-row stores) -- of whole pairs of tiles, or (`lone_tail`) of a
+    block size that ends in a lone tile."""
+    S = synth
+    rng = np.random.default_rng(2025)
+    parts = []
+    fams = [(4096, 64, 8, 1.0), (4096 + 16, 32, 12, 1.0), (48, 64, 4, 1.0), (1024, 32, 8, 9.0), (2048, 32, 12, 9.0), (32, 64, 2, 1.0)]
+    fams.append((1024 + 16, 33, 8, 1.0) if lone_tail else (4096, 40, 8, 1.0))
+    for bs, n, omax, loud in fams:
+        pcm = np.empty((n, 2, bs), dtype=np.int32)
+        fps = []
+        for i in range(n):
+            L, R, g = S.pcm_music_like(int(rng.integers(0, 1 << 20)) + i, bs)
+            L = np.clip(L * loud, -32768, 32767).astype(np.int32)
+            R = np.clip(R * (-loud if loud > 1.0 and i % 2 else loud), -32768, 32767).astype(np.int32)      # (out of phase: the side channel is the loud one)
+            fp = S.FrameParams(3, 0, i)
+            for c in range(2):
+                po = min(int(g.integers(0, 5)), max(0, int(np.log2(bs)) - 5))
+                while (bs >> po) % 4:                        # (partitions of whole fours: anything else is the slow turn's, and then the general kernels')
+                    po -= 1
+                fp.sf[c] = S.sf(S.SF_LPC if (i + c) % 4 else S.SF_FIXED, int(g.integers(1, omax + 1)) if (i + c) % 4 else int(g.integers(0, min(omax, 4) + 1)),
+                                int(g.integers(8, 15)), po)
+            if bs == 48 and i % 9 == 4:
+                fp.sf[1] = S.sf(S.SF_VERBATIM, 0, 0, 0)
+            pcm[i, 0], pcm[i, 1] = L, R
+            fps.append(fp)
+        parts.append(S.encode_frames("mid/side bs%d" % bs, pcm, 2, bs, 16, fps))
+    return S.concat("mid/side for the movers", parts)

@@ -291,3 +291,19 @@ def test_pool_tickets_on_the_gpu(oracle):
             lo, hi = int(w.out_offs[i]), int(w.out_offs[i]) + int(w.channels[i]) * int(w.block_sizes[i])
             assert np.array_equal(got[lo:hi], ref[lo:hi]), (k, int(i))
     batch.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_mid_side_undone_by_the_movers_on_the_gpu(oracle):
+    """parity_cases.ms_mover_workload on the GPU: waves of plain mid/side pairs, whose turns stage mid and side as decoded and whose movers write
+    left and right (cln_ms4, round 6) -- planar and CLX_OUT_PCM16, a ragged last wave of whole pairs of tiles and one that ends in a lone tile,
+    damaged frames, the frames' CRC-16."""
+    from parity_util import GpuBackend
+    ctx = cx.Context(0, wait_s=120)
+    for lone_tail in (False, True):
+        w = pc.ms_mover_workload(lone_tail)
+        pc.check_workload(oracle, GpuBackend(ctx, cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
+        assert pc.check_pcm16(oracle, GpuBackend(ctx, cx.OUT_PCM16), w) == w.n
+        assert pc.check_pcm16(oracle, GpuBackend(ctx, cx.OUT_PCM16), w, damage=0.2, seed=5) < w.n
+    pc.check_crc_in_batch(oracle, GpuBackend(ctx, cx.PATH_LANES | cx.LANES_FUSED), w, seed=12)
+    ctx.close()

@@ -543,3 +543,25 @@ def test_sim_narrow_output_of_mono_frames(oracle):
     assert pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w) == w.n
     assert stats[52] >= 2 and stats[49] <= 2, (int(stats[52]), int(stats[49]))      # groups the lean kernel wrote itself | groups left (where block sizes meet)
     assert pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w, damage=0.25, seed=9) < w.n
+
+
+def test_sim_mid_side_undone_by_the_movers(oracle):
+    """parity_cases.ms_mover_workload: waves of plain mid/side pairs -- clx_k_lean's turns stage mid and side as decoded, its movers write left and
+    right (cln_ms4: four instructions per pair of samples where the lanes took four per sample each).  Planar and CLX_OUT_PCM16, intact and
+    with damaged frames, a ragged last wave of whole pairs of tiles and one that ends in a lone tile; the lean kernel keeps every group."""
+    import ctypes as C
+    import simlib
+    simlib.build()
+    stats = (C.c_uint64 * 64).in_dll(simlib.lib(), "sim_stats")
+    for lone_tail in (False, True):
+        w = pc.ms_mover_workload(lone_tail)
+        for i in range(64):
+            stats[i] = 0
+        pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
+        assert stats[58] >= 64 and stats[49] <= 1, (int(stats[58]), int(stats[49]))   # wide turns (per lane): the loud families | groups left to the general kernels (a wave that gave up)
+        for i in range(64):
+            stats[i] = 0
+        assert pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w) == w.n
+        assert stats[52] >= 10 and stats[49] <= 1, (int(stats[52]), int(stats[49]))   # groups the lean kernel wrote itself | groups left
+        assert pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w, damage=0.2, seed=5) < w.n
+    pc.check_crc_in_batch(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, seed=12)

@@ -58,6 +58,16 @@ static inline void clx_store4x16(int32_t* p0, int32_t* p1, int32_t* p2, int32_t*
     *reinterpret_cast<int4*>(p0) = w0; *reinterpret_cast<int4*>(p1) = w1; *reinterpret_cast<int4*>(p2) = w2; *reinterpret_cast<int4*>(p3) = w3;
 }
 static inline void clx_store1x16_s(uint64_t base, uint32_t o, const int4& w) { *reinterpret_cast<int4*>((uintptr_t)(base + o)) = w; }
+template <int O0, int O1, int O2, int O3>
+static inline void clx_bperm4(uint32_t byte_addr, uint32_t v, uint32_t (&r)[4]) {
+    r[0] = (uint32_t)__shfl(v, (int)(((byte_addr + O0) >> 2) & 63u), 64); r[1] = (uint32_t)__shfl(v, (int)(((byte_addr + O1) >> 2) & 63u), 64);
+    r[2] = (uint32_t)__shfl(v, (int)(((byte_addr + O2) >> 2) & 63u), 64); r[3] = (uint32_t)__shfl(v, (int)(((byte_addr + O3) >> 2) & 63u), 64);
+}
+template <int O0, int O1>
+static inline void clx_bperm2(uint32_t byte_addr, uint32_t v, uint32_t (&r)[2]) {
+    r[0] = (uint32_t)__shfl(v, (int)(((byte_addr + O0) >> 2) & 63u), 64); r[1] = (uint32_t)__shfl(v, (int)(((byte_addr + O1) >> 2) & 63u), 64);
+}
+static inline void clx_store2x16_s(uint64_t base, uint32_t o0, uint32_t o1, const int4& w0, const int4& w1) { clx_store1x16_s(base, o0, w0); clx_store1x16_s(base, o1, w1); }
 static inline void clx_store4x16_s(uint64_t base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
     clx_store1x16_s(base, o0, w0); clx_store1x16_s(base, o1, w1); clx_store1x16_s(base, o2, w2); clx_store1x16_s(base, o3, w3);
 }
@@ -66,7 +76,6 @@ static inline int32_t clx_ms_short_(int line, int32_t y, uint32_t sgn, uint32_t 
     const uint32_t mid = (uint32_t)wavesim::update_dpp_(line, 0, y, 0xA0, 0xF, 0xF, false);
     return (int32_t)(mid + (uint32_t)((int32_t)((side ^ sgn) + c) >> 1));
 }
-#define clx_ms_short8(y, out, sgn, c) do { for (int q_ = 0; q_ < 8; ++q_) (out)[q_] = clx_ms_short_(__LINE__, (y)[q_], (sgn), (c)); } while (0)
 #define clx_ms_short4(y, out, sgn, c) do { for (int q_ = 0; q_ < 4; ++q_) (out)[q_] = clx_ms_short_(__LINE__, (y)[q_], (sgn), (c)); } while (0)
 static inline uint32_t clx_ffbh(uint32_t x) { return x ? (uint32_t)__builtin_clz(x) : 0xffffffffu; }
 static inline int32_t clx_mad24_(int32_t a, int32_t b, int32_t c) {      // v_mad_i32_i24: the low 24 bits of a and b, sign-extended
