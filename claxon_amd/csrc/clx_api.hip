@@ -352,6 +352,9 @@ struct clx_batch {
     LaunchRef flight_launch[CLX_SUBMIT_DEPTH] = {};    // the merged launch that used a flight's scratch last (count 0: none)
     uint64_t n_merged = 0;
     uint64_t n_submitted = 0;
+    int first_merge = 0;               // runs in the first merged launch behind a wait (0: `merge`); tune_prio: internal stream priorities (measurement builds)
+    int tune_prio = 0;
+    uint64_t launches_since_wait = 0;
     int last_slot = -1;              // flight of the most recent pipelined submission (-1: the last run was a plain clx_batch_run)
 };
 
@@ -659,6 +662,9 @@ extern "C" int clx_batch_create(clx_ctx* ctx, const clx_frame_desc* frames, size
         if (m >= 1 && m <= CLX_MAX_MERGE) { b->merge = m; b->merge_tuned = true; }
         if (st >= 1 && st <= clx_batch::kMaxStreams) b->n_streams = st;
         if (b->merge * b->n_streams > clx_batch::kDepthLanes) b->n_streams = std::max(1, clx_batch::kDepthLanes / b->merge);
+        const char* ef = std::getenv("CLX_TUNE_FIRST"); const char* ep = std::getenv("CLX_TUNE_PRIO");
+        if (ef && std::atoi(ef) >= 1 && std::atoi(ef) <= CLX_MAX_MERGE) b->first_merge = std::atoi(ef);
+        if (ep) b->tune_prio = std::atoi(ep);
     }
 #endif
     if (batch_plan(b, frames, n, out_sample_offsets, flags) != CLX_OK) { clx_batch_destroy(b); return CLX_API_ERROR; }
@@ -959,7 +965,13 @@ int launch_pending(clx_batch* b, bool inputs_ready) {
         // the stream, its events and its ticket counter into locals first: the batch gets them only when ALL of them exist (a stream
         // without its events would make every later launch on it fail)
         hipStream_t st = nullptr; hipEvent_t e_in = nullptr, e_done[clx_batch::kEvRing] = {}; clx_pool_state* pool = nullptr;
-        hipError_t e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        hipError_t e0 = hipSuccess;
+        if (b->tune_prio) {            // (measurement builds: the even streams above the odd ones, or the other way round)
+            int lo_p = 0, hi_p = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);       // (least, greatest priority: greatest is the smaller number)
+            const bool high = ((k & 1) == 0) == (b->tune_prio == 1);
+            e0 = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, high ? hi_p : lo_p);
+        } else e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (e0 == hipSuccess) e0 = hipMalloc((void**)&pool, sizeof(clx_pool_state));
         if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&e_in, hipEventDisableTiming);
         for (auto& e : e_done) if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -1047,6 +1059,7 @@ int launch_pending(clx_batch* b, bool inputs_ready) {
     b->m_unwaited[k] = true;
     b->pend.clear();
     ++b->n_merged;
+    ++b->launches_since_wait;
     return CLX_OK;
 }
 // make `stream` wait for every pipelined submission that nobody has waited for yet (what is pending is launched first)
@@ -1057,6 +1070,7 @@ int wait_flights(clx_batch* b, hipStream_t stream) {
         b->ctx->last_error = "an earlier merged launch of this batch failed; its submissions were dropped";
         return CLX_API_ERROR;
     }
+    b->launches_since_wait = 0;
     for (int k = 0; k < clx_batch::kMaxStreams; ++k)
         if (b->m_unwaited[k]) { HIP_TRY(b->ctx, hipStreamWaitEvent(stream, b->m_done[k][(b->m_count[k] - 1) % clx_batch::kEvRing], 0)); b->m_unwaited[k] = false; }
     for (auto& F : b->flight)
@@ -1246,7 +1260,8 @@ extern "C" int clx_batch_submit(clx_batch* b, const uint8_t* d_arena, size_t are
         b->last_stream = stream;
         ++b->n_submitted;
         b->ev_valid = false;
-        if ((int)b->pend.size() >= b->merge && launch_pending(b) != CLX_OK) return CLX_API_ERROR;
+        const int want = (b->first_merge > 0 && b->launches_since_wait == 0) ? std::min(b->first_merge, b->merge) : b->merge;
+        if ((int)b->pend.size() >= want && launch_pending(b) != CLX_OK) return CLX_API_ERROR;
         return CLX_OK;
     }
     // ---- wave kernels: a whole run on the flight's own stream

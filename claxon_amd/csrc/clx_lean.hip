@@ -1480,7 +1480,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     Finish F = clx_lfinish_setup(n, h.kind == 0u ? 0u : h.wasted, decor, pair_ok, lane);      // (a constant's wasted bits are folded into it below)
     // every lane in a mid/side pair, no wasted bits (the 16-bit tier; planar or interleaved 16-bit output): the stage takes mid and side as
     // they are decoded and the movers undo the pair (cln_ms4) -- to the turns, the slow turn and the prologue such a wave has no stereo at all
-    M.ms = !SPLIT && F.ms_plain && M.pcm16 <= 1u;
+    M.ms = F.ms_plain && M.pcm16 <= 1u;
     if (M.ms) { F.all_ms = false; F.any_decor = false; F.ms_plain = false; }
 
     // ---- careful prologue (as clx_lanes_body's): warm-up samples, the transition, the first residuals -- one sample per turn of

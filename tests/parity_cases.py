@@ -828,3 +828,30 @@ def ms_mover_workload(lone_tail=False):
             fps.append(fp)
         parts.append(S.encode_frames("mid/side bs%d" % bs, pcm, 2, bs, 16, fps))
     return S.concat("mid/side for the movers", parts)
+
+
+def ms_mover24_workload():
+    """The same for the split tier (clx_k_lean24): waves of plain mid/side pairs of 24- and 20-bit audio, <= 12 and <= 32 taps, whole pairs of tiles
+    and a lone last tile, a ragged last wave."""
+    S = synth
+    rng = np.random.default_rng(2424)
+    parts = []
+    for bs, n, omax, bits in ((1024, 32, 12, 24), (1024 + 16, 32, 32, 24), (4096, 32, 32, 24), (512, 32, 32, 20), (1024, 40, 32, 24)):
+        pcm = np.empty((n, 2, bs), dtype=np.int32)
+        fps = []
+        lim = 1 << (bits - 1)
+        for i in range(n):
+            L, R, g = S.pcm_music_like(int(rng.integers(0, 1 << 20)) + i, bs)
+            k = 1 << (bits - 16)
+            pcm[i, 0] = np.clip(L * k, -lim, lim - 1)
+            pcm[i, 1] = np.clip(R * (-k if i % 3 == 0 else k), -lim, lim - 1)                 # (every third frame out of phase: a loud side channel)
+            fp = S.FrameParams(3, 0, i)
+            for c in range(2):
+                po = min(int(g.integers(0, 5)), max(0, int(np.log2(bs)) - 5))
+                while (bs >> po) % 4:
+                    po -= 1
+                fp.sf[c] = S.sf(S.SF_LPC if (i + c) % 5 else S.SF_FIXED, int(g.integers(1 if omax <= 12 else 9, omax + 1)) if (i + c) % 5 else int(g.integers(0, 5)),
+                                int(g.integers(8, 16)), po, force_rice2=int(g.uniform() < 0.3))
+            fps.append(fp)
+        parts.append(S.encode_frames("mid/side %d bits bs%d" % (bits, bs), pcm, 2, bs, bits, fps))
+    return S.concat("mid/side for the split tier's movers", parts)

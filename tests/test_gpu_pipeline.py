@@ -306,4 +306,7 @@ def test_mid_side_undone_by_the_movers_on_the_gpu(oracle):
         assert pc.check_pcm16(oracle, GpuBackend(ctx, cx.OUT_PCM16), w) == w.n
         assert pc.check_pcm16(oracle, GpuBackend(ctx, cx.OUT_PCM16), w, damage=0.2, seed=5) < w.n
     pc.check_crc_in_batch(oracle, GpuBackend(ctx, cx.PATH_LANES | cx.LANES_FUSED), w, seed=12)
+    w = pc.ms_mover24_workload()                                                      # (the split tier's waves of such pairs: the same movers)
+    pc.check_workload(oracle, GpuBackend(ctx, cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
+    pc.check_crc_in_batch(oracle, GpuBackend(ctx, cx.PATH_LANES | cx.LANES_FUSED), w, seed=13)
     ctx.close()

@@ -565,3 +565,10 @@ def test_sim_mid_side_undone_by_the_movers(oracle):
         assert stats[52] >= 10 and stats[49] <= 1, (int(stats[52]), int(stats[49]))   # groups the lean kernel wrote itself | groups left
         assert pc.check_pcm16(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED | cx.OUT_PCM16), w, damage=0.2, seed=5) < w.n
     pc.check_crc_in_batch(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, seed=12)
+    # the split tier's waves of plain mid/side pairs (24- and 20-bit audio): the same movers
+    w = pc.ms_mover24_workload()
+    for i in range(64):
+        stats[i] = 0
+    pc.check_workload(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, verify_crc=True)
+    assert stats[49] <= 1, int(stats[49])                                             # groups left to the general kernels
+    pc.check_crc_in_batch(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), w, seed=13)
