@@ -633,6 +633,11 @@ struct LMover {
 //     left = ((mid << 1 | side & 1) + side) >> 1 = mid + ((side + 1) >> 1)        right = left - side        (frame.rs:382-384)
 // is four plain instructions per PAIR of samples.  So in waves in which every lane belongs to a mid/side pair without wasted bits the
 // turns stage what they decoded and the movers do this: two instructions per sample less.  a: mid -> left, b: side -> right.
+// (The short form is the reference's wrapping arithmetic while nothing wraps: mid and side inside [-2^29, 2^29).  The lean and wide turns' range
+// checks are far stricter; the prologue and the slow turn, which stage whatever a stream decodes to, look at what they stage and give the
+// group up beyond it -- a damaged or crafted stream: the general kernels' form of the stereo step is exact for every value.)
+#define CLN_MS_RANGE (1 << 29)
+__device__ __forceinline__ bool cln_ms_wild(int32_t s) { return (uint32_t)s + (uint32_t)CLN_MS_RANGE >= 2u * (uint32_t)CLN_MS_RANGE; }
 __device__ __forceinline__ void cln_ms4(int4& a, int4& b) {
     const int32_t tx = (b.x + 1) >> 1, ty = (b.y + 1) >> 1, tz = (b.z + 1) >> 1, tw = (b.w + 1) >> 1;
     a.x += tx; a.y += ty; a.z += tz; a.w += tw;
@@ -1182,6 +1187,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
         if (++nslow > CLN_SLOW_BUDGET && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // (wave-uniform; not when the end is near anyway)
         // ---- slow turn: sixteen samples one by one, generic reader, i64 predictor (taps beyond the order are zero)
         int32_t* const ys = reinterpret_cast<int32_t*>(mine);
+        bool wild = false;
 #pragma unroll 1
         for (uint32_t ii = 0; ii < 16u; ++ii) {
             int32_t x = 0;
@@ -1193,9 +1199,11 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
 #pragma unroll
             for (int j = 2 * NP - 1; j > 0; --j) H[j] = H[j - 1];
             H[0] = (uint32_t)s;
-            const int32_t v = clx_lfinish(s, F);
+            const int32_t v = clx_lfinish(s, F);             // (a wave of plain mid/side pairs has no stereo form here: its movers', cln_ms4)
+            wild = wild || cln_ms_wild(s);
             ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
         }
+        if (M.ms && __any(live && wild)) return false;       // (however near the end: the movers' short form is not the reference's out there)
         cln_done(T, t0);
         ring_ok = false;                                  // the position moved without the ring
     }
@@ -1293,6 +1301,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         int32_t U[2 * NP];
         cln_unpack12<NP>(H, U);
         int32_t* const ys = reinterpret_cast<int32_t*>(mine);
+        bool wild = false;
 #pragma unroll 1
         for (uint32_t ii = 0; ii < 16u; ++ii) {
             int32_t x = 0;
@@ -1305,8 +1314,10 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
             for (int j = 2 * NP - 1; j > 0; --j) U[j] = U[j - 1];
             U[0] = s;
             const int32_t v = clx_lfinish(s, F);
+            wild = wild || cln_ms_wild(s);
             ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
         }
+        if (M.ms && __any(live && wild)) return false;       // (as cln_body's: the movers' short form is not the reference's out there)
         bool in = true;
 #pragma unroll
         for (int j = 0; j < 2 * NP; ++j) in = in && U[j] < lim && U[j] >= -lim;
@@ -1503,6 +1514,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     LTile T = { 0u, 0u };
     int4* const stage0 = &L.stage[0][0][0];
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
+    bool wild = false;                                      // M.ms: a sample outside the range in which cln_ms4 is the reference's step
 #pragma unroll 1
     for (uint32_t i = 0; i < i0; ++i) {
         const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
@@ -1512,9 +1524,15 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
+        wild = wild || cln_ms_wild(s);
         if constexpr (SPLIT) { if ((i & 15u) == 0u) cln_flush<SPLIT>(T, stage0, M, lane); }      // (the 16-bit tier's prologue is ONE tile: i0 = 16 for <= 12 taps)
         reinterpret_cast<int32_t*>(cln_mine(stage0, i, lane))[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
         if ((i & 15u) == 15u) cln_done(T, i & ~15u);
+    }
+    if (M.ms && __any(n != 0u && wild)) {                  // (a damaged or crafted stream: clx_k_lanes decodes the group, its stereo step is exact for every value)
+        if (lane == 0) taken[bx] = 0u;
+        CLX_STAT(SPLIT ? 11 : 57, 1);
+        return;
     }
     // ---- steady state
     LRing g;

@@ -783,8 +783,9 @@ def ms_wild_workload(n=96, bs=1024, seed=31337):
     return w, arena
 
 
-def check_ms_wild(oracle, backend):
-    w, arena = ms_wild_workload()
+def check_ms_wild(oracle, backend, bs=1024):
+    """(bs: short blocks -- 256 -- are the ones whose waves never give a group up by the slow turns' budget: 'not when the end is near'.)"""
+    w, arena = ms_wild_workload(bs=bs)
     descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
     out, res = backend.decode(arena, w.arena_len, descs, w.out_offs, False, fill=0x5a5a5a5a)
     ref = np.zeros(w.pcm.size, dtype=np.int32)

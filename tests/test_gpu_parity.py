@@ -50,6 +50,8 @@ def test_gpu_mid_side_that_runs_away(oracle, gpu):
     """parity_cases.ms_wild_workload: mid/side streams whose samples run away past every range check (and wrap): clx_k_lean's waves give
     them up, the general kernels decode them -- the oracle's wrapping arithmetic everywhere, with every kernel selection"""
     assert pc.check_ms_wild(oracle, gpu) > 0
+    for bs in (256, 64):       # (short blocks, whose groups the slow turns' budget never gives up: the prologue and the slow turn do, by what they stage)
+        assert pc.check_ms_wild(oracle, gpu, bs=bs) > 0
 
 
 def test_gpu_edges(oracle, gpu):

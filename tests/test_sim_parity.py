@@ -411,6 +411,10 @@ def test_sim_mid_side_that_runs_away_is_left_to_the_general_kernels(oracle):
     assert changed > 0
     given_up, taken = stats[57] // 64, stats[52]
     assert (given_up, taken) == (2, 1), (given_up, taken)                  # three waves: two run away and are given up, one stays
+    # short blocks: the slow turns' budget never gives such a group up ("not when the end is near") -- since the movers undo mid/side with
+    # the short form (cln_ms4, round 6), the slow turn and the prologue do: they look at what they stage
+    for bs in (256, 64):
+        assert pc.check_ms_wild(oracle, SimBackend(cx.PATH_LANES | cx.LANES_FUSED), bs=bs) > 0
     # the narrow output of the same streams (the low halves of the same samples)
     w, arena = pc.ms_wild_workload()
     descs, _ = cx.descs_from_offsets(w.arena[:w.arena_len], w.offs, w.lens, check_crc=False)
