@@ -637,7 +637,10 @@ struct LMover {
 // checks are far stricter; the prologue and the slow turn, which stage whatever a stream decodes to, look at what they stage and give the
 // group up beyond it -- a damaged or crafted stream: the general kernels' form of the stereo step is exact for every value.)
 #define CLN_MS_RANGE (1 << 29)
-__device__ __forceinline__ bool cln_ms_wild(int32_t s) { return (uint32_t)s + (uint32_t)CLN_MS_RANGE >= 2u * (uint32_t)CLN_MS_RANGE; }
+// (gathered per lane in a register -- bit 31 of the sum: some sample had bit 30 or 31 set in s + 2^29, i.e. lay outside the range -- and voted on once
+//  behind the loop.  As a bool carried through the prologue's loop, whose trip count the compiler takes for divergent, the HEAD of round 6 faulted on
+//  the GPU -- every wave's rows written through a bad offset -- while the simulator agreed with the oracle; this form does not.)
+__device__ __forceinline__ uint32_t cln_ms_wild(int32_t s) { const uint32_t t = (uint32_t)s + (uint32_t)CLN_MS_RANGE; return t | (t << 1); }
 __device__ __forceinline__ void cln_ms4(int4& a, int4& b) {
     const int32_t tx = (b.x + 1) >> 1, ty = (b.y + 1) >> 1, tz = (b.z + 1) >> 1, tw = (b.w + 1) >> 1;
     a.x += tx; a.y += ty; a.z += tz; a.w += tw;
@@ -1187,7 +1190,7 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
         if (++nslow > CLN_SLOW_BUDGET && t0 + 16u * 4u * CLN_SLOW_BUDGET < nmax) return false;      // (wave-uniform; not when the end is near anyway)
         // ---- slow turn: sixteen samples one by one, generic reader, i64 predictor (taps beyond the order are zero)
         int32_t* const ys = reinterpret_cast<int32_t*>(mine);
-        bool wild = false;
+        uint32_t wild = 0u;
 #pragma unroll 1
         for (uint32_t ii = 0; ii < 16u; ++ii) {
             int32_t x = 0;
@@ -1200,10 +1203,10 @@ __device__ __forceinline__ bool cln_body(const clx_buf& buf, LaneReader& r, LRin
             for (int j = 2 * NP - 1; j > 0; --j) H[j] = H[j - 1];
             H[0] = (uint32_t)s;
             const int32_t v = clx_lfinish(s, F);             // (a wave of plain mid/side pairs has no stereo form here: its movers', cln_ms4)
-            wild = wild || cln_ms_wild(s);
+            wild |= cln_ms_wild(s);
             ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
         }
-        if (M.ms && __any(live && wild)) return false;       // (however near the end: the movers' short form is not the reference's out there)
+        if (M.ms && __any(live && (wild >> 31) != 0u)) return false;       // (however near the end: the movers' short form is not the reference's out there)
         cln_done(T, t0);
         ring_ok = false;                                  // the position moved without the ring
     }
@@ -1301,7 +1304,7 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
         int32_t U[2 * NP];
         cln_unpack12<NP>(H, U);
         int32_t* const ys = reinterpret_cast<int32_t*>(mine);
-        bool wild = false;
+        uint32_t wild = 0u;
 #pragma unroll 1
         for (uint32_t ii = 0; ii < 16u; ++ii) {
             int32_t x = 0;
@@ -1314,10 +1317,10 @@ __device__ __forceinline__ bool cln_body24(const clx_buf& buf, LaneReader& r, LR
             for (int j = 2 * NP - 1; j > 0; --j) U[j] = U[j - 1];
             U[0] = s;
             const int32_t v = clx_lfinish(s, F);
-            wild = wild || cln_ms_wild(s);
+            wild |= cln_ms_wild(s);
             ys[((ii >> 2) ^ sw) * 4u + (ii & 3u)] = v;
         }
-        if (M.ms && __any(live && wild)) return false;       // (as cln_body's: the movers' short form is not the reference's out there)
+        if (M.ms && __any(live && (wild >> 31) != 0u)) return false;       // (as cln_body's: the movers' short form is not the reference's out there)
         bool in = true;
 #pragma unroll
         for (int j = 0; j < 2 * NP; ++j) in = in && U[j] < lim && U[j] >= -lim;
@@ -1514,7 +1517,7 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
     LTile T = { 0u, 0u };
     int4* const stage0 = &L.stage[0][0][0];
     const uint32_t sw = ((uint32_t)lane >> 1) & 3u;
-    bool wild = false;                                      // M.ms: a sample outside the range in which cln_ms4 is the reference's step
+    uint32_t wild = 0u;                                     // M.ms: a sample outside the range in which cln_ms4 is the reference's step (bit 31)
 #pragma unroll 1
     for (uint32_t i = 0; i < i0; ++i) {
         const int32_t x = clx_lcareful_raw<OMAX>(S, h, bs, i, n);
@@ -1524,20 +1527,18 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
 #pragma unroll
         for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
-        wild = wild || cln_ms_wild(s);
-        if constexpr (SPLIT) { if ((i & 15u) == 0u) cln_flush<SPLIT>(T, stage0, M, lane); }      // (the 16-bit tier's prologue is ONE tile: i0 = 16 for <= 12 taps)
+        wild |= cln_ms_wild(s);
+        if ((i & 15u) == 0u) cln_flush<SPLIT>(T, stage0, M, lane);
         reinterpret_cast<int32_t*>(cln_mine(stage0, i, lane))[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
         if ((i & 15u) == 15u) cln_done(T, i & ~15u);
     }
-    if (M.ms && __any(n != 0u && wild)) {                  // (a damaged or crafted stream: clx_k_lanes decodes the group, its stereo step is exact for every value)
-        if (lane == 0) taken[bx] = 0u;
-        CLX_STAT(SPLIT ? 11 : 57, 1);
-        return;
-    }
+    // (M.ms and a prologue sample out there -- a damaged or crafted stream: the group is given up below, clx_k_lanes' stereo step is exact for every value)
+    const bool tame = !(M.ms && __any(n != 0u && (wild >> 31) != 0u));
     // ---- steady state
     LRing g;
     g.origin = r.origin; g.fill = 0; g.fs = 0; g.np = 0; g.pa = make_uint4(0u, 0u, 0u, 0u); g.pb = g.pa; g.pc = g.pa;
-    if (i0 < nmax) {
+    bool done = tame;
+    if (tame && i0 < nmax) {
         // what every lane does from here on (the prologue is over: predicted subframes have switched to residuals)
         LKind K;
         K.rice = S.phase == 1u; K.verb = S.phase == 0u;
@@ -1549,7 +1550,6 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
         K.vshm = K.verb ? K.vsh : 0u;
         const bool lv = n != 0u && !S.r.err;
         const int mode = __any(lv && !K.rice) ? 1 : 0;                                    // wave-uniform: the mixed form or the plain one
-        bool done;
         if constexpr (SPLIT) {
             // the split evaluation needs sum|c| < 2^19 (S.lim >= 4096) -- any <= 32 coefficients of <= 15 bits but the all -2^14 row
             if (__any(lv && S.order != 0u && S.lim < 4096)) done = false;
@@ -1560,11 +1560,11 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
             else if (omax <= 8u)         done = cln_run<4>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
             else                         done = cln_run<6>(buf, S, g, &L.ring[0][lane], stage0, n, i0, nmax, K, mode, F, M, T, lane, CR, crc, calm);
         }
-        if (!done) {                                       // given up: clx_k_lanes decodes the group
-            if (lane == 0) taken[bx] = 0u;
-            CLX_STAT(SPLIT ? 11 : 57, 1);
-            return;
-        }
+    }
+    if (!done) {                                           // given up: clx_k_lanes decodes the group
+        if (lane == 0) taken[bx] = 0u;
+        CLX_STAT(SPLIT ? 11 : 57, 1);
+        return;
     }
     cln_flush_all<SPLIT>(T, stage0, M, lane);               // what is still in the stage
     // ---- trailing parameters of empty partitions are part of the stream (they move the next subframe / the CRC)

@@ -189,14 +189,12 @@ __device__ __forceinline__ void clx_store4x16_s(uint64_t base, uint32_t o0, uint
 // the decode loop (the movers' eight row places: eight registers of the 168, some of them spilled).  byte_addr + Ok < 256.
 template <int O0, int O1, int O2, int O3>
 __device__ __forceinline__ void clx_bperm4(uint32_t byte_addr, uint32_t v, uint32_t (&r)[4]) {
-    asm volatile("ds_bpermute_b32 %0, %4, %5 offset:%6\n\tds_bpermute_b32 %1, %4, %5 offset:%7\n\tds_bpermute_b32 %2, %4, %5 offset:%8\n\t"
-                 "ds_bpermute_b32 %3, %4, %5 offset:%9\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(byte_addr), "v"(v), "n"(O0), "n"(O1), "n"(O2), "n"(O3));
+    r[0] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O0), (int)v); r[1] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O1), (int)v);
+    r[2] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O2), (int)v); r[3] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O3), (int)v);
 }
 template <int O0, int O1>
 __device__ __forceinline__ void clx_bperm2(uint32_t byte_addr, uint32_t v, uint32_t (&r)[2]) {
-    asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%4\n\tds_bpermute_b32 %1, %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(byte_addr), "v"(v), "n"(O0), "n"(O1));
+    r[0] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O0), (int)v); r[1] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O1), (int)v);
 }
 __device__ __forceinline__ void clx_store2x16_s(uint64_t base, uint32_t o0, uint32_t o1, const int4& w0, const int4& w1) {
     const clx_i32x4 a = { w0.x, w0.y, w0.z, w0.w }, b = { w1.x, w1.y, w1.z, w1.w };
