@@ -22,8 +22,10 @@ def build(force=False):
            [os.path.join(_DIR, "fake", "clx_intrin.h"), os.path.join(_DIR, "fake", "clx_k2_dot2.h")]
     if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps):
         return _SO
+    tmp = "%s.%d.tmp" % (_SO, os.getpid())                   # (pytest -n: several workers may build at once -- each to its own name, then a rename)
     subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++",
-                           "-I", os.path.join(_DIR, "fake"), "-I", _CSRC, "-o", _SO, os.path.join(_DIR, "sim_lib.cpp")])
+                           "-I", os.path.join(_DIR, "fake"), "-I", _CSRC, "-o", tmp, os.path.join(_DIR, "sim_lib.cpp")])
+    os.replace(tmp, _SO)
     return _SO
 
 
