@@ -1528,6 +1528,8 @@ __device__ __forceinline__ void cln_kernel(LeanLds& L, const clx_run& R, const c
         for (int j = OMAX - 1; j > 0; --j) S.hist[j] = S.hist[j - 1];
         S.hist[0] = s;
         wild |= cln_ms_wild(s);
+        // (the split tier's prologue is up to three tiles long and flushes a pair here; the 16-bit tier's is ONE tile and never does -- the call stays
+        //  all the same: round 6's builds without it faulted on the GPU in clx_k_pool, for no reason found in the code)
         if ((i & 15u) == 0u) cln_flush<SPLIT>(T, stage0, M, lane);
         reinterpret_cast<int32_t*>(cln_mine(stage0, i, lane))[(((i >> 2) & 3u) ^ sw) * 4u + (i & 3u)] = clx_lfinish(s, F);
         if ((i & 15u) == 15u) cln_done(T, i & ~15u);

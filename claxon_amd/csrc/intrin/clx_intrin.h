@@ -184,9 +184,10 @@ __device__ __forceinline__ void clx_store4x16_s(uint64_t base, uint32_t o0, uint
                  "global_store_dwordx4 %3, %7, %8" CLX_STORE_POLICY "\n\ts_nop 1"
                  :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(a), "v"(b), "v"(c), "v"(d), "s"(base) : "memory");
 }
-// Four (two) ds_bpermute_b32 off ONE address register: r[k] = the value of v in lane (byte_addr + Ok) / 4.  The offsets are instruction fields;
-// the compiler's own form of __shfl(v, lane term + constant) computes an address register per read and keeps all of them alive across
-// the decode loop (the movers' eight row places: eight registers of the 168, some of them spilled).  byte_addr + Ok < 256.
+// Four (two) ds_bpermute_b32 off ONE address register: r[k] = the value of v in lane (byte_addr + Ok) / 4, byte_addr + Ok < 256.  Written as
+// address + constant the constant becomes the instruction's offset field; __shfl(v, lane term + constant) masks the lane number first, and the
+// compiler then computes an address register per read and keeps all of them alive across the decode loop (the movers' eight row places: eight
+// registers of the 168, some of them spilled).
 template <int O0, int O1, int O2, int O3>
 __device__ __forceinline__ void clx_bperm4(uint32_t byte_addr, uint32_t v, uint32_t (&r)[4]) {
     r[0] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O0), (int)v); r[1] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O1), (int)v);
@@ -195,11 +196,6 @@ __device__ __forceinline__ void clx_bperm4(uint32_t byte_addr, uint32_t v, uint3
 template <int O0, int O1>
 __device__ __forceinline__ void clx_bperm2(uint32_t byte_addr, uint32_t v, uint32_t (&r)[2]) {
     r[0] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O0), (int)v); r[1] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byte_addr + (uint32_t)O1), (int)v);
-}
-__device__ __forceinline__ void clx_store2x16_s(uint64_t base, uint32_t o0, uint32_t o1, const int4& w0, const int4& w1) {
-    const clx_i32x4 a = { w0.x, w0.y, w0.z, w0.w }, b = { w1.x, w1.y, w1.z, w1.w };
-    asm volatile("global_store_dwordx4 %0, %2, %4" CLX_STORE_POLICY "\n\tglobal_store_dwordx4 %1, %3, %4" CLX_STORE_POLICY "\n\ts_nop 1"
-                 :: "v"(o0), "v"(o1), "v"(a), "v"(b), "s"(base) : "memory");
 }
 __device__ __forceinline__ void clx_store1x16_s(uint64_t base, uint32_t o, const int4& w) {
     const clx_i32x4 a = { w.x, w.y, w.z, w.w };

@@ -67,7 +67,6 @@ template <int O0, int O1>
 static inline void clx_bperm2(uint32_t byte_addr, uint32_t v, uint32_t (&r)[2]) {
     r[0] = (uint32_t)__shfl(v, (int)(((byte_addr + O0) >> 2) & 63u), 64); r[1] = (uint32_t)__shfl(v, (int)(((byte_addr + O1) >> 2) & 63u), 64);
 }
-static inline void clx_store2x16_s(uint64_t base, uint32_t o0, uint32_t o1, const int4& w0, const int4& w1) { clx_store1x16_s(base, o0, w0); clx_store1x16_s(base, o1, w1); }
 static inline void clx_store4x16_s(uint64_t base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, const int4& w0, const int4& w1, const int4& w2, const int4& w3) {
     clx_store1x16_s(base, o0, w0); clx_store1x16_s(base, o1, w1); clx_store1x16_s(base, o2, w2); clx_store1x16_s(base, o3, w3);
 }
