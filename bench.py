@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--process-group", action="store_true",
                     help="create the process group even when WORLD_SIZE is 1: the barrier and the MAX / SUM / all_gather reductions then go "
                          "through the backend (RCCL on device tensors with --backend nccl) on the one GPU that is there")
+    ap.add_argument("--spaced-figure", action="store_true",
+                    help="internal: print the secondary figure of the same steps with the frames' output blocks spaced apart (config.spaced_output_blocks) and nothing else")
     ap.add_argument("--pcm16-figure", action="store_true",
                     help="internal: only the CLX_OUT_PCM16 secondary figure of this workload, as one JSON object (the default line runs this in a "
                          "process of its own: the figure depends on which hardware queues the batch's streams get, i.e. on what ran before it)")
@@ -154,6 +156,10 @@ def main():
     with_crc = (not w.bare_subframes) and not args.no_crc
     if args.pcm16_figure:
         fig = _pcm16_from_the_decode(torch, ctx, cx, w, descs, d_arena, dev, args.steps, args.repeats, with_crc, path)
+        _emit(json.dumps(fig))
+        return
+    if args.spaced_figure:
+        fig = _spaced_output_blocks(torch, ctx, cx, w, descs, d_arena, dev, args.steps, args.repeats, with_crc, path)
         _emit(json.dumps(fig))
         return
     batch = ctx.plan(descs, w.out_offs, verify_crc=with_crc, path=path)
@@ -409,6 +415,10 @@ def main():
         fig = _pcm16_subprocess(args)
         if fig is not None:
             cfg["pcm16_from_the_decode" if fig.get("sample_bytes", 2) == 2 else "pcm24_from_the_decode"] = fig
+        if w.pcm is not None and len(set((w.channels.astype(np.int64) * w.block_sizes.astype(np.int64)).tolist())) == 1:
+            fig = _pcm16_subprocess(args, "--spaced-figure")
+            if fig is not None:
+                cfg["spaced_output_blocks"] = fig
     if rank == 0 and not args.no_cpu_baseline:
         # (at N > 1 too, on rank 0's share, behind the timed regions: north_star wants the CPU path timed in the same run at every N;
         #  the other ranks wait at the end)
@@ -477,9 +487,52 @@ def _pcm16_from_the_decode(torch, ctx, cx, w, descs, d_arena, dev, steps, repeat
                     "steps, measured in a process of its own; secondary -- `value` is planar i32, Claxon's Block" % sb}
 
 
-def _pcm16_subprocess(args):
+def _spaced_output_blocks(torch, ctx, cx, w, descs, d_arena, dev, steps, repeats, with_crc, path, pad=96):
+    """The same consecutive steps with every frame's output block `pad` samples further from its neighbour than it has to be (the caller's choice:
+    out_sample_offsets).  `value`'s layout puts the frames' blocks one behind the other, so every row of a store instruction of the decode waves starts
+    a multiple of 16 KiB from the next -- a stride that does not spread over the memory channels; 384 bytes between the blocks do (tools/layout_probe.py:
+    0, 128, 256, 384, 640, 4 224 bytes measured).  A secondary figure, never `value`: what INTEGRATION.md tells a binder about laying a batch out."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    size = int(w.channels[0]) * int(w.block_sizes[0])                       # (the caller made sure every frame has this many samples)
+    offs = np.asarray(w.out_offs, dtype=np.uint64) + np.arange(w.n, dtype=np.uint64) * np.uint64(pad)
+    assert np.array_equal(np.asarray(w.out_offs, dtype=np.uint64), np.arange(w.n, dtype=np.uint64) * np.uint64(size))
+    total = w.n * (size + pad)
+    bp = ctx.plan(descs, offs, verify_crc=with_crc, path=path & (cx.COMPOSE | cx.NO_COMPOSE | cx.POOL))
+    depth = bp.submit_depth
+    arenas = [d_arena] + [d_arena.clone() for _ in range(depth - 1)]          # (distinct copies of the input, like `value`'s steps)
+    outs = [torch.zeros(total, dtype=torch.int32, device=dev) for _ in range(depth)]
+    ref = torch.from_numpy(w.pcm).to(dev).view(w.n, size)
+    exact_all = lambda bufs: all(bool(torch.equal(torch.as_strided(o, (w.n, size), (size + pad, 1)), ref)) for o in bufs)
+    for i in range(depth):
+        bp.submit(arenas[i % depth].data_ptr(), w.arena_len, outs[i].data_ptr(), stream)
+    bp.flush(stream); torch.cuda.synchronize()
+    if not (exact_all(outs) and bool(np.all(bp.results()["status"] == 0))):
+        bp.close()
+        raise RuntimeError("bench: the spaced output layout is not bit-exact")
+    for o in outs:
+        o.zero_()
+    regs = []
+    for _ in range(max(1, repeats)):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            bp.submit(arenas[i % depth].data_ptr(), w.arena_len, outs[i % depth].data_ptr(), stream)
+        bp.flush(stream); torch.cuda.synchronize(); regs.append(time.perf_counter() - t0)
+    exact = exact_all(outs[:min(steps, depth)])                              # (what the TIMED steps wrote)
+    bp.close(); del outs
+    if not exact:
+        raise RuntimeError("bench: the spaced output layout of the timed steps is not bit-exact")
+    ms_p = 1e3 * float(np.median(regs)) / steps
+    alg = w.compressed_bytes + 4 * w.total_samples
+    return {"value": round(w.total_samples / (ms_p * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms_p, 4), "steps": steps,
+            "pad_samples": pad, "bit_exact": True, "frac": round(alg / (ms_p * 1e-3) / 1e9 / PEAK_GBS, 4),
+            "note": "the same steps, every frame's output block %d bytes further from its neighbour (out_sample_offsets: the caller's choice) -- `value`'s frames lie one "
+                    "behind the other, 16 KiB from row to row, which does not spread over the memory channels; checked frame by frame before and after the timed "
+                    "steps, measured in a process of its own; secondary, never `value`" % (4 * pad)}
+
+
+def _pcm16_subprocess(args, which="--pcm16-figure"):
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--pcm16-figure", "--steps", str(args.steps), "--repeats", str(args.repeats),
+    cmd = [sys.executable, os.path.abspath(__file__), which, "--steps", str(args.steps), "--repeats", str(args.repeats),
            "--workload", args.workload, "--frames", str(args.frames), "--total-frames", str(args.total_frames), "--unique", str(args.unique),
            "--shard-of", str(args.shard_of), "--shard-rank", str(args.shard_rank), "--compose", args.compose, "--devices", args.devices]
     if args.no_crc:
