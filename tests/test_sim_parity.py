@@ -58,7 +58,9 @@ def test_sim_truncations(oracle, sim):
 
 
 def test_sim_bitflips(oracle, sim):
-    seen = pc.check_bitflips(oracle, sim, n_frames=24, trials=20)      # same cases as the GPU test
+    # (the GPU test's cases are 24 frames x 20 flips; half of the flips here keep the CPU suite, which runs the simulator's fibers one wave at a
+    #  time, inside a few minutes -- tools/stress_sim.py and tools/stress_gpu.py run thousands)
+    seen = pc.check_bitflips(oracle, sim, n_frames=24, trials=10)
     assert len(seen) >= 5
 
 
